@@ -1,0 +1,347 @@
+"""Generates tests/golden/*.npz by executing the reference's own modules.
+
+TEST INFRASTRUCTURE ONLY.  Run in the build container, where /root/reference
+exists:
+
+    python oracle/make_goldens.py
+
+The reference's source files are read and executed IN PLACE (never copied) on
+the NumPy TF-1.4 stand-in `oracle/tf1_numpy_shim.py`; only inputs and outputs
+(data) are written to `tests/golden/`.  The fixtures travel to the GPU box, this
+script's dependency on /root/reference does not (no test imports this file).
+
+Every fixture stores the inputs, the projection matrix the reference computed
+(so every implementation consumes the same `M`), and the reference's outputs.
+For forward_splat the per-pixel scatter indices / updates of the weight splat
+are captured from the reference's own tf.scatter_nd calls (sampling.py:278).
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import tf1_numpy_shim as tf  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), 'tests', 'golden')
+T = tf.Tensor
+
+
+def f32(x):
+  return np.asarray(x, dtype=np.float32)
+
+
+def smooth_noise(rs, shape, radius):
+  """Box-blurred uniform noise along the two spatial axes (H, W = axes -2,-1)."""
+  x = rs.rand(*shape).astype(np.float64)
+  for ax in (-2, -1):
+    acc = np.zeros_like(x)
+    for d in range(-radius, radius + 1):
+      acc += np.roll(x, d, axis=ax)
+    x = acc / (2 * radius + 1)
+  x = (x - x.min()) / (x.max() - x.min() + 1e-12)
+  return x.astype(np.float32)
+
+
+def rot_xyz(ax, ay, az):
+  cx, sx, cy, sy, cz, sz = (np.cos(ax), np.sin(ax), np.cos(ay), np.sin(ay),
+                            np.cos(az), np.sin(az))
+  rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+  ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+  rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+  return (rz @ ry @ rx).astype(np.float32)
+
+
+def kitti_cams(b, h, w, tx=-0.532):
+  k = f32([[0.58 * w, 0, w / 2.0], [0, 0.58 * w, h / 2.0], [0, 0, 1]])
+  k = np.broadcast_to(k, (b, 3, 3)).copy()
+  rot = np.broadcast_to(np.eye(3, dtype=np.float32), (b, 3, 3)).copy()
+  t = np.broadcast_to(f32([[tx], [0], [0]]), (b, 3, 1)).copy()
+  return k, k.copy(), rot, t
+
+
+def synth_cams(rs, b, h, w, ang=0.15, tr=0.4, tz=0.2):
+  k = f32([[w, 0, w / 2.0], [0, h, h / 2.0], [0, 0, 1]])
+  k = np.broadcast_to(k, (b, 3, 3)).copy()
+  rot = np.stack([rot_xyz(*(rs.uniform(-ang, ang, 3))) for _ in range(b)])
+  t = np.stack([
+      f32([[rs.uniform(-tr, tr)], [rs.uniform(-tr, tr)],
+           [rs.uniform(-tz, tz)]]) for _ in range(b)
+  ])
+  return k, k.copy(), f32(rot), f32(t)
+
+
+def run_forward_splat(mods, name, tex, mask, disp, k_s, k_t, rot, t, s, bg,
+                      max_disp, zbuf):
+  ldi = mods['lsi.geometry.ldi']
+  helpers = mods['lsi.nnutils.helpers']
+  proj = mods['lsi.geometry.projection']
+  nl, b, h, w, _ = tex.shape
+  pc = helpers.pixel_coords(b, h, w)
+  mat = proj.forward_projection_matrix(T(k_s), T(k_t), T(rot), T(t)).a
+  out = {
+      'tex': tex, 'mask': mask, 'disp': disp, 'k_s': k_s, 'k_t': k_t,
+      'rot': rot, 't': t, 'M': mat,
+      'params': np.array([s, bg, max_disp, zbuf], dtype=np.float64),
+  }
+  for compose in (True, False):
+    tf.SCATTER_LOG = []
+    img, wts, dsp = ldi.forward_splat(
+        [T(tex), T(mask), T(disp)], pc, T(k_s), T(k_t), T(rot), T(t),
+        compose_layers=compose, compute_trg_disp=True, trg_downsampling=s,
+        bg_layer_disp=bg, max_disp=max_disp, zbuf_scale=zbuf)
+    log = tf.SCATTER_LOG
+    tf.SCATTER_LOG = None
+    tag = 'compose' if compose else 'indep'
+    out[tag + '_img'] = img.a
+    out[tag + '_wts'] = wts.a
+    out[tag + '_disp'] = dsp.a
+    if compose:
+      # 20 scatter_nd per layer: 12 (rgb) + 4 (weights) + 4 (disp); take the
+      # weight splat's four corners tl,tr,bl,br.
+      assert len(log) == 20 * nl, len(log)
+      p = log[0][2] // b
+      idx4 = np.zeros((nl, b, h * w, 4), np.int32)
+      upd4 = np.zeros((nl, b, h * w, 4), np.float32)
+      off = (np.arange(b, dtype=np.int32) * p)[:, None]
+      for l in range(nl):
+        for k in range(4):
+          flat, upd, _ = log[20 * l + 12 + k]
+          idx4[l, :, :, k] = flat.reshape(b, h * w) - off
+          upd4[l, :, :, k] = upd.reshape(b, h * w)
+      out['idx4'] = idx4
+      out['upd4'] = upd4
+  np.savez_compressed(os.path.join(OUT, 'fs_%s.npz' % name), **out)
+  print('fs_%s' % name, 'img mean', out['compose_img'].mean())
+
+
+def make_forward_splat(mods):
+  rs = np.random.RandomState(1234)
+
+  # BASELINE config 1: synthetic 1-layer 64x64 batch 2, s = 0.5.
+  nl, b, h, w = 1, 2, 64, 64
+  k_s, k_t, rot, t = synth_cams(rs, b, h, w)
+  tex = rs.rand(nl, b, h, w, 3).astype(np.float32)
+  disp = (0.28 + 0.22 * smooth_noise(rs, (nl, b, h, w), 3))[..., None]
+  mask = np.ones((nl, b, h, w, 1), np.float32)
+  run_forward_splat(mods, 'cfg1_synth_L1_64', tex, mask, f32(disp), k_s, k_t,
+                    rot, t, 0.5, 0.2, 1.0, 50)
+
+  # KITTI-like rectified stereo, 2 layers, s = 0.5 (BASELINE config 2 shape,
+  # shrunk).
+  nl, b, h, w = 2, 2, 32, 96
+  k_s, k_t, rot, t = kitti_cams(b, h, w)
+  tex = rs.rand(nl, b, h, w, 3).astype(np.float32)
+  sm = smooth_noise(rs, (nl, b, h, w), 4)
+  scale = np.array([1.0, 0.5], np.float32).reshape(nl, 1, 1, 1)
+  disp = (0.4 * sm * scale)[..., None]
+  mask = np.ones((nl, b, h, w, 1), np.float32)
+  run_forward_splat(mods, 'kitti_L2_s05', tex, mask, f32(disp), k_s, k_t, rot,
+                    t, 0.5, 1e-3, 0.4, 50)
+
+  # The trg->src direction used by the training loss (ldi_enc_dec.py:322-334):
+  # swapped intrinsics, inverse pose; 1 layer, s = 1, iid disparities.
+  nl, b, h, w = 1, 2, 24, 40
+  k_s, k_t, rot, t = kitti_cams(b, h, w)
+  tex = rs.rand(nl, b, h, w, 3).astype(np.float32)
+  disp = (0.4 * rs.rand(nl, b, h, w, 1)).astype(np.float32)
+  mask = np.ones((nl, b, h, w, 1), np.float32)
+  inv_rot = np.transpose(rot, (0, 2, 1)).copy()
+  inv_t = -np.matmul(inv_rot, t)
+  run_forward_splat(mods, 'kitti_inv_L1_s1', tex, mask, disp, k_t, k_s,
+                    inv_rot, f32(inv_t), 1, 1e-3, 0.4, 50)
+
+  # General pose (rotation + 3-D translation), 3 layers, soft masks.
+  nl, b, h, w = 3, 2, 32, 32
+  k_s, k_t, rot, t = synth_cams(rs, b, h, w, ang=0.2, tr=0.5, tz=0.3)
+  tex = rs.rand(nl, b, h, w, 3).astype(np.float32)
+  disp = (0.2 + 0.5 * rs.rand(nl, b, h, w, 1)).astype(np.float32)
+  mask = rs.rand(nl, b, h, w, 1).astype(np.float32)
+  run_forward_splat(mods, 'general_L3_s05', tex, mask, disp, k_s, k_t, rot, t,
+                    0.5, 0.2, 1.0, 50)
+
+  # Edge cases: disparities <= 0 and > max_disp, points behind the camera
+  # (normaliser <= 0), exact-zero normaliser, far out-of-image projections.
+  nl, b, h, w = 2, 1, 16, 24
+  k = f32([[w, 0, w / 2.0], [0, h, h / 2.0], [0, 0, 1]])[None]
+  rot = rot_xyz(0.05, -0.1, 0.02)[None]
+  t = f32([[0.3], [-0.2], [-2.0]])[None]
+  tex = rs.rand(nl, b, h, w, 3).astype(np.float32)
+  disp = rs.uniform(-0.3, 1.6, (nl, b, h, w, 1)).astype(np.float32)
+  disp[0, 0, 0, :4, 0] = 0.0
+  disp[1, 0, 3, 5, 0] = 1e6
+  disp[1, 0, 4, 5, 0] = -1e6
+  mask = (rs.rand(nl, b, h, w, 1) > 0.2).astype(np.float32)
+  run_forward_splat(mods, 'edge_L2_s05', tex, mask, disp, k, k.copy(), rot, t,
+                    0.5, 0.0, 1.0, 10)
+
+
+def make_known_answers(mods):
+  samp = mods['lsi.geometry.sampling']
+  helpers = mods['lsi.nnutils.helpers']
+  out = {}
+  one = T(np.ones((1, 1, 1, 1), np.float32))
+
+  def one_px(x, y):
+    return samp.splat(one, T(f32([[[[x, y]]]])),
+                      T(np.zeros((1, 4, 4, 1), np.float32))).a[0, :, :, 0]
+
+  pts = [(1.75, 2.25), (0.2, 0.5), (4.2, 3.5), (1.5005, 1.5), (-7.0, 1.5),
+         (1e9, 1.5), (4.5, 1.5)]
+  out['splat_pts'] = f32(pts)
+  out['splat_canvases'] = np.stack([one_px(*p) for p in pts])
+  two = T(np.ones((1, 1, 2, 1), np.float32))
+  out['splat_two_same'] = samp.splat(
+      two, T(f32([[[[2.5, 2.5], [2.5, 2.5]]]])),
+      T(np.zeros((1, 4, 4, 1), np.float32))).a[0, :, :, 0]
+  zin = f32([-.1, 0, .0025, .5, 1, 1.3])
+  out['zbuf_in'] = zin
+  out['zbuf_out_50'] = helpers.zbuffer_weights(T(zin), 50).a
+  out['zbuf_out_10'] = helpers.zbuffer_weights(T(zin), 10).a
+  out['bg_wt_kitti'] = helpers.zbuffer_weights(1e-3 / 0.4, scale=50).a
+  out['bg_wt_synth'] = helpers.zbuffer_weights(2e-1 / 1.0, scale=50).a
+  out['divsafe_num'] = f32([1, 1, -1, 0])
+  out['divsafe_den'] = f32([0, 2, 0, 0])
+  out['divsafe_out'] = helpers.divide_safe(T(out['divsafe_num']),
+                                           T(out['divsafe_den'])).a
+  out['pixel_coords_2_3_5'] = helpers.pixel_coords(2, 3, 5).a
+  # scatter_add_tensor / batch_scatter_add_tensor
+  rs = np.random.RandomState(7)
+  init = rs.rand(3, 11).astype(np.float32)
+  idx = rs.randint(0, 11, (3, 20)).astype(np.int32)
+  upd = rs.rand(3, 20).astype(np.float32)
+  out['bsa_init'], out['bsa_idx'], out['bsa_upd'] = init, idx, upd
+  out['bsa_out'] = samp.batch_scatter_add_tensor(T(init), T(idx), T(upd)).a
+  out['sa_out'] = samp.scatter_add_tensor(T(init[0]), T(idx[0][:, None]),
+                                          T(upd[0])).a
+  np.savez_compressed(os.path.join(OUT, 'known_answers.npz'), **out)
+  print('known_answers', out['splat_canvases'][0])
+
+
+def make_bilinear(mods):
+  samp = mods['lsi.geometry.sampling']
+  rs = np.random.RandomState(11)
+  imgs = rs.rand(2, 9, 12, 3).astype(np.float32)
+  coords = np.stack([rs.uniform(-2, 14, (2, 7, 8)),
+                     rs.uniform(-2, 11, (2, 7, 8))], -1).astype(np.float32)
+  coords[0, 0, 0] = [0.5, 0.5]
+  coords[0, 0, 1] = [11.5, 8.5]
+  coords[0, 0, 2] = [12.0, 9.0]
+  coords[0, 0, 3] = [0.0, 0.0]
+  out = {'imgs': imgs, 'coords': coords,
+         'out': samp.bilinear(T(imgs), T(coords)).a}
+  imgs5 = rs.rand(2, 3, 6, 7, 4).astype(np.float32)
+  coords5 = np.stack([rs.uniform(-1, 8, (2, 3, 5, 4)),
+                      rs.uniform(-1, 7, (2, 3, 5, 4))], -1).astype(np.float32)
+  out['imgs5'], out['coords5'] = imgs5, coords5
+  out['out5'] = samp.bilinear_wrapper(T(imgs5), T(coords5)).a
+  np.savez_compressed(os.path.join(OUT, 'bilinear.npz'), **out)
+  print('bilinear', out['out'].mean())
+
+
+def make_layers(mods):
+  layers = mods['lsi.geometry.layers']
+  hom = mods['lsi.geometry.homography']
+  helpers = mods['lsi.nnutils.helpers']
+  proj = mods['lsi.geometry.projection']
+  rs = np.random.RandomState(21)
+  nl, b, h, w = 3, 2, 10, 12
+  imgs = rs.rand(nl, b, h, w, 3).astype(np.float32)
+  masks = (rs.rand(nl, b, h, w, 1) > 0.4).astype(np.float32)
+  dmaps = rs.uniform(-0.1, 1.0, (nl, b, h, w, 1)).astype(np.float32)
+  out = {'imgs': imgs, 'masks': masks, 'dmaps': dmaps}
+  out['compose_hard'] = layers.compose(T(imgs), T(masks), T(dmaps)).a
+  out['compose_soft'] = layers.compose(T(imgs), T(masks), T(dmaps), soft=True,
+                                       min_disp=1e-3,
+                                       depth_softmax_temp=0.4).a
+  out['compose_depth'] = layers.compose_depth(T(masks), T(dmaps)).a
+  out['compose_depth_bg'] = layers.compose_depth(
+      T(masks), T(dmaps), bg_layer=True, min_disp=1e-3,
+      depth_softmax_temp=0.4).a
+  out['soft_z'] = helpers.soft_z_buffering(T(masks), T(dmaps), 0.4).a
+  out['enforce_bg'] = helpers.enforce_bg_occupied(T(masks)).a
+
+  # planar_transform + the homography pieces: 2 planes, batch 2, 16x20.
+  nl, b, h, w = 2, 2, 16, 20
+  k_s, k_t, rot, t = synth_cams(rs, b, h, w, ang=0.1, tr=0.3, tz=0.1)
+  pimgs = rs.rand(nl, b, h, w, 3).astype(np.float32)
+  pmasks = (rs.rand(nl, b, h, w, 1) > 0.3).astype(np.float32)
+  n_hat = rs.normal(size=(nl, b, 1, 3)).astype(np.float32)
+  n_hat[..., 2] = np.abs(n_hat[..., 2]) + 2.0
+  n_hat /= np.linalg.norm(n_hat, axis=-1, keepdims=True)
+  a = rs.uniform(-3.5, -2.0, (nl, b, 1, 1)).astype(np.float32)
+  pc = helpers.pixel_coords(b, h, w)
+  ti, tm, td = layers.planar_transform(T(pimgs), T(pmasks), pc, T(k_s), T(k_t),
+                                       T(rot), T(t), T(n_hat), T(a))
+  out.update(p_imgs=pimgs, p_masks=pmasks, p_k_s=k_s, p_k_t=k_t, p_rot=rot,
+             p_t=t, p_n_hat=n_hat, p_a=a, p_out_imgs=ti.a, p_out_masks=tm.a,
+             p_out_dmaps=td.a)
+  out['inv_hom'] = hom.inv_homography(T(k_s), T(k_t), T(rot), T(t),
+                                      T(n_hat[0]), T(a[0])).a
+  out['inv_hom_dmat'] = hom.inv_homography_dmat(T(k_t), T(rot), T(t),
+                                                T(n_hat[0]), T(a[0])).a
+  nt, at = hom.transform_plane_eqns(T(rot), T(t), T(n_hat[0]), T(a[0]))
+  out['plane_n_t'], out['plane_a_t'] = nt.a, at.a
+  out['fwd_mat'] = proj.forward_projection_matrix(T(k_s), T(k_t), T(rot),
+                                                  T(t)).a
+  out['inv_mat'] = proj.inverse_projection_matrix(T(k_s), T(k_t), T(rot),
+                                                  T(t)).a
+  np.savez_compressed(os.path.join(OUT, 'layers.npz'), **out)
+  print('layers', out['compose_hard'].mean(), out['p_out_imgs'].mean())
+
+
+def make_disocclusion(mods):
+  proj = mods['lsi.geometry.projection']
+  helpers = mods['lsi.nnutils.helpers']
+  rs = np.random.RandomState(31)
+  b, h, w = 2, 20, 28
+  k_s, k_t, rot, t = synth_cams(rs, b, h, w, ang=0.08, tr=0.3, tz=0.1)
+  ds = (0.3 + 0.2 * smooth_noise(rs, (b, h, w), 2))[..., None]
+  dt = (0.3 + 0.2 * smooth_noise(rs, (b, h, w), 2))[..., None]
+  mat = proj.forward_projection_matrix(T(k_s), T(k_t), T(rot), T(t))
+  pc = helpers.pixel_coords(b, h, w)
+  mask = proj.disocclusion_mask(T(f32(ds)), T(f32(dt)), pc, mat).a
+  np.savez_compressed(os.path.join(OUT, 'disocclusion.npz'), disps_src=f32(ds),
+                      disps_trg=f32(dt), M=mat.a, mask=mask)
+  print('disocclusion', mask.mean())
+
+
+def make_losses(mods):
+  loss = mods['lsi.loss.loss']
+  ldi = mods['lsi.geometry.ldi']
+  rs = np.random.RandomState(41)
+  nl, b, h, w = 3, 2, 12, 16
+  imgs = rs.rand(nl, b, h, w, 3).astype(np.float32)
+  masks = rs.rand(nl, b, h, w, 1).astype(np.float32)
+  disps = (0.4 * rs.rand(nl, b, h, w, 1)).astype(np.float32)
+  trg = rs.rand(b, h, w, 3).astype(np.float32)
+  out = {'imgs': imgs, 'masks': masks, 'disps': disps, 'trg': trg}
+  out['zbuf_comp_loss'] = loss.zbuffer_composition_loss(
+      T(imgs), T(masks), T(disps), T(trg), bg_layer_disp=1e-3, max_disp=0.4,
+      zbuf_scale=50).a
+  out['decr_disp_loss'] = loss.decreasing_disp_loss(T(disps)).a
+  out['decr_disp_loss_L1'] = np.float32(loss.decreasing_disp_loss(T(disps[:1])))
+  out['smooth_loss'] = ldi.disp_smoothness_loss(T(disps)).a
+  dx, dy = ldi.gradient(T(disps))
+  out['grad_dx'], out['grad_dy'] = dx.a, dy.a
+  np.savez_compressed(os.path.join(OUT, 'losses.npz'), **out)
+  print('losses', out['zbuf_comp_loss'], out['decr_disp_loss'],
+        out['smooth_loss'])
+
+
+def main():
+  os.makedirs(OUT, exist_ok=True)
+  mods = tf.load_reference()
+  make_known_answers(mods)
+  make_forward_splat(mods)
+  make_bilinear(mods)
+  make_layers(mods)
+  make_disocclusion(mods)
+  make_losses(mods)
+  total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
+  print('wrote %d bytes under %s' % (total, OUT))
+
+
+if __name__ == '__main__':
+  main()
