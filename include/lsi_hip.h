@@ -1,0 +1,204 @@
+/*
+ * lsi_hip.h -- C ABI of liblsi_hip.so, the MI355X (gfx950) implementation of
+ * the layered-depth-image renderer hot path of google/layered-scene-inference.
+ *
+ * The reference has no FFI/plugin interface of its own: the boundary it offers
+ * is the Python function surface of lsi.geometry.* / lsi.nnutils.helpers
+ * (SURVEY.md section 8b).  Each entry point below names the reference
+ * function(s) (paths relative to /root/reference) whose arithmetic it replaces;
+ * the Python mirror in layered-scene-inference_amd/lsi/ binds them with ctypes
+ * (binding shown in INTEGRATION.md).
+ *
+ * Conventions
+ *   - plain C: POD structs, raw device pointers, sizes; no C++/torch types.
+ *   - every function returns LSI_OK (0) or a negative LSI_E* code, never throws,
+ *     never allocates device memory, never synchronises the host.
+ *   - all pointers are DEVICE pointers valid on the device the stream belongs
+ *     to; work is enqueued on `stream` (a hipStream_t passed as void*; NULL =
+ *     the legacy default stream) and the call returns immediately.
+ *   - tensors are fp32.  Inputs carry explicit ELEMENT strides so that both the
+ *     reference's channels-last L x B x H x W x C layout and planar (permuted
+ *     NCHW) conv outputs are consumed without a copy.  Outputs are contiguous
+ *     in the reference's logical shape.
+ *   - pixel centres are at +0.5 (helpers.py:107-110); coordinates are (x, y).
+ *   - the library keeps no state between calls.
+ */
+#ifndef LSI_HIP_H_
+#define LSI_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LSI_VERSION 100 /* 0.1.0 */
+
+/* error codes */
+#define LSI_OK 0
+#define LSI_EINVAL -1        /* bad shape / stride / flag combination        */
+#define LSI_ENULL -2         /* required pointer is NULL                      */
+#define LSI_EWORKSPACE -3    /* workspace too small                           */
+#define LSI_ELAUNCH -4       /* kernel launch failed (hipGetLastError != 0)   */
+#define LSI_EUNSUPPORTED -5  /* valid request this build does not implement   */
+
+/* LsiSplatDesc.flags */
+#define LSI_COMPOSE 1u       /* compose_layers=True  (ldi.py:167-171)         */
+#define LSI_WANT_DISP 2u     /* compute_trg_disp=True (ldi.py:179-180)        */
+#define LSI_HAS_MASK 4u      /* mask pointer is given (else mask == 1)        */
+
+/* LsiSplatDesc.path: which kernel family renders the splat.                  */
+#define LSI_PATH_AUTO 0      /* library decides from the descriptor          */
+#define LSI_PATH_ATOMIC 1    /* source-parallel, global fp32 atomics; any M   */
+#define LSI_PATH_ROWBAND 2   /* target-row-band tiles accumulated in LDS;     */
+                             /* requires M[b][1][3] == M[b][2][3] == 0 for    */
+                             /* every b (target row independent of disparity, */
+                             /* e.g. rectified stereo) -- see rowband_ok.     */
+
+typedef void* lsi_stream_t; /* hipStream_t */
+
+/*
+ * Descriptor of one forward_splat call (ldi.py:71-182).
+ *   tex  [l,b,y,x,c]  c in 0..2     element strides tex_s{l,b,y,x,c}
+ *   disp [l,b,y,x]                  element strides disp_s{l,b,y,x}
+ *   mask [l,b,y,x]   (optional)     element strides mask_s{l,b,y,x}
+ * Ht = H * trg_downsampling and Wt = W * trg_downsampling must be integral
+ * (the reference only works then: ldi.py:113-125).
+ */
+typedef struct LsiSplatDesc {
+  int32_t L, B, H, W, Ht, Wt;
+  int64_t tex_sl, tex_sb, tex_sy, tex_sx, tex_sc;
+  int64_t disp_sl, disp_sb, disp_sy, disp_sx;
+  int64_t mask_sl, mask_sb, mask_sy, mask_sx;
+  float trg_downsampling; /* s                                              */
+  float max_disp;
+  float zbuf_scale;
+  float bg_wt;            /* lsi_bg_weight(bg_layer_disp, max_disp, scale)   */
+  uint32_t flags;
+  int32_t path;
+  /* ROWBAND only: set by the caller from a host copy of M (lsi_rowband_ok). */
+  int32_t reserved0, reserved1;
+} LsiSplatDesc;
+
+/* Library version (LSI_VERSION of the build). */
+int lsi_version(void);
+
+/* Human-readable text for an LSI_E* code. */
+const char* lsi_strerror(int code);
+
+/*
+ * Background weight of the white canvas, ldi.py:115-116:
+ *   zbuffer_weights(bg_layer_disp / max_disp, zbuf_scale)   (helpers.py:180-193)
+ * with the python-float division done in double, as the reference does.
+ * Host function (no GPU work).
+ */
+float lsi_bg_weight(double bg_layer_disp, double max_disp, double zbuf_scale);
+
+/*
+ * Host-side test on a HOST copy of the B projection matrices (row-major 4x4):
+ * returns 1 when LSI_PATH_ROWBAND renders this call exactly (target row of a
+ * source pixel does not depend on its disparity and the normaliser is positive
+ * over the whole source image), else 0.
+ */
+int lsi_rowband_ok(const LsiSplatDesc* desc, const float* M_host);
+
+/* Bytes of device workspace lsi_splat_fwd needs for this descriptor. */
+size_t lsi_splat_workspace_bytes(const LsiSplatDesc* desc);
+
+/*
+ * forward_splat, ldi.py:71-182, with its callees fused into the launch:
+ *   projection of every source pixel      helpers.py:116-137 (transform_pts)
+ *   divide_safe                           helpers.py:82-85
+ *   soft z-buffer weight                  helpers.py:180-193
+ *   4-corner bilinear splat x3            sampling.py:171-254
+ *   normalise / compose epilogue          ldi.py:157-182
+ * M is the B x 4 x 4 src->trg matrix (projection.py:71-86), passed as data.
+ * Outputs (contiguous; nl = 1 if LSI_COMPOSE else L):
+ *   out_img  [nl,B,Ht,Wt,3]   out_wts [nl,B,Ht,Wt,1] (un-normalised weight sum)
+ *   out_disp [nl,B,Ht,Wt,1]   required iff LSI_WANT_DISP
+ * mask may be NULL (then LSI_HAS_MASK must be clear).
+ */
+int lsi_splat_fwd(const LsiSplatDesc* desc, const float* tex, const float* disp,
+                  const float* mask, const float* M, float* out_img,
+                  float* out_wts, float* out_disp, void* workspace,
+                  size_t workspace_bytes, lsi_stream_t stream);
+
+/*
+ * Gradient of lsi_splat_fwd w.r.t. tex, disp and mask given the gradients of
+ * out_img (g_img, [nl,B,Ht,Wt,3]) and optionally out_wts (g_wts, may be NULL).
+ * The reference has no hand-written backward (TF autodiff, train_utils.py:113);
+ * this implements the closed form of SURVEY.md section 3.5, reproducing TF's
+ * zero-gradient conventions (floor, comparisons, clamps on the closed interval).
+ * out_img / out_wts are the forward outputs.  g_tex [L,B,H,W,3], g_disp_in
+ * [L,B,H,W], g_mask [L,B,H,W] (NULL unless LSI_HAS_MASK) are contiguous.
+ * Gradients through out_disp are not implemented (it feeds no loss:
+ * ldi_enc_dec.py:302-357) -- LSI_WANT_DISP is ignored here.
+ * workspace: lsi_splat_bwd_workspace_bytes(desc) bytes of device scratch (one
+ * float4 per output pixel: the gradient w.r.t. the un-normalised canvases).
+ */
+size_t lsi_splat_bwd_workspace_bytes(const LsiSplatDesc* desc);
+
+int lsi_splat_bwd(const LsiSplatDesc* desc, const float* tex, const float* disp,
+                  const float* mask, const float* M, const float* out_img,
+                  const float* out_wts, const float* g_img, const float* g_wts,
+                  float* g_tex, float* g_disp_in, float* g_mask,
+                  void* workspace, size_t workspace_bytes, lsi_stream_t stream);
+
+/*
+ * Parity/debug view of the projection stage: for every source pixel the four
+ * flat target indices (tl,tr,bl,br; x + y*Wt within the batch element,
+ * sampling.py:234-241) and the four updates of the weight splat,
+ * zbuffer_weight * mask * corner_weight (ldi.py:145-153, sampling.py:213-232).
+ *   idx4 [L,B,H*W,4] int32      upd4 [L,B,H*W,4] fp32
+ */
+int lsi_project_indices(const LsiSplatDesc* desc, const float* disp,
+                        const float* mask, const float* M, int32_t* idx4,
+                        float* upd4, lsi_stream_t stream);
+
+/*
+ * sampling.splat, sampling.py:171-254: 4-corner bilinear forward scatter-add
+ * of a C-channel image at float coordinates onto an initial canvas.
+ *   src [B,Hs,Ws,C], coords [B,Hs,Ws,2] (x,y), out [B,Ht,Wt,C]; all contiguous.
+ * `out` must already hold init_trg_image; updates are added to it in place.
+ */
+int lsi_splat_generic(int32_t B, int32_t Hs, int32_t Ws, int32_t C, int32_t Ht,
+                      int32_t Wt, const float* src, const float* coords,
+                      float* out, lsi_stream_t stream);
+
+/* Gradients of lsi_splat_generic w.r.t. src and coords (g_out [B,Ht,Wt,C]). */
+int lsi_splat_generic_bwd(int32_t B, int32_t Hs, int32_t Ws, int32_t C,
+                          int32_t Ht, int32_t Wt, const float* src,
+                          const float* coords, const float* g_out, float* g_src,
+                          float* g_coords, lsi_stream_t stream);
+
+/*
+ * sampling.batch_scatter_add_tensor, sampling.py:287-313 (and scatter_add_tensor
+ * :257-284 with B = 1): out[b, idx[b,i]] += upd[b,i]; duplicates add.
+ *   out [B,P] (holds init on entry), idx [B,N] int32 in [0,P), upd [B,N].
+ * Out-of-range indices are skipped (TF raises; the Python mirror checks).
+ */
+int lsi_scatter_add(int32_t B, int64_t P, int64_t N, const int32_t* idx,
+                    const float* upd, float* out, lsi_stream_t stream);
+
+/*
+ * sampling.bilinear (compose=True), sampling.py:41-132: 4-tap gather with zero
+ * outside.  imgs [B,Hs,Ws,C], coords [B,Ht,Wt,2] (x,y), out [B,Ht,Wt,C].
+ */
+int lsi_bilinear_fwd(int32_t B, int32_t Hs, int32_t Ws, int32_t C, int32_t Ht,
+                     int32_t Wt, const float* imgs, const float* coords,
+                     float* out, lsi_stream_t stream);
+
+/*
+ * Gradients of lsi_bilinear_fwd.  g_imgs [B,Hs,Ws,C] must be zero on entry
+ * (scatter-add target); g_coords [B,Ht,Wt,2] may be NULL.
+ */
+int lsi_bilinear_bwd(int32_t B, int32_t Hs, int32_t Ws, int32_t C, int32_t Ht,
+                     int32_t Wt, const float* imgs, const float* coords,
+                     const float* g_out, float* g_imgs, float* g_coords,
+                     lsi_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LSI_HIP_H_ */

@@ -1,0 +1,65 @@
+"""Builds liblsi_hip.so (gfx950) in-tree with hipcc.
+
+    python layered-scene-inference_amd/build.py [--force]
+
+The shared library is plain C ABI (include/lsi_hip.h); it links only the HIP
+runtime.  Cross-compiles without a GPU.  The .so is git-ignored but travels
+with the tree to the GPU box.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, 'csrc')
+SO = os.path.join(PKG, 'liblsi_hip.so')
+SOURCES = ['lsi_splat.hip', 'lsi_sampling.hip', 'lsi_fused.hip']
+HEADERS = [os.path.join(CSRC, 'lsi_common.h'),
+           os.path.join(ROOT, 'include', 'lsi_hip.h')]
+
+HIPCC_FLAGS = [
+    '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC',
+    '-ffp-contract=off',        # index arithmetic must not be FMA-contracted
+    '-munsafe-fp-atomics',      # fp32 atomicAdd -> global_atomic_add_f32/ds_add_f32
+    '-fno-fast-math', '-Wall', '-Wno-unused-function',
+]
+
+
+def hipcc():
+  exe = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+  if not os.path.exists(exe):
+    raise RuntimeError('hipcc not found; ROCm toolchain is required')
+  return exe
+
+
+def _stale(target, deps):
+  if not os.path.exists(target):
+    return True
+  t = os.path.getmtime(target)
+  return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+  srcs = [os.path.join(CSRC, s) for s in SOURCES
+          if os.path.exists(os.path.join(CSRC, s))]
+  objs = []
+  for src in srcs:
+    obj = src[:-4] + '.o'
+    if force or _stale(obj, [src] + HEADERS):
+      cmd = [hipcc()] + HIPCC_FLAGS + ['-c', src, '-o', obj]
+      if verbose:
+        print(' '.join(cmd))
+      subprocess.check_call(cmd)
+    objs.append(obj)
+  if force or _stale(SO, objs):
+    cmd = [hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', SO] + objs
+    if verbose:
+      print(' '.join(cmd))
+    subprocess.check_call(cmd)
+  return SO
+
+
+if __name__ == '__main__':
+  print(build(force='--force' in sys.argv, verbose=True))

@@ -1,0 +1,113 @@
+"""ctypes binding of liblsi_hip.so (C ABI: include/lsi_hip.h).
+
+There is NO fallback: if the shared library is missing, or an op is handed a
+tensor that does not live on a ROCm device, this module raises.  PyTorch is used
+only for device memory, streams and autograd bookkeeping.
+"""
+import ctypes
+import os
+
+import torch
+
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SO_PATH = os.path.join(_PKG, 'liblsi_hip.so')
+
+LSI_OK = 0
+LSI_COMPOSE, LSI_WANT_DISP, LSI_HAS_MASK = 1, 2, 4
+LSI_PATH_AUTO, LSI_PATH_ATOMIC, LSI_PATH_ROWBAND = 0, 1, 2
+
+_c_f = ctypes.POINTER(ctypes.c_float)
+_c_i = ctypes.POINTER(ctypes.c_int32)
+
+
+class LsiSplatDesc(ctypes.Structure):
+  _fields_ = (
+      [(n, ctypes.c_int32) for n in ('L', 'B', 'H', 'W', 'Ht', 'Wt')] +
+      [(n, ctypes.c_int64) for n in (
+          'tex_sl', 'tex_sb', 'tex_sy', 'tex_sx', 'tex_sc',
+          'disp_sl', 'disp_sb', 'disp_sy', 'disp_sx',
+          'mask_sl', 'mask_sb', 'mask_sy', 'mask_sx')] +
+      [(n, ctypes.c_float) for n in (
+          'trg_downsampling', 'max_disp', 'zbuf_scale', 'bg_wt')] +
+      [('flags', ctypes.c_uint32), ('path', ctypes.c_int32),
+       ('reserved0', ctypes.c_int32), ('reserved1', ctypes.c_int32)])
+
+
+# name -> (restype, argtypes); every symbol include/lsi_hip.h declares.
+_I32, _I64, _VP, _SZ = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p, ctypes.c_size_t
+_DP = ctypes.POINTER(LsiSplatDesc)
+SIGNATURES = {
+    'lsi_version': (ctypes.c_int, []),
+    'lsi_strerror': (ctypes.c_char_p, [ctypes.c_int]),
+    'lsi_bg_weight': (ctypes.c_float, [ctypes.c_double] * 3),
+    'lsi_rowband_ok': (ctypes.c_int, [_DP, _VP]),
+    'lsi_splat_workspace_bytes': (_SZ, [_DP]),
+    'lsi_splat_fwd': (ctypes.c_int, [_DP] + [_VP] * 8 + [_SZ, _VP]),
+    'lsi_splat_bwd_workspace_bytes': (_SZ, [_DP]),
+    'lsi_splat_bwd': (ctypes.c_int, [_DP] + [_VP] * 12 + [_SZ, _VP]),
+    'lsi_project_indices': (ctypes.c_int, [_DP] + [_VP] * 6),
+    'lsi_splat_generic': (ctypes.c_int, [_I32] * 6 + [_VP] * 4),
+    'lsi_splat_generic_bwd': (ctypes.c_int, [_I32] * 6 + [_VP] * 6),
+    'lsi_scatter_add': (ctypes.c_int, [_I32, _I64, _I64] + [_VP] * 4),
+    'lsi_bilinear_fwd': (ctypes.c_int, [_I32] * 6 + [_VP] * 4),
+    'lsi_bilinear_bwd': (ctypes.c_int, [_I32] * 6 + [_VP] * 6),
+}
+
+_lib = None
+
+
+def lib():
+  """The loaded shared library; raises if it has not been built."""
+  global _lib
+  if _lib is None:
+    if not os.path.exists(SO_PATH):
+      raise RuntimeError(
+          'liblsi_hip.so is missing (%s). Build it with '
+          '`python layered-scene-inference_amd/build.py`; there is no CPU or '
+          'PyTorch fallback for the lsi HIP ops.' % SO_PATH)
+    handle = ctypes.CDLL(SO_PATH)
+    for name, (res, args) in SIGNATURES.items():
+      fn = getattr(handle, name)  # AttributeError => ABI mismatch, loudly
+      fn.restype = res
+      fn.argtypes = args
+    _lib = handle
+  return _lib
+
+
+def check(rc, what):
+  if rc != LSI_OK:
+    msg = lib().lsi_strerror(rc).decode()
+    raise RuntimeError('%s failed: %s (code %d)' % (what, msg, rc))
+
+
+def require_device(*tensors):
+  """Every tensor must be fp32 on one ROCm device; returns that device."""
+  dev = None
+  for t in tensors:
+    if t is None:
+      continue
+    if not t.is_cuda:
+      raise RuntimeError(
+          'lsi HIP ops need tensors on a ROCm GPU (got device %s); there is no '
+          'CPU fallback' % t.device)
+    if t.dtype != torch.float32 and t.dtype != torch.int32:
+      raise RuntimeError('lsi HIP ops are fp32 (got %s)' % t.dtype)
+    if dev is None:
+      dev = t.device
+    elif t.device != dev:
+      raise RuntimeError('tensors on different devices: %s vs %s' %
+                         (dev, t.device))
+  return dev
+
+
+def ptr(t):
+  return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr(device):
+  return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def bg_weight(bg_layer_disp, max_disp, zbuf_scale):
+  return float(lib().lsi_bg_weight(float(bg_layer_disp), float(max_disp),
+                                   float(zbuf_scale)))

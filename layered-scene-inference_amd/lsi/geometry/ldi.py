@@ -1,0 +1,232 @@
+"""Layered depth images: forward splat renderer and disparity smoothness.
+
+Mirror of the reference's `lsi/geometry/ldi.py` call surface on eager
+torch.Tensors, rendering through liblsi_hip.so (HIP, gfx950).
+
+An LDI is {textures, masks, disps}:
+  textures: L x B x H x W x C   masks: L x B x H x W x 1   disps: L x B x H x W x 1
+(reference ldi.py:18-21).  Any strides are accepted (e.g. a permuted NCHW conv
+output) -- the kernels take element strides, nothing is copied.
+"""
+import ctypes
+
+import torch
+
+from lsi import _C
+from lsi.geometry import projection
+
+
+def gradient(pred):
+  """x and y forward differences (reference ldi.py:33-44). pred: L x B x H x W x C."""
+  dy = pred[:, :, 1:, :, :] - pred[:, :, :-1, :, :]
+  dx = pred[:, :, :, 1:, :] - pred[:, :, :, :-1, :]
+  return dx, dy
+
+
+def disp_smoothness_loss(pred_disp):
+  """Mean absolute second differences (reference ldi.py:47-68)."""
+  dx, dy = gradient(pred_disp)
+  dx2, dxdy = gradient(dx)
+  dydx, dy2 = gradient(dy)
+  return (dx2.abs().mean() + dxdy.abs().mean() + dydx.abs().mean() +
+          dy2.abs().mean())
+
+
+def _desc(tex, mask, disp, ht, wt, s, max_disp, zbuf_scale, bg_wt, flags, path,
+          band_rows=0, threads=0):
+  nl, b, h, w, _ = tex.shape
+  d = _C.LsiSplatDesc()
+  d.L, d.B, d.H, d.W, d.Ht, d.Wt = nl, b, h, w, ht, wt
+  (d.tex_sl, d.tex_sb, d.tex_sy, d.tex_sx, d.tex_sc) = tex.stride()
+  (d.disp_sl, d.disp_sb, d.disp_sy, d.disp_sx) = disp.stride()[:4]
+  if mask is not None:
+    (d.mask_sl, d.mask_sb, d.mask_sy, d.mask_sx) = mask.stride()[:4]
+  d.trg_downsampling, d.max_disp, d.zbuf_scale = s, max_disp, zbuf_scale
+  d.bg_wt = bg_wt
+  d.flags, d.path = flags, path
+  d.reserved0, d.reserved1 = band_rows, threads
+  return d
+
+
+def select_path(desc, mat_host, path='auto'):
+  """Chooses the kernel family.  `mat_host` is a CPU copy of the B x 4 x 4
+  projection matrices (or None => the general atomic path)."""
+  if path == 'atomic':
+    return _C.LSI_PATH_ATOMIC
+  ok = False
+  if mat_host is not None:
+    m = mat_host.contiguous()
+    ok = bool(_C.lib().lsi_rowband_ok(ctypes.byref(desc),
+                                      ctypes.c_void_p(m.data_ptr())))
+  if path == 'rowband':
+    if not ok:
+      raise RuntimeError('rowband path requested but the projection matrices '
+                         'do not satisfy its precondition (lsi_rowband_ok)')
+    return _C.LSI_PATH_ROWBAND
+  return _C.LSI_PATH_ROWBAND if ok else _C.LSI_PATH_ATOMIC
+
+
+class _ForwardSplat(torch.autograd.Function):
+  """lsi_splat_fwd / lsi_splat_bwd (include/lsi_hip.h)."""
+
+  @staticmethod
+  def forward(ctx, tex, mask, disp, mat, mat_host, cfg):
+    dev = _C.require_device(tex, mask, disp, mat)
+    nl, b, h, w, c = tex.shape
+    if c != 3:
+      raise ValueError('forward_splat renders 3-channel textures (got %d)' % c)
+    s = cfg['trg_downsampling']
+    ht, wt = h * s, w * s
+    if ht != int(ht) or wt != int(wt):
+      raise ValueError('H*trg_downsampling and W*trg_downsampling must be '
+                       'integral (reference ldi.py:113-125)')
+    ht, wt = int(ht), int(wt)
+    flags = 0
+    if cfg['compose_layers']:
+      flags |= _C.LSI_COMPOSE
+    if cfg['compute_trg_disp']:
+      flags |= _C.LSI_WANT_DISP
+    if mask is not None:
+      flags |= _C.LSI_HAS_MASK
+    bg_wt = _C.bg_weight(cfg['bg_layer_disp'], cfg['max_disp'],
+                         cfg['zbuf_scale'])
+    desc = _desc(tex, mask, disp, ht, wt, float(s), float(cfg['max_disp']),
+                 float(cfg['zbuf_scale']), bg_wt, flags, 0,
+                 cfg.get('band_rows', 0), cfg.get('threads', 0))
+    desc.path = select_path(desc, mat_host, cfg.get('path', 'auto'))
+    nlo = 1 if cfg['compose_layers'] else nl
+    img = torch.empty((nlo, b, ht, wt, 3), dtype=torch.float32, device=dev)
+    wts = torch.empty((nlo, b, ht, wt, 1), dtype=torch.float32, device=dev)
+    dsp = (torch.empty((nlo, b, ht, wt, 1), dtype=torch.float32, device=dev)
+           if cfg['compute_trg_disp'] else None)
+    lib = _C.lib()
+    ws, ws_bytes = None, 0
+    if desc.path == _C.LSI_PATH_ATOMIC:
+      ws_bytes = int(lib.lsi_splat_workspace_bytes(ctypes.byref(desc)))
+      ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+    mat = mat.contiguous()
+    rc = lib.lsi_splat_fwd(ctypes.byref(desc), _C.ptr(tex), _C.ptr(disp),
+                           _C.ptr(mask), _C.ptr(mat), _C.ptr(img), _C.ptr(wts),
+                           _C.ptr(dsp), _C.ptr(ws), ws_bytes,
+                           _C.stream_ptr(dev))
+    _C.check(rc, 'lsi_splat_fwd')
+    ctx.desc = desc
+    ctx.has_mask = mask is not None
+    ctx.save_for_backward(tex, mask if mask is not None else tex.new_empty(0),
+                          disp, mat, img, wts)
+    if dsp is None:
+      dsp = img.new_empty(0)
+    ctx.mark_non_differentiable(dsp)
+    return img, wts, dsp
+
+  @staticmethod
+  def backward(ctx, g_img, g_wts, _g_dsp):
+    tex, mask, disp, mat, img, wts = ctx.saved_tensors
+    mask = mask if ctx.has_mask else None
+    desc = ctx.desc
+    dev = tex.device
+    nl, b, h, w, _ = tex.shape
+    g_img = g_img.contiguous() if g_img is not None else torch.zeros_like(img)
+    g_wts = g_wts.contiguous() if g_wts is not None else None
+    g_tex = torch.empty((nl, b, h, w, 3), dtype=torch.float32, device=dev)
+    g_disp = torch.empty((nl, b, h, w, 1), dtype=torch.float32, device=dev)
+    g_mask = (torch.empty((nl, b, h, w, 1), dtype=torch.float32, device=dev)
+              if mask is not None else None)
+    lib = _C.lib()
+    ws_bytes = int(lib.lsi_splat_bwd_workspace_bytes(ctypes.byref(desc)))
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+    rc = lib.lsi_splat_bwd(ctypes.byref(desc), _C.ptr(tex), _C.ptr(disp),
+                           _C.ptr(mask), _C.ptr(mat), _C.ptr(img), _C.ptr(wts),
+                           _C.ptr(g_img), _C.ptr(g_wts), _C.ptr(g_tex),
+                           _C.ptr(g_disp), _C.ptr(g_mask), _C.ptr(ws), ws_bytes,
+                           _C.stream_ptr(dev))
+    _C.check(rc, 'lsi_splat_bwd')
+    return g_tex, g_mask, g_disp, None, None, None
+
+
+def forward_splat_matrix(ldi_src, src2trg_mat, compose_layers=True,
+                         compute_trg_disp=False, trg_downsampling=1,
+                         bg_layer_disp=0, max_disp=1, zbuf_scale=10,
+                         mat_host=None, path='auto', band_rows=0, threads=0):
+  """forward_splat with the B x 4 x 4 src->trg projection matrix given as data.
+
+  `mat_host` (optional CPU copy of the matrices) lets the row-band LDS path be
+  selected without a device->host copy; when omitted and `src2trg_mat` is on the
+  GPU it is fetched once (one small synchronising copy).
+  """
+  tex, mask, disp = ldi_src
+  if mat_host is None and path != 'atomic':
+    mat_host = src2trg_mat.detach().to('cpu', torch.float32)
+  mat = src2trg_mat.detach().to(tex.device, torch.float32)
+  cfg = dict(compose_layers=bool(compose_layers),
+             compute_trg_disp=bool(compute_trg_disp),
+             trg_downsampling=trg_downsampling, bg_layer_disp=bg_layer_disp,
+             max_disp=max_disp, zbuf_scale=zbuf_scale, path=path,
+             band_rows=band_rows, threads=threads)
+  img, wts, dsp = _ForwardSplat.apply(tex, mask, disp, mat, mat_host, cfg)
+  if compute_trg_disp:
+    return img, wts, dsp
+  return img, wts
+
+
+def forward_splat(ldi_src,
+                  pixel_coords_src,
+                  k_s,
+                  k_t,
+                  rot,
+                  t,
+                  focal_disps=None,
+                  compose_layers=True,
+                  compute_trg_disp=False,
+                  trg_downsampling=1,
+                  bg_layer_disp=0,
+                  max_disp=1,
+                  zbuf_scale=10):
+  """Forward splat the ldi_src (reference ldi.py:71-182; same signature).
+
+  Args:
+    ldi_src: [textures, masks, disps]; masks may be None (all ones).
+    pixel_coords_src: B x H x W x 3 pixel-centre grid.  The kernels generate
+        (x+0.5, y+0.5, 1) themselves -- the only value the reference's callers
+        pass (helpers.pixel_coords, train_utils.py:86-88); the argument is kept
+        for signature compatibility.
+    k_s, k_t: B x 3 x 3 intrinsics; rot: B x 3 x 3; t: B x 3 x 1.  Camera
+        tensors on the CPU avoid a device->host copy when choosing the kernel.
+    focal_disps: not supported (lytro data only; None in both reference scripts).
+  Returns:
+    trg_img nl x B x Ht x Wt x 3, trg_wts nl x B x Ht x Wt x 1 (un-normalised)
+    [, trg_disp nl x B x Ht x Wt x 1]; nl = 1 if compose_layers else L.
+  """
+  del pixel_coords_src
+  if focal_disps is not None:
+    raise NotImplementedError('focal_disps is not supported by the HIP renderer')
+  mat_host = projection.forward_projection_matrix(
+      k_s.detach().to('cpu', torch.float32), k_t.detach().to('cpu', torch.float32),
+      rot.detach().to('cpu', torch.float32), t.detach().to('cpu', torch.float32))
+  return forward_splat_matrix(
+      ldi_src, mat_host, compose_layers=compose_layers,
+      compute_trg_disp=compute_trg_disp, trg_downsampling=trg_downsampling,
+      bg_layer_disp=bg_layer_disp, max_disp=max_disp, zbuf_scale=zbuf_scale,
+      mat_host=mat_host)
+
+
+def project_indices(disp, mask, src2trg_mat, trg_downsampling=1, max_disp=1,
+                    zbuf_scale=10):
+  """Parity/debug view: per source pixel the four flat target indices and the
+  four weight-splat updates (lsi_project_indices).  disp/mask: L x B x H x W x 1.
+  Returns idx4 int32 [L,B,H*W,4], upd4 fp32 [L,B,H*W,4]."""
+  dev = _C.require_device(disp, mask)
+  nl, b, h, w = disp.shape[:4]
+  ht, wt = int(h * trg_downsampling), int(w * trg_downsampling)
+  tex_stub = disp.new_empty((nl, b, h, w, 1))
+  flags = _C.LSI_HAS_MASK if mask is not None else 0
+  desc = _desc(tex_stub, mask, disp, ht, wt, float(trg_downsampling),
+               float(max_disp), float(zbuf_scale), 0.0, flags, 0)
+  mat = src2trg_mat.detach().to(dev, torch.float32).contiguous()
+  idx4 = torch.empty((nl, b, h * w, 4), dtype=torch.int32, device=dev)
+  upd4 = torch.empty((nl, b, h * w, 4), dtype=torch.float32, device=dev)
+  rc = _C.lib().lsi_project_indices(ctypes.byref(desc), _C.ptr(disp),
+                                    _C.ptr(mask), _C.ptr(mat), _C.ptr(idx4),
+                                    _C.ptr(upd4), _C.stream_ptr(dev))
+  _C.check(rc, 'lsi_project_indices')
+  return idx4, upd4

@@ -1,0 +1,77 @@
+"""Loss functions on LDIs (mirror of the reference's lsi/loss/loss.py) plus the
+view-synthesis loss the reference computes inline in ldi_enc_dec.py:337-357."""
+import math
+
+import torch
+
+from lsi.nnutils import helpers as nn_helpers
+
+
+def event_prob(layer_masks):
+  """Per-pixel ordered-multiplication layer probabilities (reference
+  loss.py:27-45; dead code there, kept for surface parity)."""
+  eps = 1e-6
+  layer_masks = torch.clamp(layer_masks, eps, 1 - eps)
+  log_inv_m = torch.log(1 - layer_masks)
+  log_prob = torch.cumsum(log_inv_m, dim=0) - log_inv_m + torch.log(layer_masks)
+  layer_probs = torch.exp(log_prob)
+  escape_probs = 1 - torch.sum(layer_probs, dim=0, keepdim=True)
+  return layer_probs, escape_probs
+
+
+def decreasing_disp_loss(layer_disps):
+  """Penalises disparities that increase from one layer to the next, with the
+  nearer layer detached (reference loss.py:48-63)."""
+  n_layers = layer_disps.shape[0]
+  if n_layers == 1:
+    return 0
+  disps_pre = layer_disps[0:n_layers - 1].detach()
+  disps_post = layer_disps[1:n_layers]
+  return torch.relu(disps_post - disps_pre).mean()
+
+
+def zbuffer_composition_loss(layer_imgs, layer_masks, layer_disps, trg_imgs,
+                             bg_layer_disp=0, max_disp=1, zbuf_scale=10):
+  """Depth+mask weighted self-consistency loss with a white background layer
+  (reference loss.py:66-115)."""
+  layer_imgs = torch.cat([layer_imgs, torch.ones_like(layer_imgs[:1])], 0)
+  layer_masks = torch.cat([layer_masks, torch.ones_like(layer_masks[:1])], 0)
+  layer_disps = torch.cat(
+      [layer_disps, torch.ones_like(layer_disps[:1]) * bg_layer_disp], 0)
+  layer_probs = nn_helpers.zbuffer_weights(
+      layer_disps / max_disp, scale=zbuf_scale) * layer_masks
+  probs_sum = torch.sum(layer_probs, dim=0, keepdim=True)
+  layer_probs = nn_helpers.divide_safe(layer_probs, probs_sum)
+  layerwise_cost = torch.square(layer_imgs - trg_imgs) * layer_probs
+  layerwise_cost = torch.sum(layerwise_cost, dim=0)
+  return 0.5 * layerwise_cost.mean()
+
+
+def area_downsample(img, ht, wt):
+  """tf.image.resize_images(..., AREA) for integer reduction factors: exact box
+  mean.  img: B x H x W x C."""
+  b, h, w, c = img.shape
+  fy, fx = h // ht, w // wt
+  if fy * ht != h or fx * wt != w:
+    raise ValueError('AREA resize implemented for integer factors only')
+  if fy == 1 and fx == 1:
+    return img
+  return img.reshape(b, ht, fy, wt, fx, c).mean(dim=(2, 4))
+
+
+def _py2_round(x):
+  return int(math.floor(abs(x) + 0.5)) * (1 if x >= 0 else -1)
+
+
+def view_synthesis_loss(recons_splat, to_recons_img, splat_bdry_ignore=0.05):
+  """L1 view-synthesis loss of the reference's training script
+  (ldi_enc_dec.py:337-357): AREA-downsample the target to the splat's size,
+  mean |diff| over channels, min over layers, crop the border, mean."""
+  _, _, ht, wt, _ = recons_splat.shape
+  tgt = area_downsample(to_recons_img, ht, wt)
+  pw = torch.min(torch.mean(torch.abs(tgt.unsqueeze(0) - recons_splat), dim=4),
+                 dim=0)[0]
+  x_min = _py2_round(wt * splat_bdry_ignore)
+  y_min = _py2_round(ht * splat_bdry_ignore)
+  pw = pw[:, y_min:ht - y_min, x_min:wt - x_min]
+  return pw.mean()

@@ -1,0 +1,119 @@
+"""Differentiable torch (CPU, any float dtype) restatement of forward_splat,
+splat and bilinear -- the gradient oracle.
+
+TEST INFRASTRUCTURE ONLY.  The reference has no hand-written backward: TF
+autodiff differentiates the op graph (train_utils.py:113).  This file restates
+the same op graph (ldi.py:71-182, sampling.py:41-254, helpers.py) with torch
+ops whose autograd conventions match TF's on the pieces that matter: floor and
+comparisons have zero gradient, clamp passes gradient on the closed interval,
+scatter-add is linear.  Gradients from it (in fp64) are what the HIP backward
+kernels are checked against; it is itself checked against finite differences
+(tests/test_oracle_golden.py).
+"""
+import torch
+
+
+def divide_safe(num, den):
+  den = den + 1e-8 * (den == 0).to(den.dtype)
+  return num / den
+
+
+def zbuffer_weights(x, scale):
+  pos = (x > 0).to(x.dtype)
+  # TF clip_by_value = minimum(maximum(x, lo), hi): gradient passes on [lo, hi].
+  inside = ((x >= 0) & (x <= 1)).to(x.dtype)
+  xc = x * inside + (x > 1).to(x.dtype)  # value of clamp, closed-interval grad
+  return torch.exp((xc - 0.5) * scale) * pos
+
+
+def corners(u, v, ht, wt):
+  """sampling.py:183-241; returns idx [...,4] (long) and w [...,4]."""
+  x, y = u - 0.5, v - 0.5
+  x0, y0 = torch.floor(x).detach(), torch.floor(y).detach()
+  x1, y1 = x0 + 1, y0 + 1
+  x0s, x1s = x0.clamp(0, wt - 1), x1.clamp(0, wt - 1)
+  y0s, y1s = y0.clamp(0, ht - 1), y1.clamp(0, ht - 1)
+  dt = u.dtype
+  wx0 = (x1 - x) * (x0 == x0s).to(dt)
+  wx1 = (x - x0) * (x1 == x1s).to(dt)
+  wy0 = (y1 - y) * (y0 == y0s).to(dt)
+  wy1 = (y - y0) * (y1 == y1s).to(dt)
+  ws = [wx0 * wy0, wx1 * wy0, wx0 * wy1, wx1 * wy1]
+  ws = [w * (w > 1e-3).to(dt) for w in ws]
+  ids = [x0s + y0s * wt, x1s + y0s * wt, x0s + y1s * wt, x1s + y1s * wt]
+  return (torch.stack([i.long() for i in ids], -1), torch.stack(ws, -1))
+
+
+def splat(src, coords, init):
+  """sampling.py:171-254.  src B x Hs x Ws x C, coords B x Hs x Ws x 2."""
+  b, _, _, c = src.shape
+  _, ht, wt, _ = init.shape
+  idx, w = corners(coords[..., 0], coords[..., 1], ht, wt)
+  out = init.reshape(b, ht * wt, c)
+  srcf = src.reshape(b, -1, c)
+  idx = idx.reshape(b, -1, 4)
+  w = w.reshape(b, -1, 4)
+  res = []
+  for bi in range(b):
+    o = out[bi]
+    for k in range(4):
+      o = o.index_add(0, idx[bi, :, k], srcf[bi] * w[bi, :, k:k + 1])
+    res.append(o)
+  return torch.stack(res).reshape(b, ht, wt, c)
+
+
+def forward_splat(tex, mask, disp, mat, s, bg_layer_disp, max_disp, zbuf_scale,
+                  compose):
+  """ldi.py:71-182.  tex L x B x H x W x 3, mask/disp L x B x H x W x 1,
+  mat B x 4 x 4.  Returns img, wts, disp_out."""
+  nl, b, h, w, c = tex.shape
+  dt = tex.dtype
+  ht, wt = int(h * s), int(w * s)
+  bg = zbuffer_weights(torch.tensor(bg_layer_disp / max_disp, dtype=dt),
+                       zbuf_scale)
+  xs = (torch.arange(w, dtype=dt) + 0.5).view(1, 1, w).expand(b, h, w)
+  ys = (torch.arange(h, dtype=dt) + 0.5).view(1, h, 1).expand(b, h, w)
+  imgs, wtss, dsps = [], [], []
+  for l in range(nl):
+    p = torch.stack([xs, ys, torch.ones_like(xs), disp[l, ..., 0]], -1)
+    q = torch.einsum('bhwk,bjk->bhwj', p, mat.to(dt))
+    uv = divide_safe(q[..., 0:2], q[..., 2:3]) * s
+    dd = divide_safe(q[..., 3:4], q[..., 2:3])
+    pw = zbuffer_weights(dd / max_disp, zbuf_scale) * mask[l]
+    ones3 = torch.ones((b, ht, wt, c), dtype=dt)
+    ones1 = torch.ones((b, ht, wt, 1), dtype=dt)
+    imgs.append(splat(tex[l] * pw, uv, ones3 * bg))
+    wtss.append(splat(pw, uv, ones1 * bg))
+    dsps.append(splat(dd * pw, uv, ones1 * 0))
+  img, wts, dsp = torch.stack(imgs), torch.stack(wtss), torch.stack(dsps)
+  dsp = divide_safe(dsp, wts)
+  if compose:
+    img = img.sum(0, keepdim=True)
+    wts = wts.sum(0, keepdim=True)
+    dsp = dsp.max(0, keepdim=True)[0]
+  return divide_safe(img, wts), wts, dsp
+
+
+def bilinear(imgs, coords):
+  """sampling.py:41-132 (compose=True)."""
+  b, hs, ws, c = imgs.shape
+  dt = imgs.dtype
+  x, y = coords[..., 0:1] - 0.5, coords[..., 1:2] - 0.5
+  x0, y0 = torch.floor(x).detach(), torch.floor(y).detach()
+  x1, y1 = x0 + 1, y0 + 1
+  x0s, x1s = x0.clamp(0, ws - 1), x1.clamp(0, ws - 1)
+  y0s, y1s = y0.clamp(0, hs - 1), y1.clamp(0, hs - 1)
+  wx0, wx1, wy0, wy1 = x1 - x, x - x0, y1 - y, y - y0
+  vx0, vx1 = (x0 == x0s).to(dt), (x1 == x1s).to(dt)
+  vy0, vy1 = (y0 == y0s).to(dt), (y1 == y1s).to(dt)
+  flat = imgs.reshape(b, hs * ws, c)
+
+  def tap(xs_, ys_):
+    idx = (xs_ + ys_ * ws).long()[..., 0]
+    return torch.stack([flat[bi][idx[bi]] for bi in range(b)])
+
+  out = vx0 * vy0 * wx0 * wy0 * tap(x0s, y0s)
+  out = out + vx0 * vy1 * wx0 * wy1 * tap(x0s, y1s)
+  out = out + vx1 * vy0 * wx1 * wy0 * tap(x1s, y0s)
+  out = out + vx1 * vy1 * wx1 * wy1 * tap(x1s, y1s)
+  return out

@@ -1,0 +1,114 @@
+"""Host-side mirror functions (torch elementwise / small-matrix helpers) against
+the reference-generated goldens, on CPU tensors.  The HIP-backed ops
+(forward_splat, splat, bilinear, scatter_add) are covered by the -m gpu tests."""
+import numpy as np
+import torch
+
+from conftest import golden
+from lsi.geometry import homography, layers, ldi, projection
+from lsi.loss import loss
+from lsi.nnutils import helpers
+
+T = torch.tensor
+
+
+def close(a, b, rtol=1e-5, atol=1e-6):
+  np.testing.assert_allclose(a.detach().cpu().numpy(), b, rtol=rtol, atol=atol)
+
+
+def test_helpers_known_answers():
+  g = golden('known_answers.npz')
+  close(helpers.zbuffer_weights(T(g['zbuf_in']), 50), g['zbuf_out_50'], 2e-6, 0)
+  close(helpers.divide_safe(T(g['divsafe_num']), T(g['divsafe_den'])),
+        g['divsafe_out'], 0, 0)
+  np.testing.assert_array_equal(helpers.pixel_coords(2, 3, 5).numpy(),
+                                g['pixel_coords_2_3_5'])
+  assert float(helpers.zbuffer_weights(1e-3 / 0.4, scale=50)) > 0
+  m = torch.rand(2, 3, 4)
+  assert helpers.transpose(m).shape == (2, 4, 3)
+
+
+def test_projection_matrices_match_reference_bitwise():
+  for name in ('fs_kitti_L2_s05.npz', 'fs_cfg1_synth_L1_64.npz',
+               'fs_general_L3_s05.npz', 'fs_kitti_inv_L1_s1.npz'):
+    g = golden(name)
+    m = projection.forward_projection_matrix(T(g['k_s']), T(g['k_t']),
+                                             T(g['rot']), T(g['t']))
+    close(m, g['M'], 1e-6, 1e-6)
+  g = golden('layers.npz')
+  close(projection.forward_projection_matrix(T(g['p_k_s']), T(g['p_k_t']),
+                                             T(g['p_rot']), T(g['p_t'])),
+        g['fwd_mat'], 1e-5, 1e-5)
+  close(projection.inverse_projection_matrix(T(g['p_k_s']), T(g['p_k_t']),
+                                             T(g['p_rot']), T(g['p_t'])),
+        g['inv_mat'], 1e-5, 1e-5)
+  k = torch.rand(2, 3, 3)
+  assert projection.pad_intrinsic(k)[0, 3, 3] == 1
+  assert projection.pad_extrinsic(k, torch.rand(2, 3, 1)).shape == (2, 4, 4)
+
+
+def test_layers_compose_and_soft_z():
+  g = golden('layers.npz')
+  imgs, masks, dmaps = T(g['imgs']), T(g['masks']), T(g['dmaps'])
+  close(layers.compose(imgs, masks, dmaps), g['compose_hard'])
+  close(layers.compose(imgs, masks, dmaps, soft=True, min_disp=1e-3,
+                       depth_softmax_temp=0.4), g['compose_soft'], 1e-4, 1e-6)
+  close(layers.compose_depth(masks, dmaps), g['compose_depth'])
+  close(layers.compose_depth(masks, dmaps, bg_layer=True, min_disp=1e-3,
+                             depth_softmax_temp=0.4), g['compose_depth_bg'])
+  close(helpers.soft_z_buffering(masks, dmaps, 0.4), g['soft_z'], 1e-4, 1e-7)
+  np.testing.assert_array_equal(helpers.enforce_bg_occupied(masks).numpy(),
+                                g['enforce_bg'])
+
+
+def test_homography_algebra():
+  g = golden('layers.npz')
+  args = [T(g[k]) for k in ('p_k_s', 'p_k_t', 'p_rot', 'p_t')]
+  n_hat, a = T(g['p_n_hat'][0]), T(g['p_a'][0])
+  close(homography.inv_homography(*args, n_hat, a), g['inv_hom'], 1e-4, 1e-5)
+  close(homography.inv_homography_dmat(args[1], args[2], args[3], n_hat, a),
+        g['inv_hom_dmat'], 1e-4, 1e-6)
+  nt, at = homography.transform_plane_eqns(args[2], args[3], n_hat, a)
+  close(nt, g['plane_n_t'], 1e-5, 1e-6)
+  close(at, g['plane_a_t'], 1e-5, 1e-6)
+  pc = helpers.pixel_coords(2, 16, 20)
+  pc = pc.unsqueeze(0).expand(2, 2, 16, 20, 3)
+  rep = [x.unsqueeze(0).expand((2,) + tuple(x.shape)) for x in args]
+  td = homography.trg_disp_maps(pc, rep[1], rep[2], rep[3], T(g['p_n_hat']),
+                                T(g['p_a']))
+  close(td, g['p_out_dmaps'], 1e-4, 1e-6)
+  pts = torch.rand(2, 5, 3) + 0.5
+  close(homography.normalize_homogeneous(pts),
+        (pts[..., :2] / pts[..., 2:]).numpy())
+
+
+def test_losses():
+  g = golden('losses.npz')
+  imgs, masks, disps, trg = (T(g[k]) for k in ('imgs', 'masks', 'disps', 'trg'))
+  got = loss.zbuffer_composition_loss(imgs, masks, disps, trg,
+                                      bg_layer_disp=1e-3, max_disp=0.4,
+                                      zbuf_scale=50)
+  assert abs(float(got) - float(g['zbuf_comp_loss'])) < 1e-5 * float(g['zbuf_comp_loss'])
+  assert abs(float(loss.decreasing_disp_loss(disps)) - float(g['decr_disp_loss'])) < 1e-6
+  assert loss.decreasing_disp_loss(disps[:1]) == 0
+  assert abs(float(ldi.disp_smoothness_loss(disps)) - float(g['smooth_loss'])) < 1e-5
+  dx, dy = ldi.gradient(disps)
+  np.testing.assert_array_equal(dx.numpy(), g['grad_dx'])
+  np.testing.assert_array_equal(dy.numpy(), g['grad_dy'])
+  probs, esc = loss.event_prob(masks)
+  assert probs.shape == masks.shape and esc.shape[0] == 1
+  assert float((probs.sum(0, keepdim=True) + esc - 1).abs().max()) < 1e-5
+
+
+def test_view_synthesis_loss():
+  import lsi_oracle as O
+  rs = np.random.RandomState(3)
+  tgt = rs.rand(2, 16, 24, 3).astype(np.float32)
+  recon = rs.rand(3, 2, 8, 12, 3).astype(np.float32)
+  want = O.view_synthesis_loss(recon, tgt, 0.05)
+  got = loss.view_synthesis_loss(T(recon), T(tgt), 0.05)
+  assert abs(float(got) - float(want)) < 1e-6
+  # decreasing_disp_loss stops the gradient of the nearer layer (loss.py:58-60)
+  d = torch.rand(3, 1, 4, 4, 1, requires_grad=True)
+  loss.decreasing_disp_loss(d).backward()
+  assert float(d.grad[0].abs().sum()) == 0

@@ -1,0 +1,166 @@
+"""Parity of lsi.geometry.sampling / layers / homography / projection on the GPU
+(HIP bilinear gather, generic splat, scatter-add) with the reference goldens."""
+import numpy as np
+import pytest
+import torch
+
+import lsi_oracle as O
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev(built_lib):
+  if not torch.cuda.is_available():
+    pytest.fail('gpu test selected but no ROCm device is visible')
+  return torch.device('cuda:0')
+
+
+def T(x, dev):
+  return torch.tensor(x, device=dev)
+
+
+def test_splat_known_answers(dev):
+  from lsi.geometry import sampling
+  g = golden('known_answers.npz')
+  one = torch.ones(1, 1, 1, 1, device=dev)
+  for (x, y), want in zip(g['splat_pts'], g['splat_canvases']):
+    got = sampling.splat(one, T([[[[x, y]]]], dev).float(),
+                         torch.zeros(1, 4, 4, 1, device=dev))
+    np.testing.assert_array_equal(got[0, :, :, 0].cpu().numpy(), want)
+  two = sampling.splat(torch.ones(1, 1, 2, 1, device=dev),
+                       T([[[[2.5, 2.5], [2.5, 2.5]]]], dev).float(),
+                       torch.zeros(1, 4, 4, 1, device=dev))
+  np.testing.assert_array_equal(two[0, :, :, 0].cpu().numpy(),
+                                g['splat_two_same'])
+
+
+def test_splat_random_against_oracle(dev):
+  from lsi.geometry import sampling
+  rs = np.random.RandomState(2)
+  src = rs.rand(2, 20, 30, 5).astype(np.float32)
+  coords = np.stack([rs.uniform(-3, 20, (2, 20, 30)),
+                     rs.uniform(-3, 14, (2, 20, 30))], -1).astype(np.float32)
+  init = rs.rand(2, 11, 17, 5).astype(np.float32)
+  want = O.splat(src, coords, init)
+  got = sampling.splat(T(src, dev), T(coords, dev), T(init, dev))
+  np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-5, atol=1e-6)
+
+
+def test_scatter_add_goldens(dev):
+  from lsi.geometry import sampling
+  g = golden('known_answers.npz')
+  got = sampling.batch_scatter_add_tensor(T(g['bsa_init'], dev),
+                                          T(g['bsa_idx'], dev),
+                                          T(g['bsa_upd'], dev))
+  np.testing.assert_allclose(got.cpu().numpy(), g['bsa_out'], rtol=1e-6)
+  got1 = sampling.scatter_add_tensor(T(g['bsa_init'][0], dev),
+                                     T(g['bsa_idx'][0][:, None], dev),
+                                     T(g['bsa_upd'][0], dev))
+  np.testing.assert_allclose(got1.cpu().numpy(), g['sa_out'], rtol=1e-6)
+  with pytest.raises(IndexError):
+    sampling.batch_scatter_add_tensor(torch.zeros(1, 4, device=dev),
+                                      T(np.array([[7]], np.int32), dev),
+                                      torch.ones(1, 1, device=dev))
+  # gradients: d/d init = g, d/d updates = gather(g)
+  init = torch.zeros(2, 6, device=dev, requires_grad=True)
+  upd = torch.ones(2, 3, device=dev, requires_grad=True)
+  idx = T(np.array([[0, 0, 5], [1, 2, 2]], np.int32), dev)
+  out = sampling.batch_scatter_add_tensor(init, idx, upd)
+  w = torch.arange(12, device=dev, dtype=torch.float32).reshape(2, 6)
+  (out * w).sum().backward()
+  np.testing.assert_array_equal(upd.grad.cpu().numpy(),
+                                [[0, 0, 5], [7, 8, 8]])
+  np.testing.assert_array_equal(init.grad.cpu().numpy(), w.cpu().numpy())
+
+
+def test_bilinear_goldens(dev):
+  from lsi.geometry import sampling
+  g = golden('bilinear.npz')
+  got = sampling.bilinear(T(g['imgs'], dev), T(g['coords'], dev))
+  np.testing.assert_allclose(got.cpu().numpy(), g['out'], rtol=1e-6, atol=1e-7)
+  got5 = sampling.bilinear_wrapper(T(g['imgs5'], dev), T(g['coords5'], dev))
+  np.testing.assert_allclose(got5.cpu().numpy(), g['out5'], rtol=1e-6,
+                             atol=1e-7)
+  with pytest.raises(NotImplementedError):
+    sampling.bilinear(T(g['imgs'], dev), T(g['coords'], dev), compose=False)
+
+
+def test_bilinear_and_splat_gradients(dev):
+  import lsi_torch_ref as TR
+  from lsi.geometry import sampling
+  rs = np.random.RandomState(4)
+  imgs = rs.rand(2, 9, 11, 3)
+  coords = np.stack([rs.uniform(-1, 12, (2, 6, 7)),
+                     rs.uniform(-1, 10, (2, 6, 7))], -1)
+  # keep clear of cell boundaries so that fp32/fp64 floors agree
+  coords = np.where(np.abs(coords - 0.5 - np.round(coords - 0.5)) < 1e-3,
+                    coords + 0.01, coords)
+  cw = rs.rand(2, 6, 7, 3)
+  i64 = torch.tensor(imgs, requires_grad=True)
+  c64 = torch.tensor(coords, requires_grad=True)
+  (TR.bilinear(i64, c64) * torch.tensor(cw)).sum().backward()
+  i32 = torch.tensor(imgs, dtype=torch.float32, device=dev, requires_grad=True)
+  c32 = torch.tensor(coords, dtype=torch.float32, device=dev,
+                     requires_grad=True)
+  (sampling.bilinear(i32, c32) * T(cw, dev).float()).sum().backward()
+  np.testing.assert_allclose(i32.grad.cpu().numpy(), i64.grad.numpy(),
+                             rtol=1e-4, atol=1e-5)
+  np.testing.assert_allclose(c32.grad.cpu().numpy(), c64.grad.numpy(),
+                             rtol=1e-4, atol=1e-4)
+
+  src = rs.rand(2, 6, 7, 3)
+  init = rs.rand(2, 9, 11, 3)
+  cw2 = rs.rand(2, 9, 11, 3)
+  s64 = torch.tensor(src, requires_grad=True)
+  c64 = torch.tensor(coords, requires_grad=True)
+  n64 = torch.tensor(init, requires_grad=True)
+  (TR.splat(s64, c64, n64) * torch.tensor(cw2)).sum().backward()
+  s32 = torch.tensor(src, dtype=torch.float32, device=dev, requires_grad=True)
+  c32 = torch.tensor(coords, dtype=torch.float32, device=dev,
+                     requires_grad=True)
+  n32 = torch.tensor(init, dtype=torch.float32, device=dev, requires_grad=True)
+  (sampling.splat(s32, c32, n32) * T(cw2, dev).float()).sum().backward()
+  np.testing.assert_allclose(s32.grad.cpu().numpy(), s64.grad.numpy(),
+                             rtol=1e-4, atol=1e-5)
+  np.testing.assert_allclose(c32.grad.cpu().numpy(), c64.grad.numpy(),
+                             rtol=1e-4, atol=1e-4)
+  np.testing.assert_allclose(n32.grad.cpu().numpy(), n64.grad.numpy(),
+                             rtol=1e-6)
+
+
+def test_planar_transform_and_compose_on_gpu(dev):
+  from lsi.geometry import layers
+  from lsi.nnutils import helpers
+  g = golden('layers.npz')
+  pc = helpers.pixel_coords(2, 16, 20, device=dev)
+  ti, tm, td = layers.planar_transform(
+      T(g['p_imgs'], dev), T(g['p_masks'], dev), pc, T(g['p_k_s'], dev),
+      T(g['p_k_t'], dev), T(g['p_rot'], dev), T(g['p_t'], dev),
+      T(g['p_n_hat'], dev), T(g['p_a'], dev))
+  # homography evaluated by the GPU's BLAS: coordinates agree to ~1e-5 px, the
+  # sampled images to that times the image gradient.
+  assert float(np.abs(ti.cpu().numpy() - g['p_out_imgs']).max()) < 2e-3
+  assert float(np.abs(tm.cpu().numpy() - g['p_out_masks']).max()) < 2e-3
+  np.testing.assert_allclose(td.cpu().numpy(), g['p_out_dmaps'], rtol=1e-4,
+                             atol=1e-6)
+  got = layers.compose(T(g['imgs'], dev), T(g['masks'], dev),
+                       T(g['dmaps'], dev))
+  np.testing.assert_allclose(got.cpu().numpy(), g['compose_hard'], rtol=1e-5,
+                             atol=1e-6)
+
+
+def test_disocclusion_mask_on_gpu(dev):
+  from lsi.geometry import projection
+  from lsi.nnutils import helpers
+  g = golden('disocclusion.npz')
+  b, h, w, _ = g['disps_src'].shape
+  got = projection.disocclusion_mask(T(g['disps_src'], dev),
+                                     T(g['disps_trg'], dev),
+                                     helpers.pixel_coords(b, h, w, device=dev),
+                                     T(g['M'], dev))
+  # a thresholded quantity: allow a few pixels whose |diff| sits on the 1e-2
+  # threshold to flip under a different matmul rounding
+  mism = float((got.cpu().numpy() != g['mask']).mean())
+  assert mism <= 0.005, mism

@@ -1,0 +1,335 @@
+"""Parity of the HIP forward-splat renderer (through the C ABI) with the oracle.
+
+Bars: projected pixel indices BIT-EXACT; rendered RGB |err| <= 2e-5 (values in
+[0,1]); un-normalised weights and disparity 1e-4 relative (fp32 sums of
+positive terms in a different order than the reference; exp within ~2 ulp).
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import lsi_oracle as O
+from conftest import GOLDEN, golden
+
+pytestmark = pytest.mark.gpu
+
+FS_CASES = sorted(os.path.basename(f)
+                  for f in glob.glob(os.path.join(GOLDEN, 'fs_*.npz')))
+IMG_ATOL, WTS_RTOL, DSP_RTOL = 2e-5, 1e-4, 1e-4
+
+
+@pytest.fixture(scope='module')
+def dev(built_lib):
+  if not torch.cuda.is_available():
+    pytest.fail('gpu test selected but no ROCm device is visible')
+  return torch.device('cuda:0')
+
+
+def _params(g):
+  s, bg, md, zb = [float(v) for v in g['params']]
+  s = int(s) if s == int(s) else s
+  return s, bg, md, zb
+
+
+def _cmp(got, want, tag):
+  img, wts, dsp = [t.cpu().numpy() for t in got]
+  np.testing.assert_allclose(img, want[tag + '_img'], rtol=0, atol=IMG_ATOL)
+  np.testing.assert_allclose(wts, want[tag + '_wts'], rtol=WTS_RTOL, atol=0)
+  np.testing.assert_allclose(dsp, want[tag + '_disp'], rtol=DSP_RTOL, atol=1e-7)
+
+
+def _rowband_ok(g):
+  m = g['M']
+  return bool(np.all(m[:, 1, 3] == 0) and np.all(m[:, 2, 3] == 0))
+
+
+@pytest.mark.parametrize('case', FS_CASES)
+@pytest.mark.parametrize('compose', [True, False])
+@pytest.mark.parametrize('path', ['atomic', 'rowband'])
+def test_forward_splat_matches_reference_goldens(case, compose, path, dev):
+  from lsi.geometry import ldi
+  g = golden(case)
+  if path == 'rowband' and not _rowband_ok(g):
+    pytest.skip('projection is not row-band (general pose)')
+  s, bg, md, zb = _params(g)
+  ldi_src = [torch.tensor(g[k], device=dev) for k in ('tex', 'mask', 'disp')]
+  got = ldi.forward_splat_matrix(
+      ldi_src, torch.tensor(g['M']), compose_layers=compose,
+      compute_trg_disp=True, trg_downsampling=s, bg_layer_disp=bg, max_disp=md,
+      zbuf_scale=zb, path=path)
+  _cmp(got, g, 'compose' if compose else 'indep')
+  # without the disparity output (the training configuration)
+  img, wts = ldi.forward_splat_matrix(
+      ldi_src, torch.tensor(g['M']), compose_layers=compose,
+      trg_downsampling=s, bg_layer_disp=bg, max_disp=md, zbuf_scale=zb,
+      path=path)
+  tag = 'compose' if compose else 'indep'
+  np.testing.assert_allclose(img.cpu().numpy(), g[tag + '_img'], rtol=0,
+                             atol=IMG_ATOL)
+  np.testing.assert_allclose(wts.cpu().numpy(), g[tag + '_wts'], rtol=WTS_RTOL)
+
+
+@pytest.mark.parametrize('case', FS_CASES)
+def test_projected_pixel_indices_are_bit_exact(case, dev):
+  from lsi.geometry import ldi
+  g = golden(case)
+  s, _, md, zb = _params(g)
+  idx4, upd4 = ldi.project_indices(torch.tensor(g['disp'], device=dev),
+                                   torch.tensor(g['mask'], device=dev),
+                                   torch.tensor(g['M']), s, md, zb)
+  np.testing.assert_array_equal(idx4.cpu().numpy(), g['idx4'])
+  np.testing.assert_allclose(upd4.cpu().numpy(), g['upd4'], rtol=2e-5, atol=0)
+
+
+def test_camera_api_matches_golden(dev):
+  from lsi.geometry import ldi
+  from lsi.nnutils import helpers
+  g = golden('fs_kitti_L2_s05.npz')
+  s, bg, md, zb = _params(g)
+  ldi_src = [torch.tensor(g[k], device=dev) for k in ('tex', 'mask', 'disp')]
+  nl, b, h, w, _ = g['tex'].shape
+  got = ldi.forward_splat(
+      ldi_src, helpers.pixel_coords(b, h, w), torch.tensor(g['k_s']),
+      torch.tensor(g['k_t']), torch.tensor(g['rot']), torch.tensor(g['t']),
+      compose_layers=True, compute_trg_disp=True, trg_downsampling=s,
+      bg_layer_disp=bg, max_disp=md, zbuf_scale=zb)
+  _cmp(got, g, 'compose')
+  with pytest.raises(NotImplementedError):
+    ldi.forward_splat(ldi_src, None, torch.tensor(g['k_s']),
+                      torch.tensor(g['k_t']), torch.tensor(g['rot']),
+                      torch.tensor(g['t']), focal_disps=torch.zeros(b, 1, 1, 1))
+
+
+def _synth(rs, nl, b, h, w, kitti=True, max_disp=0.4):
+  tex = rs.rand(nl, b, h, w, 3).astype(np.float32)
+  disp = (max_disp * rs.rand(nl, b, h, w, 1)).astype(np.float32)
+  if kitti:
+    k = np.array([[0.58 * w, 0, w / 2], [0, 0.58 * w, h / 2], [0, 0, 1]],
+                 np.float32)
+    k = np.broadcast_to(k, (b, 3, 3)).copy()
+    rot = np.broadcast_to(np.eye(3, dtype=np.float32), (b, 3, 3)).copy()
+    t = np.broadcast_to(np.array([[-0.532], [0], [0]], np.float32),
+                        (b, 3, 1)).copy()
+  else:
+    k = np.array([[w, 0, w / 2], [0, h, h / 2], [0, 0, 1]], np.float32)
+    k = np.broadcast_to(k, (b, 3, 3)).copy()
+    ang = rs.uniform(-0.1, 0.1, (b, 3))
+    rot = np.stack([_rot(*a) for a in ang]).astype(np.float32)
+    t = rs.uniform(-0.3, 0.3, (b, 3, 1)).astype(np.float32)
+  mat = O.forward_projection_matrix(k, k, rot, t)
+  return tex, disp, mat
+
+
+def _rot(ax, ay, az):
+  cx, sx, cy, sy, cz, sz = (np.cos(ax), np.sin(ax), np.cos(ay), np.sin(ay),
+                            np.cos(az), np.sin(az))
+  rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+  ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+  rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+  return rz @ ry @ rx
+
+
+@pytest.mark.parametrize('path', ['atomic', 'rowband'])
+@pytest.mark.parametrize('compose', [True, False])
+def test_config2_size_against_c_oracle(path, compose, dev, ref_cpu):
+  """BASELINE config 2 shape (2-layer 256x768, s=0.5), batch 2, vs the C oracle."""
+  from lsi.geometry import ldi
+  rs = np.random.RandomState(5)
+  tex, disp, mat = _synth(rs, 2, 2, 256, 768)
+  want = ref_cpu.forward_splat(tex, None, disp, mat, 0.5, 1e-3, 0.4, 50,
+                               compose)
+  ldi_src = [torch.tensor(tex, device=dev), None, torch.tensor(disp, device=dev)]
+  img, wts, dsp = ldi.forward_splat_matrix(
+      ldi_src, torch.tensor(mat), compose_layers=compose, compute_trg_disp=True,
+      trg_downsampling=0.5, bg_layer_disp=1e-3, max_disp=0.4, zbuf_scale=50,
+      path=path)
+  np.testing.assert_allclose(img.cpu().numpy(), want['img'], rtol=0,
+                             atol=IMG_ATOL)
+  np.testing.assert_allclose(wts.cpu().numpy(), want['wts'], rtol=WTS_RTOL)
+  np.testing.assert_allclose(dsp.cpu().numpy(), want['disp'], rtol=DSP_RTOL,
+                             atol=1e-7)
+  mse = float(np.mean((img.cpu().numpy() - want['img'])**2))
+  assert mse < 1e-12          # PSNR(build, oracle) > 120 dB
+
+
+def test_general_pose_against_c_oracle(dev, ref_cpu):
+  from lsi.geometry import ldi
+  rs = np.random.RandomState(6)
+  tex, disp, mat = _synth(rs, 3, 2, 128, 128, kitti=False, max_disp=1.0)
+  disp = (0.28 + 0.22 * disp).astype(np.float32)
+  mask = rs.rand(3, 2, 128, 128, 1).astype(np.float32)
+  want = ref_cpu.forward_splat(tex, mask, disp, mat, 0.5, 0.2, 1.0, 50, True)
+  ldi_src = [torch.tensor(x, device=dev) for x in (tex, mask, disp)]
+  img, wts, dsp = ldi.forward_splat_matrix(
+      ldi_src, torch.tensor(mat), compose_layers=True, compute_trg_disp=True,
+      trg_downsampling=0.5, bg_layer_disp=0.2, max_disp=1.0, zbuf_scale=50)
+  np.testing.assert_allclose(img.cpu().numpy(), want['img'], rtol=0,
+                             atol=IMG_ATOL)
+  np.testing.assert_allclose(wts.cpu().numpy(), want['wts'], rtol=WTS_RTOL)
+  np.testing.assert_allclose(dsp.cpu().numpy(), want['disp'], rtol=DSP_RTOL,
+                             atol=1e-7)
+  with pytest.raises(RuntimeError, match='precondition'):
+    ldi.forward_splat_matrix(ldi_src, torch.tensor(mat), path='rowband')
+
+
+@pytest.mark.parametrize('path', ['atomic', 'rowband'])
+def test_planar_nchw_inputs_need_no_copy(path, dev, ref_cpu):
+  """A permuted NCHW conv output (planar RGB+disparity) renders identically."""
+  from lsi.geometry import ldi
+  rs = np.random.RandomState(7)
+  tex, disp, mat = _synth(rs, 2, 2, 64, 192)
+  want = ref_cpu.forward_splat(tex, None, disp, mat, 0.5, 1e-3, 0.4, 50, True)
+  nchw = torch.tensor(np.concatenate([tex, disp], -1), device=dev)
+  nchw = nchw.permute(0, 1, 4, 2, 3).contiguous()      # L x B x 4 x H x W
+  view = nchw.permute(0, 1, 3, 4, 2)                   # L x B x H x W x 4 view
+  tex_v, disp_v = view[..., :3], view[..., 3:4]
+  assert not tex_v.is_contiguous()
+  img, wts = ldi.forward_splat_matrix(
+      [tex_v, None, disp_v], torch.tensor(mat), trg_downsampling=0.5,
+      bg_layer_disp=1e-3, max_disp=0.4, zbuf_scale=50, path=path)
+  np.testing.assert_allclose(img.cpu().numpy(), want['img'], rtol=0,
+                             atol=IMG_ATOL)
+  np.testing.assert_allclose(wts.cpu().numpy(), want['wts'], rtol=WTS_RTOL)
+
+
+@pytest.mark.parametrize('shape', [(1, 1, 1, 1), (1, 1, 2, 3), (2, 1, 7, 13),
+                                   (1, 3, 33, 65)])
+@pytest.mark.parametrize('path', ['atomic', 'rowband'])
+def test_ragged_and_tiny_shapes(shape, path, dev):
+  from lsi.geometry import ldi
+  nl, b, h, w = shape
+  rs = np.random.RandomState(h * w)
+  tex, disp, mat = _synth(rs, nl, b, h, w)
+  want = O.forward_splat(tex, np.ones_like(disp), disp, mat, 1, 1e-3, 0.4, 50,
+                         False)
+  ldi_src = [torch.tensor(tex, device=dev), None, torch.tensor(disp, device=dev)]
+  img, wts, dsp = ldi.forward_splat_matrix(
+      ldi_src, torch.tensor(mat), compose_layers=False, compute_trg_disp=True,
+      trg_downsampling=1, bg_layer_disp=1e-3, max_disp=0.4, zbuf_scale=50,
+      path=path)
+  np.testing.assert_allclose(img.cpu().numpy(), want['img'], rtol=0,
+                             atol=IMG_ATOL)
+  np.testing.assert_allclose(wts.cpu().numpy(), want['wts'], rtol=WTS_RTOL)
+  np.testing.assert_allclose(dsp.cpu().numpy(), want['disp'], rtol=DSP_RTOL,
+                             atol=1e-7)
+
+
+def test_non_integral_target_size_is_rejected(dev):
+  from lsi.geometry import ldi
+  tex = torch.rand(1, 1, 5, 7, 3, device=dev)
+  disp = torch.rand(1, 1, 5, 7, 1, device=dev)
+  with pytest.raises(ValueError, match='integral'):
+    ldi.forward_splat_matrix([tex, None, disp], torch.eye(4).unsqueeze(0),
+                             trg_downsampling=0.5)
+
+
+def test_nonfinite_disparity_is_dropped_not_propagated(dev):
+  from lsi.geometry import ldi
+  rs = np.random.RandomState(9)
+  tex, disp, mat = _synth(rs, 1, 1, 16, 24)
+  disp[0, 0, 3, 4, 0] = np.nan
+  disp[0, 0, 5, 6, 0] = np.inf
+  for path in ('atomic', 'rowband'):
+    img, wts = ldi.forward_splat_matrix(
+        [torch.tensor(tex, device=dev), None, torch.tensor(disp, device=dev)],
+        torch.tensor(mat), trg_downsampling=0.5, bg_layer_disp=1e-3,
+        max_disp=0.4, zbuf_scale=50, path=path)
+    assert bool(torch.isfinite(img).all()) and bool(torch.isfinite(wts).all())
+
+
+@pytest.mark.parametrize('path', ['atomic', 'rowband'])
+def test_full_size_properties(path, dev):
+  """BASELINE config 3's per-GPU shard (4-layer 256x768, batch 4, s=0.5):
+  size-independent properties instead of a CPU oracle."""
+  from lsi.geometry import ldi
+  gen = torch.Generator(device='cpu').manual_seed(11)
+  nl, b, h, w = 4, 4, 256, 768
+  tex = torch.rand(nl, b, h, w, 3, generator=gen).to(dev)
+  disp = (0.4 * torch.rand(nl, b, h, w, 1, generator=gen)).to(dev)
+  k = torch.tensor([[0.58 * w, 0, w / 2], [0, 0.58 * w, h / 2], [0, 0, 1.0]])
+  k = k.expand(b, 3, 3)
+  eye, t = torch.eye(3).expand(b, 3, 3), torch.tensor([[-0.532], [0], [0]]).expand(b, 3, 1)
+  from lsi.geometry import projection
+  mat = projection.forward_projection_matrix(k, k, eye, t)
+  img, wts = ldi.forward_splat_matrix([tex, None, disp], mat,
+                                      trg_downsampling=0.5, bg_layer_disp=1e-3,
+                                      max_disp=0.4, zbuf_scale=50, path=path)
+  # (1) mass conservation: sum of un-normalised weights = L*bg*P + all updates
+  idx4, upd4 = ldi.project_indices(disp, None, mat, 0.5, 0.4, 50)
+  from lsi import _C
+  bg = _C.bg_weight(1e-3, 0.4, 50)
+  total = float(wts.double().sum())
+  want = float(upd4.double().sum()) + nl * bg * b * (h // 2) * (w // 2)
+  assert abs(total - want) <= 1e-5 * want
+  # (2) convexity: every rendered colour is a weighted mean of colours in [0,1]
+  assert float(img.min()) >= 0.0 and float(img.max()) <= 1.0 + 1e-6
+  # (3) linearity in texture at fixed geometry: render(a*tex) == a*render(tex)
+  #     up to the white background's share, checked through A = img*wts.
+  img2, wts2 = ldi.forward_splat_matrix([0.5 * tex, None, disp], mat,
+                                        trg_downsampling=0.5,
+                                        bg_layer_disp=1e-3, max_disp=0.4,
+                                        zbuf_scale=50, path=path)
+  a1 = (img * wts - nl * bg).double()
+  a2 = (img2 * wts2 - nl * bg).double()
+  torch.testing.assert_close(wts2, wts, rtol=1e-5, atol=0)
+  assert float((a2 - 0.5 * a1).abs().max()) <= 2e-5 * float(a1.abs().max())
+  # (4) both kernel families agree with each other
+  other = 'rowband' if path == 'atomic' else 'atomic'
+  img3, wts3 = ldi.forward_splat_matrix([tex, None, disp], mat,
+                                        trg_downsampling=0.5,
+                                        bg_layer_disp=1e-3, max_disp=0.4,
+                                        zbuf_scale=50, path=other)
+  torch.testing.assert_close(img3, img, rtol=0, atol=IMG_ATOL)
+  torch.testing.assert_close(wts3, wts, rtol=WTS_RTOL, atol=0)
+
+
+def test_identity_pose_reproduces_texture(dev):
+  from lsi.geometry import ldi
+  gen = torch.Generator().manual_seed(3)
+  tex = torch.rand(1, 2, 32, 48, 3, generator=gen).to(dev)
+  disp = torch.full((1, 2, 32, 48, 1), 0.3, device=dev)
+  img, _ = ldi.forward_splat_matrix([tex, None, disp],
+                                    torch.eye(4).expand(2, 4, 4),
+                                    bg_layer_disp=1e-3, max_disp=0.4,
+                                    zbuf_scale=50)
+  assert float((img[0] - tex[0]).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize('compose', [True, False])
+@pytest.mark.parametrize('case', ['fs_general_L3_s05.npz', 'fs_kitti_L2_s05.npz'])
+def test_backward_matches_autograd_of_the_op_graph(case, compose, dev):
+  """lsi_splat_bwd vs torch autograd (fp64) over the reference's op graph."""
+  import lsi_torch_ref as TR
+  from lsi.geometry import ldi
+  g = golden(case)
+  s, bg, md, zb = _params(g)
+  sl = (slice(None), slice(0, 1), slice(0, 16), slice(0, 24))
+  tex, mask, disp = g['tex'][sl], g['mask'][sl], g['disp'][sl]
+  mask = (0.5 + 0.5 * mask).astype(np.float32)
+  mat = g['M'][:1]
+  t64 = [torch.tensor(x, dtype=torch.float64, requires_grad=True)
+         for x in (tex, mask, disp)]
+  img, wts, _ = TR.forward_splat(t64[0], t64[1], t64[2],
+                                 torch.tensor(mat, dtype=torch.float64), s, bg,
+                                 md, zb, compose)
+  gen = torch.Generator().manual_seed(0)
+  cimg = torch.rand(img.shape, generator=gen, dtype=torch.float64)
+  cwts = torch.rand(wts.shape, generator=gen, dtype=torch.float64) * 1e-3
+  ((img * cimg).sum() + (torch.log(wts) * cwts).sum()).backward()
+
+  t32 = [torch.tensor(x, device=dev, requires_grad=True)
+         for x in (tex, mask, disp)]
+  img_g, wts_g = ldi.forward_splat_matrix(
+      t32, torch.tensor(mat), compose_layers=compose, trg_downsampling=s,
+      bg_layer_disp=bg, max_disp=md, zbuf_scale=zb)
+  ((img_g * cimg.float().to(dev)).sum() +
+   (torch.log(wts_g) * cwts.float().to(dev)).sum()).backward()
+  for a, b_, name in zip(t32, t64, ('tex', 'mask', 'disp')):
+    got = a.grad.cpu().double().numpy()
+    want = b_.grad.numpy()
+    scale = np.abs(want).max() + 1e-30
+    bad = np.abs(got - want) > 2e-4 * scale + 1e-3 * np.abs(want)
+    assert bad.mean() < 0.005, (name, bad.mean(), np.abs(got - want).max() / scale)
