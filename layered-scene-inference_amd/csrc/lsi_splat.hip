@@ -43,6 +43,7 @@ struct SplatArgs {
   float* canvas;  // ATOMIC path workspace
   int nch;        // canvas channels (4, or 5 with disparity)
   int ncanv;      // canvases per batch element (1 or L)
+  int shared;     // 1: compose without disparity, all layers share a canvas
   int band_rows;  // ROWBAND: target rows per workgroup
 };
 
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(256) void splat_atomic_kernel(SplatArgs a) {
               bl = tp[2 * d.tex_sc] * p.pw;
   const float dw = p.dd * p.pw;
   const size_t P = (size_t)d.Ht * d.Wt;
-  const int lc = a.ncanv == 1 ? 0 : l;
+  const int lc = a.shared ? 0 : l;
   float* cv = a.canvas + ((size_t)lc * d.B + b) * P * a.nch;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(256) void splat_epilogue_kernel(SplatArgs a) {
   const float bg = d.bg_wt;
   const bool compose = d.flags & LSI_COMPOSE;
   const bool want_disp = d.flags & LSI_WANT_DISP;
-  if (a.ncanv == 1) {  // compose, no disparity: one shared canvas, L x bg
+  if (a.shared) {  // compose, no disparity: one shared canvas, L x bg
     const float* c = a.canvas + ((size_t)b * P + p) * a.nch;
     const float lbg = (float)d.L * bg;
     const float w = c[3] + lbg;
@@ -529,6 +530,7 @@ int lsi_splat_fwd(const LsiSplatDesc* d, const float* tex, const float* disp,
   a.canvas = (float*)workspace;
   a.nch = canvas_channels(d);
   a.ncanv = canvas_count(d);
+  a.shared = (d->flags & LSI_COMPOSE) && !(d->flags & LSI_WANT_DISP);
   a.band_rows = 0;
 
   int path = d->path;
@@ -585,7 +587,7 @@ int lsi_project_indices(const LsiSplatDesc* d, const float* disp,
   a.d = *d;
   a.tex = nullptr; a.disp = disp; a.mask = mask; a.M = M;
   a.out_img = a.out_wts = a.out_disp = a.canvas = nullptr;
-  a.nch = 4; a.ncanv = 1; a.band_rows = 0;
+  a.nch = 4; a.ncanv = 1; a.shared = 0; a.band_rows = 0;
   const int npx = d->H * d->W;
   hipLaunchKernelGGL(project_indices_kernel,
                      dim3((npx + 255) / 256, d->B, d->L), dim3(256), 0,
@@ -622,7 +624,7 @@ int lsi_splat_bwd(const LsiSplatDesc* d, const float* tex, const float* disp,
   a.d = *d;
   a.tex = tex; a.disp = disp; a.mask = mask; a.M = M;
   a.out_img = a.out_wts = a.out_disp = a.canvas = nullptr;
-  a.nch = 4; a.ncanv = 1; a.band_rows = 0;
+  a.nch = 4; a.ncanv = 1; a.shared = 0; a.band_rows = 0;
   const int npx = d->H * d->W;
   hipLaunchKernelGGL(splat_bwd_kernel, dim3((npx + 255) / 256, d->B, d->L),
                      dim3(256), 0, stream, a, (const float4*)workspace, g_tex,
