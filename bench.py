@@ -1,0 +1,285 @@
+"""Headline benchmark: rendered views/sec of the LDI splat+warp hot path.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2]
+
+A "step" is one `forward_splat(compose_layers=True, compute_trg_disp=False,
+trg_downsampling=0.5)` (reference ldi.py:71-182: projection + soft z-buffer
+weights + 4-corner splat + normalise/compose) over one batch of synthetic LDI
+tensors that are already resident in HBM.  Prints ONE JSON line (rank 0).
+
+Workloads (BASELINE.json `configs`):
+  cfg2  KITTI stereo, 2-layer, 256x768, batch 4 per GPU   (default; weak scaling)
+  cfg3  KITTI, 4-layer, 256x768, batch 32 total, sharded over the ranks (strong)
+  cfg4  synthetic 3-layer 256x256, batch 64 total, general poses (strong)
+  cfg5  KITTI 4-layer 512x1536, batch 8 total (strong)
+Multi-GPU: the batch shards along B with NO data-path collective (replicas of
+an embarrassingly parallel renderer); RCCL is used only for the barrier and
+the max-over-ranks of the elapsed time.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, 'layered-scene-inference_amd'))
+
+from lsi import _C  # noqa: E402
+from lsi.geometry import ldi, projection  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+WORKLOADS = {
+    # name: (L, H, W, batch, batch_is_per_gpu, cameras, max_disp, bg_layer_disp)
+    'cfg2': (2, 256, 768, 4, True, 'kitti', 0.4, 1e-3),
+    'cfg3': (4, 256, 768, 32, False, 'kitti', 0.4, 1e-3),
+    'cfg4': (3, 256, 256, 64, False, 'synthetic', 1.0, 0.2),
+    'cfg5': (4, 512, 1536, 8, False, 'kitti', 0.4, 1e-3),
+}
+ZBUF_SCALE = 50.0
+S = 0.5
+
+
+def algorithmic_bytes(nl, b, h, w):
+  """read L*B*H*W*16 B (RGB + disparity) + B*64 B (M); write
+  B*Ht*Wt*16 B (RGB + weight), compose mode."""
+  return nl * b * h * w * 16 + b * 64 + b * (h // 2) * (w // 2) * 16
+
+
+def box_blur(x, radius):
+  k = 2 * radius + 1
+  pad = torch.nn.functional.pad(x, (radius, radius, radius, radius),
+                                mode='replicate')
+  return torch.nn.functional.avg_pool2d(pad, k, stride=1)
+
+
+def make_inputs(nl, b, h, w, cams, max_disp, seed, dev):
+  """Seeded synthetic LDI + cameras."""
+  gen = torch.Generator(device='cpu').manual_seed(seed)
+  tex = torch.rand((nl, b, h, w, 3), generator=gen).to(dev)
+  noise = torch.rand((nl * b, 1, h, w), generator=gen).to(dev)
+  field = box_blur(noise, 8)
+  field = (field - field.amin(dim=(2, 3), keepdim=True)) / (
+      field.amax(dim=(2, 3), keepdim=True) - field.amin(dim=(2, 3), keepdim=True)
+      + 1e-12)
+  field = torch.sigmoid(4.0 * (field - 0.5)).reshape(nl, b, h, w, 1)
+  scale = torch.tensor([(nl - l) / nl for l in range(nl)],
+                       device=dev).view(nl, 1, 1, 1, 1)
+  if cams == 'kitti':
+    disp = (max_disp * field * scale).contiguous()
+    k = torch.tensor([[0.58 * w, 0, w / 2.0], [0, 0.58 * w, h / 2.0],
+                      [0, 0, 1.0]])
+    k = k.expand(b, 3, 3).contiguous()
+    rot = torch.eye(3).expand(b, 3, 3).contiguous()
+    t = torch.tensor([[-0.532], [0.0], [0.0]]).expand(b, 3, 1).contiguous()
+  else:
+    disp = (0.28 + 0.22 * field * scale).contiguous()
+    k = torch.tensor([[float(w), 0, w / 2.0], [0, float(h), h / 2.0],
+                      [0, 0, 1.0]]).expand(b, 3, 3).contiguous()
+    rs = np.random.RandomState(seed)
+    rots, ts = [], []
+    for _ in range(b):  # look-at pose, syntheticPlanes/data.py:29-52
+      cam = np.array([rs.uniform(-.5, .5), rs.uniform(-.5, .5), 0.0])
+      at = np.array([rs.uniform(-.5, .5), rs.uniform(-.5, .5),
+                     rs.uniform(3.0, 3.5)])
+      z = (at - cam) / np.linalg.norm(at - cam)
+      x = np.cross([0, 1.0, 0], z)
+      x /= np.linalg.norm(x)
+      y = np.cross(z, x)
+      r = np.stack([x, y, z])
+      rots.append(r)
+      ts.append((-r @ cam).reshape(3, 1))
+    rot = torch.tensor(np.stack(rots), dtype=torch.float32)
+    t = torch.tensor(np.stack(ts), dtype=torch.float32)
+  mat = projection.forward_projection_matrix(k, k, rot, t)  # host, fp32
+  return tex, disp, mat
+
+
+class Renderer(object):
+  """Pre-bound C-ABI call: descriptor, outputs and workspace allocated once."""
+
+  def __init__(self, tex, disp, mat_host, max_disp, bg_layer_disp, path,
+               band_rows=0, threads=0):
+    dev = tex.device
+    nl, b, h, w, _ = tex.shape
+    ht, wt = h // 2, w // 2
+    bg = _C.bg_weight(bg_layer_disp, max_disp, ZBUF_SCALE)
+    self.desc = ldi._desc(tex, None, disp, ht, wt, S, max_disp, ZBUF_SCALE, bg,
+                          _C.LSI_COMPOSE, 0, band_rows, threads)
+    ldi.select_path(self.desc, mat_host, path)
+    self.path_name = _C.PATH_NAMES[self.desc.path]
+    self.tex, self.disp = tex, disp
+    self.mat = mat_host.to(dev).contiguous()
+    self.img = torch.empty((1, b, ht, wt, 3), device=dev)
+    self.wts = torch.empty((1, b, ht, wt, 1), device=dev)
+    lib = _C.lib()
+    self.ws_bytes = int(lib.lsi_splat_workspace_bytes(ctypes.byref(self.desc)))
+    self.ws = torch.empty((max(self.ws_bytes, 16),), dtype=torch.uint8,
+                          device=dev)
+    self.fn = lib.lsi_splat_fwd
+    self.dev = dev
+
+  def launch(self):
+    rc = self.fn(ctypes.byref(self.desc), _C.ptr(self.tex), _C.ptr(self.disp),
+                 None, _C.ptr(self.mat), _C.ptr(self.img), _C.ptr(self.wts),
+                 None, _C.ptr(self.ws), self.ws_bytes, _C.stream_ptr(self.dev))
+    if rc != 0:
+      _C.check(rc, 'lsi_splat_fwd')
+
+
+def cpu_baseline(nl, b, h, w, cams, max_disp, bg, budget_s=15.0):
+  """The plain-C oracle port timed on this host's cores, on a bounded sample of
+  the same workload (same shapes/cameras; batch capped at 2)."""
+  sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+  import ref_cpu  # the checker, used here only as the reported CPU baseline
+  bb = min(b, 2)
+  tex, disp, mat = make_inputs(nl, bb, h, w, cams, max_disp, 123,
+                               torch.device('cpu'))
+  tex, disp, mat = tex.numpy(), disp.numpy(), mat.numpy()
+  cores = ref_cpu.num_threads()
+  ref_cpu.forward_splat(tex, None, disp, mat, S, bg, max_disp, ZBUF_SCALE, True,
+                        want_disp=False)  # warm-up
+  times = []
+  t_end = time.time() + budget_s
+  while len(times) < 5 or (time.time() < t_end and len(times) < 200):
+    t0 = time.perf_counter()
+    ref_cpu.forward_splat(tex, None, disp, mat, S, bg, max_disp, ZBUF_SCALE,
+                          True, want_disp=False)
+    times.append(time.perf_counter() - t0)
+  med = float(np.median(times))
+  return {
+      'value': bb / med, 'unit': 'views/s', 'cores': cores, 'kind': 'port',
+      'sample': '%d runs of oracle/lsi_ref_cpu.c (fused C + OpenMP) on '
+                'L=%d B=%d %dx%d, median' % (len(times), nl, bb, h, w),
+  }
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--gpus', type=int, default=1)
+  ap.add_argument('--steps', type=int, default=200)
+  ap.add_argument('--warmup', type=int, default=20)
+  ap.add_argument('--workload', default='cfg2', choices=sorted(WORKLOADS))
+  ap.add_argument('--path', default='auto', choices=['auto', 'atomic', 'rowband', 'stream'])
+  ap.add_argument('--launch', default='graph', choices=['graph', 'eager'])
+  ap.add_argument('--band-rows', type=int, default=0)
+  ap.add_argument('--threads', type=int, default=0)
+  ap.add_argument('--no-cpu-baseline', action='store_true')
+  args = ap.parse_args()
+
+  world = int(os.environ.get('WORLD_SIZE', '1'))
+  rank = int(os.environ.get('RANK', '0'))
+  local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+  if args.gpus > 1 and world != args.gpus:
+    raise SystemExit('launch with torch.distributed.run --nproc-per-node %d'
+                     % args.gpus)
+  dist = None
+  if world > 1:
+    import torch.distributed as dist
+    dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+  torch.cuda.set_device(local_rank)
+  dev = torch.device('cuda', local_rank)
+
+  nl, h, w, batch, per_gpu, cams, max_disp, bg = WORKLOADS[args.workload]
+  if per_gpu:
+    b_local, scaling = batch, 'weak'
+  else:
+    if batch % world:
+      raise SystemExit('batch %d does not split over %d ranks' % (batch, world))
+    b_local, scaling = batch // world, 'strong'
+  tex, disp, mat = make_inputs(nl, b_local, h, w, cams, max_disp, 1000 + rank,
+                               dev)
+  r = Renderer(tex, disp, mat, max_disp, bg, args.path, args.band_rows,
+               args.threads)
+
+  stream = torch.cuda.Stream(device=dev)
+  launch_mode = args.launch
+  with torch.cuda.stream(stream):
+    for _ in range(max(args.warmup, 1)):
+      r.launch()
+    stream.synchronize()
+    graph = None
+    if launch_mode == 'graph':
+      try:
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=stream):
+          for _ in range(args.steps):
+            r.launch()
+        graph.replay()          # one untimed replay (graph upload)
+        stream.synchronize()
+      except Exception as e:  # pylint: disable=broad-except
+        sys.stderr.write('graph capture failed (%s); eager launches\n' % e)
+        graph, launch_mode = None, 'eager'
+
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    if dist is not None:
+      dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    if graph is not None:
+      graph.replay()
+    else:
+      for _ in range(args.steps):
+        r.launch()
+    ev1.record(stream)
+    torch.cuda.synchronize()
+    if dist is not None:
+      dist.barrier()
+    elapsed = time.perf_counter() - t0
+    ev_ms = ev0.elapsed_time(ev1)
+
+  if dist is not None:
+    tmax = torch.tensor([elapsed, ev_ms], device=dev, dtype=torch.float64)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed, ev_ms = float(tmax[0]), float(tmax[1])
+
+  if rank == 0:
+    views = b_local * world * args.steps
+    alg = algorithmic_bytes(nl, b_local, h, w)
+    kern_s = ev_ms * 1e-3 / args.steps
+    achieved = alg / kern_s / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
+    if os.path.exists(tpath):
+      traffic = json.load(open(tpath)).get('%s:%s' % (args.workload,
+                                                       r.path_name))
+    out = {
+        'metric': 'rendered views/sec (BxLxHxW splat+warp)',
+        'value': views / elapsed, 'unit': 'views/s', 'n_gpus': world,
+        'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': elapsed * 1e3 / args.steps, 'higher_is_better': True,
+        'scaling': scaling, 'vs_baseline': None, 'dtype': 'f32',
+        'data': 'synthetic',
+        'config': {
+            'workload': '%s: %d-layer LDI %dx%d, batch %d per GPU (%d total), '
+                        'trg_downsampling 0.5, %s cameras, compose_layers' %
+                        (args.workload, nl, h, w, b_local, b_local * world,
+                         cams),
+            'kernel_path': r.path_name, 'launch': launch_mode,
+            'parallelism': 'batch-sharded replicas x%d (no collective)' % world,
+        },
+        'roofline': {
+            'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS,
+            'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS,
+            'traffic': traffic,
+            'kernel': 'splat_%s_kernel' % r.path_name,
+            'algorithmic_bytes_per_launch': alg,
+            'avg_launch_us': kern_s * 1e6,
+        },
+    }
+    if world == 1 and not args.no_cpu_baseline:
+      out['cpu_baseline'] = cpu_baseline(nl, b_local, h, w, cams, max_disp, bg)
+    print(json.dumps(out))
+  if dist is not None:
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+  main()

@@ -51,10 +51,15 @@ extern "C" {
 /* LsiSplatDesc.path: which kernel family renders the splat.                  */
 #define LSI_PATH_AUTO 0      /* library decides from the descriptor          */
 #define LSI_PATH_ATOMIC 1    /* source-parallel, global fp32 atomics; any M   */
-#define LSI_PATH_ROWBAND 2   /* target-row-band tiles accumulated in LDS;     */
-                             /* requires M[b][1][3] == M[b][2][3] == 0 for    */
-                             /* every b (target row independent of disparity, */
-                             /* e.g. rectified stereo) -- see rowband_ok.     */
+#define LSI_PATH_ROWBAND 2   /* target-row-band tiles accumulated in LDS with */
+                             /* fp32 LDS atomics; requires M[b][1][3] ==      */
+                             /* M[b][2][3] == 0 for every b (target row       */
+                             /* independent of disparity) -- lsi_rowband_ok.  */
+#define LSI_PATH_STREAM 3    /* row-uniform projections (additionally         */
+                             /* M[b][1][0] == M[b][2][0] == 0: rectified      */
+                             /* stereo): wave-private LDS row windows updated */
+                             /* by plain read-modify-write, merged into       */
+                             /* register accumulators -- lsi_stream_ok.       */
 
 typedef void* lsi_stream_t; /* hipStream_t */
 
@@ -77,8 +82,9 @@ typedef struct LsiSplatDesc {
   float bg_wt;            /* lsi_bg_weight(bg_layer_disp, max_disp, scale)   */
   uint32_t flags;
   int32_t path;
-  /* ROWBAND only: set by the caller from a host copy of M (lsi_rowband_ok). */
-  int32_t reserved0, reserved1;
+  /* Tuning knobs, 0 = library default: target rows per workgroup, threads   */
+  /* per workgroup, and (STREAM) LDS window cells per wave = lsi_stream_ok(). */
+  int32_t tune_rows, tune_threads, tune_window, reserved;
 } LsiSplatDesc;
 
 /* Library version (LSI_VERSION of the build). */
@@ -102,6 +108,14 @@ float lsi_bg_weight(double bg_layer_disp, double max_disp, double zbuf_scale);
  * over the whole source image), else 0.
  */
 int lsi_rowband_ok(const LsiSplatDesc* desc, const float* M_host);
+
+/*
+ * Host-side test for LSI_PATH_STREAM on a HOST copy of the matrices: returns 0
+ * when the path does not apply (projection not row-uniform, unsupported
+ * strides/alignment, LSI_WANT_DISP), else the number of LDS window cells per
+ * wave the call needs (put it in desc->tune_window).
+ */
+int lsi_stream_ok(const LsiSplatDesc* desc, const float* M_host);
 
 /* Bytes of device workspace lsi_splat_fwd needs for this descriptor. */
 size_t lsi_splat_workspace_bytes(const LsiSplatDesc* desc);

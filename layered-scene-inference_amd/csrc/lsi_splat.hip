@@ -29,23 +29,9 @@
 
 using namespace lsi;
 
-namespace {
+#include "lsi_splat_internal.h"
 
-struct SplatArgs {
-  LsiSplatDesc d;
-  const float* tex;
-  const float* disp;
-  const float* mask;
-  const float* M;
-  float* out_img;
-  float* out_wts;
-  float* out_disp;
-  float* canvas;  // ATOMIC path workspace
-  int nch;        // canvas channels (4, or 5 with disparity)
-  int ncanv;      // canvases per batch element (1 or L)
-  int shared;     // 1: compose without disparity, all layers share a canvas
-  int band_rows;  // ROWBAND: target rows per workgroup
-};
+namespace {
 
 // ---------------------------------------------------------------------------
 // LSI_PATH_ATOMIC
@@ -537,11 +523,11 @@ int lsi_splat_fwd(const LsiSplatDesc* d, const float* tex, const float* disp,
   if (path == LSI_PATH_AUTO) path = LSI_PATH_ATOMIC;  // AUTO needs host M:
                                                       // callers use rowband_ok
   if (path == LSI_PATH_ROWBAND) {
-    const int R = d->reserved0 > 0 ? d->reserved0 : pick_band_rows(d);
+    const int R = d->tune_rows > 0 ? d->tune_rows : pick_band_rows(d);
     const size_t lds = rowband_lds_bytes(d, R);
     if (lds > 160 * 1024) return LSI_EINVAL;
     a.band_rows = R;
-    const int threads = d->reserved1 > 0 ? d->reserved1 : 512;
+    const int threads = d->tune_threads > 0 ? d->tune_threads : 512;
     dim3 grid((d->Ht + R - 1) / R, d->B);
     if (a.nch == 5) {
       if (hipFuncSetAttribute((const void*)splat_rowband_kernel<5>,
@@ -560,6 +546,7 @@ int lsi_splat_fwd(const LsiSplatDesc* d, const float* tex, const float* disp,
     }
     return hipGetLastError() == hipSuccess ? LSI_OK : LSI_ELAUNCH;
   }
+  if (path == LSI_PATH_STREAM) return lsi_stream_launch(a, stream);
   if (path != LSI_PATH_ATOMIC) return LSI_EINVAL;
 
   const size_t need = lsi_splat_workspace_bytes(d);

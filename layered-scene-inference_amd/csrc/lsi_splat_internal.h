@@ -1,0 +1,24 @@
+// Internal (non-ABI) declarations shared by the splat translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/lsi_hip.h"
+
+struct SplatArgs {
+  LsiSplatDesc d;
+  const float* tex;
+  const float* disp;
+  const float* mask;
+  const float* M;
+  float* out_img;
+  float* out_wts;
+  float* out_disp;
+  float* canvas;  // ATOMIC path workspace
+  int nch;        // canvas channels (4, or 5 with disparity)
+  int ncanv;      // canvases per batch element (1 or L)
+  int shared;     // 1: compose without disparity, all layers share a canvas
+  int band_rows;  // ROWBAND: target rows per workgroup
+};
+
+// LSI_PATH_STREAM launcher (lsi_splat_stream.hip).
+int lsi_stream_launch(const SplatArgs& a, hipStream_t stream);

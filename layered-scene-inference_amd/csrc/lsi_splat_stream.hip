@@ -1,0 +1,450 @@
+// LSI_PATH_STREAM: forward splat for row-uniform projections (rectified stereo)
+// without floating-point atomics on the hot path.
+//
+// Why this exists: on gfx950 ds_add_f32 retires ~0.33 lanes/clk/CU (measured,
+// tools/microbench2.hip: 194 clk per wave instruction) while a plain LDS
+// read-modify-write of a float4 costs ~20 clk per wave instruction and integer
+// LDS atomics ~9 clk.  A splat needs 16 accumulations per source pixel, so the
+// accumulation has to be plain RMW on memory only one wave touches.
+//
+// Precondition (lsi_stream_ok): for every b, M[1][0] = M[1][3] = M[2][0] =
+// M[2][3] = 0 and the normaliser is positive.  Then the target ROW of a source
+// pixel, its two row weights (wy0, wy1) and the normaliser depend on the source
+// row only, and the corner weights factor as (wx * wy) -- up to the reference's
+// 1e-3 clamp on the product (sampling.py:218-222), which is honoured exactly by
+// routing the rare affected corners through an exact slow path.
+//
+// Structure.  Workgroup = (band of R target rows, batch element b), NW waves.
+//   task  = (source row y, layer l, 256-pixel segment j); every step each wave
+//           runs one task:
+//     x-pass  lanes load 4 consecutive pixels (dwordx4), project them, and add
+//             V*wx0 / V*wx1 (V = (r,g,b,1)*pixel weight) into the wave's
+//             PRIVATE window of float4 cells in LDS by plain RMW.  Lanes are 4
+//             pixels apart, so their cells are distinct whenever floor(X) is
+//             strictly increasing across the wave (checked); otherwise the
+//             lanes are ranked per cell with an integer LDS atomic and the RMW
+//             is issued rank by rank.
+//     barrier
+//     merge   every target cell of the band is owned by one lane, which keeps
+//             its accumulator in REGISTERS and adds window[cell] * wy of each
+//             task that touches its row.  No shared accumulation tile, no
+//             locks, deterministic summation order.
+//     barrier
+//   Corners that the factorisation cannot represent exactly (clamped products,
+//   cells outside the window because the disparity leaves [0, max_disp]) are
+//   added with fp32 LDS atomics into a small `extras` tile -- exact for any
+//   input, slow only when such corners are common.
+//   epilogue: (acc + extras + background) normalised, each output written once.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/lsi_hip.h"
+#include "lsi_common.h"
+#include "lsi_splat_internal.h"
+
+#pragma clang fp contract(off)
+
+using namespace lsi;
+
+namespace {
+
+constexpr int SEG = 256;   // source pixels per task (64 lanes x 4)
+constexpr int MAXU = 4;    // target-cell units (64 cells) owned per wave
+constexpr int MAXNW = 16;
+
+struct TaskInfo {
+  int row0;        // target row of the task's top contribution, band-relative
+  float wy0, wy1;  // row weights incl. border masks (sampling.py:210-211)
+  int wlo, wwin;   // window: absolute first cell, number of cells
+};
+
+struct StreamCfg {
+  int R;      // target rows per workgroup
+  int wmax;   // window cells per wave
+};
+
+#define LSI_COMPILER_FENCE() asm volatile("" ::: "memory")
+
+__device__ __forceinline__ float4 f4_madd(float4 t, float4 v, float w) {
+  t.x += v.x * w; t.y += v.y * w; t.z += v.z * w; t.w += v.w * w;
+  return t;
+}
+
+template <int LAYOUT>  // 0: channels-last RGB (x stride 3), 1: planar
+__global__ __launch_bounds__(1024) void splat_stream_kernel(SplatArgs a,
+                                                            StreamCfg cfg) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const LsiSplatDesc& d = a.d;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int T = blockDim.x, NW = T >> 6;
+  const int R = cfg.R, WMAX = cfg.wmax;
+  const int Wt = d.Wt, Ht = d.Ht, W = d.W;
+  const int b = blockIdx.y;
+  const int row0 = blockIdx.x * R;
+  const int rows = min(R, Ht - row0);
+  const int NB = (Wt + 63) >> 6;
+  const int nunits = rows * NB;
+
+  float4* rb_all = reinterpret_cast<float4*>(smem_raw);          // [NW][WMAX]
+  unsigned* cnt_all = reinterpret_cast<unsigned*>(rb_all + NW * WMAX);
+  float* extras = reinterpret_cast<float*>(cnt_all + NW * WMAX);  // [R][Wt][4]
+  TaskInfo* tinfo = reinterpret_cast<TaskInfo*>(extras + R * Wt * 4);
+  int* yrange = reinterpret_cast<int*>(tinfo + MAXNW);
+  float4* rb = rb_all + wave * WMAX;
+  unsigned* cnt = cnt_all + wave * WMAX;
+
+  const float* __restrict__ m = a.M + 16 * b;
+  const float s = d.trg_downsampling;
+  const float xmax = (float)Wt - 1.0f, ymax = (float)Ht - 1.0f;
+  const bool has_mask = d.flags & LSI_HAS_MASK;
+  const bool compose = d.flags & LSI_COMPOSE;
+
+  // ---- one-time init ------------------------------------------------------
+  for (int i = tid; i < NW * WMAX; i += T) {
+    rb_all[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    cnt_all[i] = 0u;
+  }
+  for (int i = tid; i < R * Wt * 4; i += T) extras[i] = 0.0f;
+  if (tid == 0) { yrange[0] = d.H; yrange[1] = -1; }
+  __syncthreads();
+  {  // source rows whose target rows (y0, y0+1) intersect the band
+    int lo = d.H, hi = -1;
+    for (int y = tid; y < d.H; y += T) {
+      const float py = (float)y + 0.5f;
+      const float q1 = mrow(m, 1, 0.5f, py, 0.0f);
+      const float nd = safe_den(mrow(m, 2, 0.5f, py, 0.0f));
+      const float Y = div_rn(q1, nd) * s - 0.5f;
+      if (!finite_f(Y)) continue;
+      const float y0 = floorf(Y);
+      if (y0 >= (float)(row0 - 1) && y0 <= (float)(row0 + rows - 1)) {
+        lo = min(lo, y); hi = max(hi, y);
+      }
+    }
+    if (hi >= 0) { atomicMin(&yrange[0], lo); atomicMax(&yrange[1], hi); }
+  }
+  __syncthreads();
+  const int y_lo = yrange[0], y_hi = yrange[1];
+  const int nsrc = (y_hi >= y_lo) ? (y_hi - y_lo + 1) : 0;
+  const int nseg = (W + SEG - 1) / SEG;
+  const float bg = d.bg_wt;
+  const size_t P = (size_t)Ht * Wt;
+
+  const int npass = compose ? 1 : d.L;
+  const int Lp = compose ? d.L : 1;
+  for (int pass = 0; pass < npass; ++pass) {
+    float4 acc[MAXU];
+#pragma unroll
+    for (int u = 0; u < MAXU; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int l_begin = compose ? 0 : pass;
+    const int ntask = nsrc * Lp * nseg;
+    const int nstep = (ntask + NW - 1) / NW;
+
+    for (int step = 0; step < nstep; ++step) {
+      // ================= x-pass: one task per wave ========================
+      const int tg = step * NW + wave;
+      TaskInfo ti;
+      ti.row0 = -1000000; ti.wy0 = 0.f; ti.wy1 = 0.f; ti.wlo = 0; ti.wwin = 0;
+      int l = 0, y = 0, xs = 0;
+      float nden = 1.0f;
+      bool tvalid = tg < ntask;
+      if (tvalid) {
+        const int j = tg % nseg;
+        const int tmp = tg / nseg;
+        l = l_begin + tmp % Lp;
+        y = y_lo + tmp / Lp;
+        xs = j * SEG;
+        const float py = (float)y + 0.5f;
+        const float q1 = mrow(m, 1, 0.5f, py, 0.0f);
+        nden = safe_den(mrow(m, 2, 0.5f, py, 0.0f));
+        const float Y = div_rn(q1, nden) * s - 0.5f;
+        if (finite_f(Y) && fabsf(Y) < 1.0e7f) {
+          const Axis ay = splat_axis(Y, ymax);
+          ti.row0 = (int)floorf(Y) - row0;
+          ti.wy0 = ay.w0;
+          ti.wy1 = ay.w1;
+          // window hint: cells reachable for d in [0, max_disp] over the segment
+          const int xe = min(xs + SEG, W);
+          float lo = __builtin_inff(), hi = -__builtin_inff();
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const float px = (float)((c & 1) ? (xe - 1) : xs) + 0.5f;
+            const float dd = (c & 2) ? d.max_disp : 0.0f;
+            const float X = div_rn(mrow(m, 0, px, py, dd), nden) * s - 0.5f;
+            lo = fminf(lo, X); hi = fmaxf(hi, X);
+          }
+          if (finite_f(lo) && finite_f(hi) && fabsf(lo) < 1.0e7f &&
+              fabsf(hi) < 1.0e7f) {
+            ti.wlo = (int)floorf(lo) - 1;
+            ti.wwin = min(WMAX, (int)floorf(hi) + 3 - ti.wlo);
+          }
+        } else {
+          tvalid = false;
+        }
+      }
+      if (lane == 0) tinfo[wave] = ti;
+      // this wave's window is zero here (zeroed after the previous merge)
+
+      if (tvalid) {
+        const int x = xs + 4 * lane;
+        const bool inrange = x < W;
+        float dv[4] = {0.f, 0.f, 0.f, 0.f}, mk[4] = {1.f, 1.f, 1.f, 1.f};
+        float cr[4], cg[4], cb[4];
+        if (inrange) {
+          const float4 d4 = *reinterpret_cast<const float4*>(
+              a.disp + l * d.disp_sl + b * d.disp_sb + y * d.disp_sy + x);
+          dv[0] = d4.x; dv[1] = d4.y; dv[2] = d4.z; dv[3] = d4.w;
+          const float* tp = a.tex + l * d.tex_sl + b * d.tex_sb + y * d.tex_sy;
+          if (LAYOUT == 0) {
+            const float4* t4 = reinterpret_cast<const float4*>(tp + 3 * x);
+            const float4 t0 = t4[0], t1 = t4[1], t2 = t4[2];
+            cr[0] = t0.x; cg[0] = t0.y; cb[0] = t0.z;
+            cr[1] = t0.w; cg[1] = t1.x; cb[1] = t1.y;
+            cr[2] = t1.z; cg[2] = t1.w; cb[2] = t2.x;
+            cr[3] = t2.y; cg[3] = t2.z; cb[3] = t2.w;
+          } else {
+            const float4 r4 = *reinterpret_cast<const float4*>(tp + x);
+            const float4 g4 =
+                *reinterpret_cast<const float4*>(tp + d.tex_sc + x);
+            const float4 b4 =
+                *reinterpret_cast<const float4*>(tp + 2 * d.tex_sc + x);
+            cr[0] = r4.x; cr[1] = r4.y; cr[2] = r4.z; cr[3] = r4.w;
+            cg[0] = g4.x; cg[1] = g4.y; cg[2] = g4.z; cg[3] = g4.w;
+            cb[0] = b4.x; cb[1] = b4.y; cb[2] = b4.z; cb[3] = b4.w;
+          }
+          if (has_mask) {
+            const float4 m4 = *reinterpret_cast<const float4*>(
+                a.mask + l * d.mask_sl + b * d.mask_sb + y * d.mask_sy + x);
+            mk[0] = m4.x; mk[1] = m4.y; mk[2] = m4.z; mk[3] = m4.w;
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { cr[i] = cg[i] = cb[i] = 0.f; }
+        }
+        const float py = (float)y + 0.5f;
+        const float wy0 = ti.wy0, wy1 = ti.wy1;
+        const float wlo_f = (float)ti.wlo;
+        const float whi_f = (float)(ti.wlo + ti.wwin - 2);  // last left cell
+
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float px = (float)(x + i) + 0.5f;
+          const float q0 = mrow(m, 0, px, py, dv[i]);
+          const float q3 = mrow(m, 3, px, py, dv[i]);
+          const float X = div_rn(q0, nden) * s - 0.5f;
+          // a non-finite disparity poisons q1/n in the reference too: dropped
+          const bool ok = inrange && finite_f(X) && finite_f(dv[i]);
+          const float dd = div_rn(q3, nden);
+          const float pw = zbuffer_weight(div_rn(dd, d.max_disp), d.zbuf_scale) *
+                           mk[i];
+          const Axis ax = splat_axis(X, xmax);
+          const float x0raw = floorf(X);
+          const bool active = ok && (pw != 0.0f);
+          // exact corner weights of the reference
+          const float p00 = ax.w0 * wy0, p10 = ax.w1 * wy0;
+          const float p01 = ax.w0 * wy1, p11 = ax.w1 * wy1;
+          // the factorised form is exact iff no non-zero product is clamped
+          const bool sep_ok = (p00 > 1e-3f || p00 == 0.f) &&
+                              (p10 > 1e-3f || p10 == 0.f) &&
+                              (p01 > 1e-3f || p01 == 0.f) &&
+                              (p11 > 1e-3f || p11 == 0.f);
+          const bool inwin = (x0raw >= wlo_f) && (x0raw <= whi_f);
+          const bool fast = active && sep_ok && inwin;
+          const bool slow = active && !fast;
+          const float4 V = make_float4(cr[i] * pw, cg[i] * pw, cb[i] * pw, pw);
+
+          if (slow) {  // exact, rare: fp32 LDS atomics into the extras tile
+            const float wc[4] = {clamp_small(p00), clamp_small(p10),
+                                 clamp_small(p01), clamp_small(p11)};
+            const int cx[2] = {(int)ax.c0s, (int)ax.c1s};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const int r = ti.row0 + (k >> 1);
+              if (wc[k] == 0.0f || r < 0 || r >= rows) continue;
+              float* e = extras + ((size_t)r * Wt + cx[k & 1]) * 4;
+              atomic_add_f32(e + 0, V.x * wc[k]);
+              atomic_add_f32(e + 1, V.y * wc[k]);
+              atomic_add_f32(e + 2, V.z * wc[k]);
+              atomic_add_f32(e + 3, V.w * wc[k]);
+            }
+          }
+
+          // ---- conflict-free plain RMW into the private window ------------
+          const int cl = fast ? ((int)x0raw - ti.wlo) : 0;
+          const float prev = __shfl_up(x0raw, 1);
+          const bool mono_lane = (lane == 0) || !inrange || (x0raw > prev);
+          const bool mono = __ballot(mono_lane) == ~0ull;
+          if (mono) {
+            if (fast) rb[cl] = f4_madd(rb[cl], V, ax.w0);
+            LSI_COMPILER_FENCE();
+            if (fast) rb[cl + 1] = f4_madd(rb[cl + 1], V, ax.w1);
+            LSI_COMPILER_FENCE();
+          } else if (__ballot(fast) != 0ull) {
+            unsigned rank = 0u;
+            if (fast) rank = atomicAdd(&cnt[cl], 1u);
+            for (unsigned r = 0;; ++r) {
+              if (__ballot(fast && rank >= r) == 0ull) break;
+              const bool mine = fast && rank == r;
+              if (mine) rb[cl] = f4_madd(rb[cl], V, ax.w0);
+              LSI_COMPILER_FENCE();
+              if (mine) rb[cl + 1] = f4_madd(rb[cl + 1], V, ax.w1);
+              LSI_COMPILER_FENCE();
+            }
+            if (fast) cnt[cl] = 0u;
+            LSI_COMPILER_FENCE();
+          }
+        }
+      }
+      __syncthreads();
+
+      // ================= merge: cell owners gather the windows =============
+#pragma unroll
+      for (int u = 0; u < MAXU; ++u) {
+        const int unit = wave + u * NW;
+        if (unit >= nunits) continue;
+        const int r = unit / NB;
+        const int cell = (unit - r * NB) * 64 + lane;
+        for (int t = 0; t < NW; ++t) {
+          const TaskInfo q = tinfo[t];
+          float wy;
+          if (q.row0 == r) wy = q.wy0;
+          else if (q.row0 + 1 == r) wy = q.wy1;
+          else continue;
+          if (wy == 0.0f) continue;
+          const int rel = cell - q.wlo;
+          if (rel >= 0 && rel < q.wwin && cell < Wt)
+            acc[u] = f4_madd(acc[u], rb_all[t * WMAX + rel], wy);
+        }
+      }
+      __syncthreads();
+      // re-zero this wave's window for its next task
+      for (int c = lane; c < ti.wwin; c += 64)
+        rb[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+
+    // ================= epilogue for this pass ===============================
+    const float lbg = compose ? (float)d.L * bg : bg;
+    const int lo_ = compose ? 0 : pass;
+#pragma unroll
+    for (int u = 0; u < MAXU; ++u) {
+      const int unit = wave + u * NW;
+      if (unit >= nunits) continue;
+      const int r = unit / NB;
+      const int cell = (unit - r * NB) * 64 + lane;
+      if (cell >= Wt) continue;
+      float* e = extras + ((size_t)r * Wt + cell) * 4;
+      const float A0 = (acc[u].x + e[0]) + lbg, A1 = (acc[u].y + e[1]) + lbg,
+                  A2 = (acc[u].z + e[2]) + lbg, Wsum = (acc[u].w + e[3]) + lbg;
+      const float wd = safe_den(Wsum);
+      const size_t o =
+          ((size_t)lo_ * d.B + b) * P + (size_t)(row0 + r) * Wt + cell;
+      a.out_img[3 * o + 0] = div_rn(A0, wd);
+      a.out_img[3 * o + 1] = div_rn(A1, wd);
+      a.out_img[3 * o + 2] = div_rn(A2, wd);
+      a.out_wts[o] = Wsum;
+      if (pass + 1 < npass) { e[0] = 0.f; e[1] = 0.f; e[2] = 0.f; e[3] = 0.f; }
+    }
+    __syncthreads();
+  }
+}
+
+size_t stream_lds_bytes(const LsiSplatDesc* d, int R, int nw, int wmax) {
+  return (size_t)nw * wmax * 16 + (size_t)nw * wmax * 4 +
+         (size_t)R * d->Wt * 16 + MAXNW * sizeof(TaskInfo) + 16;
+}
+
+// layout class of the texture strides: 0 channels-last, 1 planar, -1 neither
+int tex_layout(const LsiSplatDesc* d) {
+  const bool al = (d->tex_sl % 4 == 0) && (d->tex_sb % 4 == 0) &&
+                  (d->tex_sy % 4 == 0);
+  if (!al) return -1;
+  if (d->tex_sc == 1 && d->tex_sx == 3) return 0;
+  if (d->tex_sx == 1 && d->tex_sc % 4 == 0) return 1;
+  return -1;
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int lsi_stream_ok(const LsiSplatDesc* d, const float* M) {
+  if (!d || !M) return 0;
+  if (!lsi_rowband_ok(d, M)) return 0;
+  if (d->flags & LSI_WANT_DISP) return 0;
+  if (d->W % 4 != 0) return 0;
+  if (tex_layout(d) < 0) return 0;
+  if (d->disp_sx != 1 || d->disp_sy % 4 || d->disp_sb % 4 || d->disp_sl % 4)
+    return 0;
+  if ((d->flags & LSI_HAS_MASK) &&
+      (d->mask_sx != 1 || d->mask_sy % 4 || d->mask_sb % 4 || d->mask_sl % 4))
+    return 0;
+  const float s = d->trg_downsampling;
+  float need = 0.0f;
+  for (int b = 0; b < d->B; ++b) {
+    const float* m = M + 16 * b;
+    if (m[4] != 0.0f || m[8] != 0.0f) return 0;  // M[1][0], M[2][0]
+    // normaliser over the rows (independent of x here)
+    const float n0 = m[9] * 0.5f + m[10];
+    const float n1 = m[9] * ((float)d->H - 0.5f) + m[10];
+    const float nmin = fminf(n0, n1);
+    const float span = (fabsf(m[0]) * (float)SEG + fabsf(m[3]) * d->max_disp) /
+                       nmin * s;
+    if (!(span == span)) return 0;
+    need = fmaxf(need, span);
+  }
+  int win = (int)ceilf(need) + 8;
+  win = (win + 63) / 64 * 64;
+  if (win < 64) win = 64;
+  if (win > 512) win = 512;  // beyond this the excess takes the exact slow path
+  return win;
+}
+
+int lsi_stream_launch(const SplatArgs& a, hipStream_t stream) {
+  const LsiSplatDesc* d = &a.d;
+  const int layout = tex_layout(d);
+  if (layout < 0 || (d->flags & LSI_WANT_DISP) || d->W % 4 != 0)
+    return LSI_EINVAL;
+  if (!aligned16(a.tex) || !aligned16(a.disp) ||
+      ((d->flags & LSI_HAS_MASK) && !aligned16(a.mask)))
+    return LSI_EINVAL;
+  if (d->tune_window <= 0) return LSI_EINVAL;  // from lsi_stream_ok
+  int threads = d->tune_threads > 0 ? d->tune_threads : 768;
+  threads = (threads + 63) / 64 * 64;
+  if (threads > 1024) threads = 1024;
+  const int nw = threads / 64;
+  const int NB = (d->Wt + 63) / 64;
+  StreamCfg cfg;
+  cfg.wmax = d->tune_window;
+  int R = d->tune_rows;
+  if (R <= 0) {  // tallest band that still gives >= 256 workgroups
+    R = 1;
+    for (int c = 2; c <= 16; c *= 2) {
+      if ((long)((d->Ht + c - 1) / c) * d->B < 256) break;
+      R = c;
+    }
+  }
+  while (R > 1 && (R * NB > MAXU * nw ||
+                   stream_lds_bytes(d, R, nw, cfg.wmax) > 150 * 1024))
+    R /= 2;
+  if (R * NB > MAXU * nw) return LSI_EINVAL;
+  const size_t lds = stream_lds_bytes(d, R, nw, cfg.wmax);
+  if (lds > 160 * 1024) return LSI_EINVAL;
+  cfg.R = R;
+  dim3 grid((d->Ht + R - 1) / R, d->B);
+  if (layout == 0) {
+    if (hipFuncSetAttribute((const void*)splat_stream_kernel<0>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+      return LSI_ELAUNCH;
+    hipLaunchKernelGGL(splat_stream_kernel<0>, grid, dim3(threads), lds, stream,
+                       a, cfg);
+  } else {
+    if (hipFuncSetAttribute((const void*)splat_stream_kernel<1>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+      return LSI_ELAUNCH;
+    hipLaunchKernelGGL(splat_stream_kernel<1>, grid, dim3(threads), lds, stream,
+                       a, cfg);
+  }
+  return hipGetLastError() == hipSuccess ? LSI_OK : LSI_ELAUNCH;
+}

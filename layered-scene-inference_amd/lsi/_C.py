@@ -14,7 +14,8 @@ SO_PATH = os.path.join(_PKG, 'liblsi_hip.so')
 
 LSI_OK = 0
 LSI_COMPOSE, LSI_WANT_DISP, LSI_HAS_MASK = 1, 2, 4
-LSI_PATH_AUTO, LSI_PATH_ATOMIC, LSI_PATH_ROWBAND = 0, 1, 2
+LSI_PATH_AUTO, LSI_PATH_ATOMIC, LSI_PATH_ROWBAND, LSI_PATH_STREAM = 0, 1, 2, 3
+PATH_NAMES = {1: 'atomic', 2: 'rowband', 3: 'stream'}
 
 _c_f = ctypes.POINTER(ctypes.c_float)
 _c_i = ctypes.POINTER(ctypes.c_int32)
@@ -30,7 +31,8 @@ class LsiSplatDesc(ctypes.Structure):
       [(n, ctypes.c_float) for n in (
           'trg_downsampling', 'max_disp', 'zbuf_scale', 'bg_wt')] +
       [('flags', ctypes.c_uint32), ('path', ctypes.c_int32),
-       ('reserved0', ctypes.c_int32), ('reserved1', ctypes.c_int32)])
+       ('tune_rows', ctypes.c_int32), ('tune_threads', ctypes.c_int32),
+       ('tune_window', ctypes.c_int32), ('reserved', ctypes.c_int32)])
 
 
 # name -> (restype, argtypes); every symbol include/lsi_hip.h declares.
@@ -41,6 +43,7 @@ SIGNATURES = {
     'lsi_strerror': (ctypes.c_char_p, [ctypes.c_int]),
     'lsi_bg_weight': (ctypes.c_float, [ctypes.c_double] * 3),
     'lsi_rowband_ok': (ctypes.c_int, [_DP, _VP]),
+    'lsi_stream_ok': (ctypes.c_int, [_DP, _VP]),
     'lsi_splat_workspace_bytes': (_SZ, [_DP]),
     'lsi_splat_fwd': (ctypes.c_int, [_DP] + [_VP] * 8 + [_SZ, _VP]),
     'lsi_splat_bwd_workspace_bytes': (_SZ, [_DP]),

@@ -44,26 +44,38 @@ def _desc(tex, mask, disp, ht, wt, s, max_disp, zbuf_scale, bg_wt, flags, path,
   d.trg_downsampling, d.max_disp, d.zbuf_scale = s, max_disp, zbuf_scale
   d.bg_wt = bg_wt
   d.flags, d.path = flags, path
-  d.reserved0, d.reserved1 = band_rows, threads
+  d.tune_rows, d.tune_threads = band_rows, threads
   return d
 
 
 def select_path(desc, mat_host, path='auto'):
-  """Chooses the kernel family.  `mat_host` is a CPU copy of the B x 4 x 4
-  projection matrices (or None => the general atomic path)."""
-  if path == 'atomic':
-    return _C.LSI_PATH_ATOMIC
-  ok = False
-  if mat_host is not None:
-    m = mat_host.contiguous()
-    ok = bool(_C.lib().lsi_rowband_ok(ctypes.byref(desc),
-                                      ctypes.c_void_p(m.data_ptr())))
-  if path == 'rowband':
-    if not ok:
-      raise RuntimeError('rowband path requested but the projection matrices '
-                         'do not satisfy its precondition (lsi_rowband_ok)')
-    return _C.LSI_PATH_ROWBAND
-  return _C.LSI_PATH_ROWBAND if ok else _C.LSI_PATH_ATOMIC
+  """Chooses the kernel family and stores it (plus the STREAM window size) in
+  `desc`.  `mat_host` is a CPU copy of the B x 4 x 4 projection matrices (None
+  => the general atomic path).  path: 'auto' | 'atomic' | 'rowband' | 'stream'."""
+  lib = _C.lib()
+  if path == 'atomic' or mat_host is None:
+    if path in ('rowband', 'stream'):
+      raise RuntimeError('%s path needs a host copy of the matrices' % path)
+    desc.path = _C.LSI_PATH_ATOMIC
+    return desc.path
+  m = mat_host.contiguous()
+  mp = ctypes.c_void_p(m.data_ptr())
+  win = int(lib.lsi_stream_ok(ctypes.byref(desc), mp)) if path in (
+      'auto', 'stream') else 0
+  band = bool(lib.lsi_rowband_ok(ctypes.byref(desc), mp))
+  if path == 'stream' and not win:
+    raise RuntimeError('stream path requested but its precondition does not '
+                       'hold (lsi_stream_ok)')
+  if path == 'rowband' and not band:
+    raise RuntimeError('rowband path requested but the projection matrices '
+                       'do not satisfy its precondition (lsi_rowband_ok)')
+  if win:
+    desc.path, desc.tune_window = _C.LSI_PATH_STREAM, win
+  elif band:
+    desc.path = _C.LSI_PATH_ROWBAND
+  else:
+    desc.path = _C.LSI_PATH_ATOMIC
+  return desc.path
 
 
 class _ForwardSplat(torch.autograd.Function):
@@ -93,7 +105,7 @@ class _ForwardSplat(torch.autograd.Function):
     desc = _desc(tex, mask, disp, ht, wt, float(s), float(cfg['max_disp']),
                  float(cfg['zbuf_scale']), bg_wt, flags, 0,
                  cfg.get('band_rows', 0), cfg.get('threads', 0))
-    desc.path = select_path(desc, mat_host, cfg.get('path', 'auto'))
+    select_path(desc, mat_host, cfg.get('path', 'auto'))
     nlo = 1 if cfg['compose_layers'] else nl
     img = torch.empty((nlo, b, ht, wt, 3), dtype=torch.float32, device=dev)
     wts = torch.empty((nlo, b, ht, wt, 1), dtype=torch.float32, device=dev)

@@ -46,21 +46,30 @@ def _rowband_ok(g):
   return bool(np.all(m[:, 1, 3] == 0) and np.all(m[:, 2, 3] == 0))
 
 
+def _stream_ok(g):
+  m = g['M']
+  return bool(_rowband_ok(g) and np.all(m[:, 1, 0] == 0) and
+              np.all(m[:, 2, 0] == 0) and g['tex'].shape[3] % 4 == 0)
+
+
 @pytest.mark.parametrize('case', FS_CASES)
 @pytest.mark.parametrize('compose', [True, False])
-@pytest.mark.parametrize('path', ['atomic', 'rowband'])
+@pytest.mark.parametrize('path', ['atomic', 'rowband', 'stream'])
 def test_forward_splat_matches_reference_goldens(case, compose, path, dev):
   from lsi.geometry import ldi
   g = golden(case)
   if path == 'rowband' and not _rowband_ok(g):
     pytest.skip('projection is not row-band (general pose)')
+  if path == 'stream' and not _stream_ok(g):
+    pytest.skip('projection is not row-uniform (stream path does not apply)')
   s, bg, md, zb = _params(g)
   ldi_src = [torch.tensor(g[k], device=dev) for k in ('tex', 'mask', 'disp')]
-  got = ldi.forward_splat_matrix(
-      ldi_src, torch.tensor(g['M']), compose_layers=compose,
-      compute_trg_disp=True, trg_downsampling=s, bg_layer_disp=bg, max_disp=md,
-      zbuf_scale=zb, path=path)
-  _cmp(got, g, 'compose' if compose else 'indep')
+  if path != 'stream':  # the stream path renders RGB + weights only
+    got = ldi.forward_splat_matrix(
+        ldi_src, torch.tensor(g['M']), compose_layers=compose,
+        compute_trg_disp=True, trg_downsampling=s, bg_layer_disp=bg,
+        max_disp=md, zbuf_scale=zb, path=path)
+    _cmp(got, g, 'compose' if compose else 'indep')
   # without the disparity output (the training configuration)
   img, wts = ldi.forward_splat_matrix(
       ldi_src, torch.tensor(g['M']), compose_layers=compose,
@@ -132,7 +141,7 @@ def _rot(ax, ay, az):
   return rz @ ry @ rx
 
 
-@pytest.mark.parametrize('path', ['atomic', 'rowband'])
+@pytest.mark.parametrize('path', ['atomic', 'rowband', 'stream'])
 @pytest.mark.parametrize('compose', [True, False])
 def test_config2_size_against_c_oracle(path, compose, dev, ref_cpu):
   """BASELINE config 2 shape (2-layer 256x768, s=0.5), batch 2, vs the C oracle."""
@@ -142,15 +151,17 @@ def test_config2_size_against_c_oracle(path, compose, dev, ref_cpu):
   want = ref_cpu.forward_splat(tex, None, disp, mat, 0.5, 1e-3, 0.4, 50,
                                compose)
   ldi_src = [torch.tensor(tex, device=dev), None, torch.tensor(disp, device=dev)]
-  img, wts, dsp = ldi.forward_splat_matrix(
-      ldi_src, torch.tensor(mat), compose_layers=compose, compute_trg_disp=True,
-      trg_downsampling=0.5, bg_layer_disp=1e-3, max_disp=0.4, zbuf_scale=50,
-      path=path)
+  out = ldi.forward_splat_matrix(
+      ldi_src, torch.tensor(mat), compose_layers=compose,
+      compute_trg_disp=(path != 'stream'), trg_downsampling=0.5,
+      bg_layer_disp=1e-3, max_disp=0.4, zbuf_scale=50, path=path)
+  img, wts = out[0], out[1]
   np.testing.assert_allclose(img.cpu().numpy(), want['img'], rtol=0,
                              atol=IMG_ATOL)
   np.testing.assert_allclose(wts.cpu().numpy(), want['wts'], rtol=WTS_RTOL)
-  np.testing.assert_allclose(dsp.cpu().numpy(), want['disp'], rtol=DSP_RTOL,
-                             atol=1e-7)
+  if path != 'stream':
+    np.testing.assert_allclose(out[2].cpu().numpy(), want['disp'],
+                               rtol=DSP_RTOL, atol=1e-7)
   mse = float(np.mean((img.cpu().numpy() - want['img'])**2))
   assert mse < 1e-12          # PSNR(build, oracle) > 120 dB
 
@@ -175,7 +186,7 @@ def test_general_pose_against_c_oracle(dev, ref_cpu):
     ldi.forward_splat_matrix(ldi_src, torch.tensor(mat), path='rowband')
 
 
-@pytest.mark.parametrize('path', ['atomic', 'rowband'])
+@pytest.mark.parametrize('path', ['atomic', 'rowband', 'stream'])
 def test_planar_nchw_inputs_need_no_copy(path, dev, ref_cpu):
   """A permuted NCHW conv output (planar RGB+disparity) renders identically."""
   from lsi.geometry import ldi
@@ -232,7 +243,7 @@ def test_nonfinite_disparity_is_dropped_not_propagated(dev):
   tex, disp, mat = _synth(rs, 1, 1, 16, 24)
   disp[0, 0, 3, 4, 0] = np.nan
   disp[0, 0, 5, 6, 0] = np.inf
-  for path in ('atomic', 'rowband'):
+  for path in ('atomic', 'rowband', 'stream'):
     img, wts = ldi.forward_splat_matrix(
         [torch.tensor(tex, device=dev), None, torch.tensor(disp, device=dev)],
         torch.tensor(mat), trg_downsampling=0.5, bg_layer_disp=1e-3,
@@ -240,7 +251,7 @@ def test_nonfinite_disparity_is_dropped_not_propagated(dev):
     assert bool(torch.isfinite(img).all()) and bool(torch.isfinite(wts).all())
 
 
-@pytest.mark.parametrize('path', ['atomic', 'rowband'])
+@pytest.mark.parametrize('path', ['atomic', 'rowband', 'stream'])
 def test_full_size_properties(path, dev):
   """BASELINE config 3's per-GPU shard (4-layer 256x768, batch 4, s=0.5):
   size-independent properties instead of a CPU oracle."""
@@ -277,7 +288,7 @@ def test_full_size_properties(path, dev):
   torch.testing.assert_close(wts2, wts, rtol=1e-5, atol=0)
   assert float((a2 - 0.5 * a1).abs().max()) <= 2e-5 * float(a1.abs().max())
   # (4) both kernel families agree with each other
-  other = 'rowband' if path == 'atomic' else 'atomic'
+  other = 'stream' if path == 'atomic' else 'atomic'
   img3, wts3 = ldi.forward_splat_matrix([tex, None, disp], mat,
                                         trg_downsampling=0.5,
                                         bg_layer_disp=1e-3, max_disp=0.4,
@@ -333,3 +344,77 @@ def test_backward_matches_autograd_of_the_op_graph(case, compose, dev):
     scale = np.abs(want).max() + 1e-30
     bad = np.abs(got - want) > 2e-4 * scale + 1e-3 * np.abs(want)
     assert bad.mean() < 0.005, (name, bad.mean(), np.abs(got - want).max() / scale)
+
+
+# ---------------------------------------------------------------------------
+# LSI_PATH_STREAM specifics: every internal route (monotone RMW, ranked RMW,
+# exact slow path, window overflow) against the C oracle.
+# ---------------------------------------------------------------------------
+def _stream_case(rs, nl, b, h, w, kind, max_disp=0.4):
+  tex, disp, mat = _synth(rs, nl, b, h, w)
+  if kind == 'smooth':          # monotone lanes: plain RMW
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    base = 0.2 + 0.1 * np.sin(xx / 37.0) * np.cos(yy / 23.0)
+    disp = np.broadcast_to(base[None, None, :, :, None],
+                           (nl, b, h, w, 1)).astype(np.float32).copy()
+  elif kind == 'iid':           # fold-overs everywhere: ranked RMW
+    pass
+  elif kind == 'outside':       # disparities beyond [0, max_disp]: slow path
+    disp = rs.uniform(-0.5, 3.0, disp.shape).astype(np.float32) * max_disp
+  elif kind == 'constant':      # long runs of identical cells at s = 0.5
+    disp[:] = 0.123
+  return tex, disp.astype(np.float32), mat
+
+
+@pytest.mark.parametrize('kind', ['smooth', 'iid', 'outside', 'constant'])
+@pytest.mark.parametrize('shape', [(2, 2, 64, 256, 0.5), (1, 1, 33, 260, 0.5),
+                                   (3, 1, 16, 40, 1), (2, 1, 40, 516, 0.5)])
+@pytest.mark.parametrize('compose', [True, False])
+def test_stream_path_routes(kind, shape, compose, dev, ref_cpu):
+  from lsi.geometry import ldi
+  nl, b, h, w, s = shape
+  if (h * s) != int(h * s):
+    h += 1
+  rs = np.random.RandomState(nl * 1000 + w)
+  tex, disp, mat = _stream_case(rs, nl, b, h, w, kind)
+  mask = (rs.rand(nl, b, h, w, 1) > 0.1).astype(np.float32) * \
+      rs.rand(nl, b, h, w, 1).astype(np.float32)
+  want = ref_cpu.forward_splat(tex, mask, disp, mat, s, 1e-3, 0.4, 50, compose)
+  ldi_src = [torch.tensor(x, device=dev) for x in (tex, mask, disp)]
+  for rows in (0, 1, 4):
+    img, wts = ldi.forward_splat_matrix(
+        ldi_src, torch.tensor(mat), compose_layers=compose, trg_downsampling=s,
+        bg_layer_disp=1e-3, max_disp=0.4, zbuf_scale=50, path='stream',
+        band_rows=rows)
+    np.testing.assert_allclose(img.cpu().numpy(), want['img'], rtol=0,
+                               atol=IMG_ATOL)
+    np.testing.assert_allclose(wts.cpu().numpy(), want['wts'], rtol=WTS_RTOL)
+
+
+def test_stream_path_is_run_to_run_deterministic(dev):
+  """No fp32 atomics on the hot path: bitwise identical results across runs."""
+  from lsi.geometry import ldi
+  rs = np.random.RandomState(21)
+  tex, disp, mat = _stream_case(rs, 2, 2, 128, 512, 'smooth')
+  ldi_src = [torch.tensor(tex, device=dev), None, torch.tensor(disp, device=dev)]
+  outs = [ldi.forward_splat_matrix(ldi_src, torch.tensor(mat),
+                                   trg_downsampling=0.5, bg_layer_disp=1e-3,
+                                   max_disp=0.4, zbuf_scale=50, path='stream')
+          for _ in range(3)]
+  for img, wts in outs[1:]:
+    assert torch.equal(img, outs[0][0]) and torch.equal(wts, outs[0][1])
+
+
+def test_stream_path_rejects_what_it_cannot_render(dev):
+  from lsi.geometry import ldi
+  rs = np.random.RandomState(22)
+  tex, disp, mat = _synth(rs, 1, 1, 16, 32)
+  ldi_src = [torch.tensor(tex, device=dev), None, torch.tensor(disp, device=dev)]
+  with pytest.raises(RuntimeError, match='precondition'):
+    ldi.forward_splat_matrix(ldi_src, torch.tensor(mat), compute_trg_disp=True,
+                             path='stream')
+  tex2, disp2, mat2 = _synth(rs, 1, 1, 16, 30)   # W % 4 != 0
+  with pytest.raises(RuntimeError, match='precondition'):
+    ldi.forward_splat_matrix(
+        [torch.tensor(tex2, device=dev), None, torch.tensor(disp2, device=dev)],
+        torch.tensor(mat2), path='stream')
