@@ -170,6 +170,7 @@ def main():
   ap.add_argument('--band-rows', type=int, default=0)
   ap.add_argument('--threads', type=int, default=0)
   ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--debug-flags', type=int, default=0)
   args = ap.parse_args()
 
   world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -196,6 +197,7 @@ def main():
                                dev)
   r = Renderer(tex, disp, mat, max_disp, bg, args.path, args.band_rows,
                args.threads)
+  r.desc.reserved = args.debug_flags
 
   stream = torch.cuda.Stream(device=dev)
   launch_mode = args.launch

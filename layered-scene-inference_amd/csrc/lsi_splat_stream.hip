@@ -15,8 +15,8 @@
 // routing the rare affected corners through an exact slow path.
 //
 // Structure.  Workgroup = (band of R target rows, batch element b), NW waves.
-//   task  = (source row y, layer l, 256-pixel segment j); every step each wave
-//           runs one task:
+//   task  = (source row y, 256-pixel segment j), all layers of the pass; every
+//           step each wave runs one task:
 //     x-pass  lanes load 4 consecutive pixels (dwordx4), project them, and add
 //             V*wx0 / V*wx1 (V = (r,g,b,1)*pixel weight) into the wave's
 //             PRIVATE window of float4 cells in LDS by plain RMW.  Lanes are 4
@@ -50,8 +50,11 @@ using namespace lsi;
 namespace {
 
 constexpr int SEG = 256;   // source pixels per task (64 lanes x 4)
-constexpr int MAXU = 4;    // target-cell units (64 cells) owned per wave
+constexpr int MAXU = 2;    // target-cell units (64 cells) owned per wave
 constexpr int MAXNW = 16;
+// lsi_stream_ok's return value: window cells, plus this bit when every batch
+// element has normaliser == 1 and M row 3 == (0,0,0,1) (division-free kernel)
+constexpr int LSI_STREAM_SIMPLE_BIT = 1 << 20;
 
 struct TaskInfo {
   int row0;        // target row of the task's top contribution, band-relative
@@ -66,12 +69,16 @@ struct StreamCfg {
 
 #define LSI_COMPILER_FENCE() asm volatile("" ::: "memory")
 
-__device__ __forceinline__ float4 f4_madd(float4 t, float4 v, float w) {
-  t.x += v.x * w; t.y += v.y * w; t.z += v.z * w; t.w += v.w * w;
+// accumulations are not index-critical: fused multiply-add
+__device__ __forceinline__ float4 f4_fma(float4 t, float4 v, float w) {
+  t.x = __fmaf_rn(v.x, w, t.x); t.y = __fmaf_rn(v.y, w, t.y);
+  t.z = __fmaf_rn(v.z, w, t.z); t.w = __fmaf_rn(v.w, w, t.w);
   return t;
 }
 
-template <int LAYOUT>  // 0: channels-last RGB (x stride 3), 1: planar
+// SIMPLE: the normaliser is exactly 1 and row 3 of M is (0,0,0,1) for every
+// batch element (rectified stereo): u = q0 and D = d with no division.
+template <int LAYOUT, bool SIMPLE>  // LAYOUT 0: channels-last RGB, 1: planar
 __global__ __launch_bounds__(1024) void splat_stream_kernel(SplatArgs a,
                                                             StreamCfg cfg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -94,12 +101,32 @@ __global__ __launch_bounds__(1024) void splat_stream_kernel(SplatArgs a,
   float4* rb = rb_all + wave * WMAX;
   unsigned* cnt = cnt_all + wave * WMAX;
 
-  const float* __restrict__ m = a.M + 16 * b;
+  // Everything read from global / kernarg memory inside the loops is copied to
+  // registers first: the LDS ordering fences below are compiler memory
+  // barriers and would otherwise force re-loads in the hot loop.
+  float m[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) m[k] = a.M[16 * b + k];
   const float s = d.trg_downsampling;
+  const float max_disp = d.max_disp, zscale = d.zbuf_scale;
+  const long tex_sl = d.tex_sl, tex_sb = d.tex_sb, tex_sy = d.tex_sy,
+             tex_sc = d.tex_sc;
+  const long disp_sl = d.disp_sl, disp_sb = d.disp_sb, disp_sy = d.disp_sy;
+  const long mask_sl = d.mask_sl, mask_sb = d.mask_sb, mask_sy = d.mask_sy;
+  const float* __restrict__ g_tex = a.tex;
+  const float* __restrict__ g_disp = a.disp;
+  const float* __restrict__ g_mask = a.mask;
+  const int dbg = d.reserved;
+  const int nlayers = d.L;
   const float xmax = (float)Wt - 1.0f, ymax = (float)Ht - 1.0f;
   const bool has_mask = d.flags & LSI_HAS_MASK;
   const bool compose = d.flags & LSI_COMPOSE;
 
+  long long* tdbg = (a.d.reserved & 4) ? reinterpret_cast<long long*>(a.canvas) +
+                        ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 32 : nullptr;
+  int tslot = 0;
+#define LSI_TSTAMP() do { if (tdbg && tid == 0 && tslot < 32) tdbg[tslot++] = (long long)__builtin_readcyclecounter(); } while (0)
+  LSI_TSTAMP();
   // ---- one-time init ------------------------------------------------------
   for (int i = tid; i < NW * WMAX; i += T) {
     rb_all[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -124,52 +151,54 @@ __global__ __launch_bounds__(1024) void splat_stream_kernel(SplatArgs a,
     if (hi >= 0) { atomicMin(&yrange[0], lo); atomicMax(&yrange[1], hi); }
   }
   __syncthreads();
+  LSI_TSTAMP();
   const int y_lo = yrange[0], y_hi = yrange[1];
   const int nsrc = (y_hi >= y_lo) ? (y_hi - y_lo + 1) : 0;
   const int nseg = (W + SEG - 1) / SEG;
   const float bg = d.bg_wt;
   const size_t P = (size_t)Ht * Wt;
 
-  const int npass = compose ? 1 : d.L;
-  const int Lp = compose ? d.L : 1;
+  const int npass = compose ? 1 : nlayers;
+  const int Lp = compose ? nlayers : 1;
   for (int pass = 0; pass < npass; ++pass) {
     float4 acc[MAXU];
 #pragma unroll
     for (int u = 0; u < MAXU; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
     const int l_begin = compose ? 0 : pass;
-    const int ntask = nsrc * Lp * nseg;
+    const int ntask = nsrc * nseg;
     const int nstep = (ntask + NW - 1) / NW;
 
     for (int step = 0; step < nstep; ++step) {
       // ================= x-pass: one task per wave ========================
+      // task = (source row y, 256-pixel segment j), all layers of the pass
       const int tg = step * NW + wave;
       TaskInfo ti;
       ti.row0 = -1000000; ti.wy0 = 0.f; ti.wy1 = 0.f; ti.wlo = 0; ti.wwin = 0;
-      int l = 0, y = 0, xs = 0;
+      int y = 0, xs = 0;
       float nden = 1.0f;
       bool tvalid = tg < ntask;
       if (tvalid) {
         const int j = tg % nseg;
-        const int tmp = tg / nseg;
-        l = l_begin + tmp % Lp;
-        y = y_lo + tmp / Lp;
+        y = y_lo + tg / nseg;
         xs = j * SEG;
         const float py = (float)y + 0.5f;
         const float q1 = mrow(m, 1, 0.5f, py, 0.0f);
         nden = safe_den(mrow(m, 2, 0.5f, py, 0.0f));
         const float Y = div_rn(q1, nden) * s - 0.5f;
+        tvalid = false;
         if (finite_f(Y) && fabsf(Y) < 1.0e7f) {
           const Axis ay = splat_axis(Y, ymax);
           ti.row0 = (int)floorf(Y) - row0;
           ti.wy0 = ay.w0;
           ti.wy1 = ay.w1;
+          tvalid = (ay.w0 != 0.0f) || (ay.w1 != 0.0f);
           // window hint: cells reachable for d in [0, max_disp] over the segment
           const int xe = min(xs + SEG, W);
           float lo = __builtin_inff(), hi = -__builtin_inff();
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
             const float px = (float)((c & 1) ? (xe - 1) : xs) + 0.5f;
-            const float dd = (c & 2) ? d.max_disp : 0.0f;
+            const float dd = (c & 2) ? max_disp : 0.0f;
             const float X = div_rn(mrow(m, 0, px, py, dd), nden) * s - 0.5f;
             lo = fminf(lo, X); hi = fmaxf(hi, X);
           }
@@ -178,8 +207,6 @@ __global__ __launch_bounds__(1024) void splat_stream_kernel(SplatArgs a,
             ti.wlo = (int)floorf(lo) - 1;
             ti.wwin = min(WMAX, (int)floorf(hi) + 3 - ti.wlo);
           }
-        } else {
-          tvalid = false;
         }
       }
       if (lane == 0) tinfo[wave] = ti;
@@ -188,142 +215,189 @@ __global__ __launch_bounds__(1024) void splat_stream_kernel(SplatArgs a,
       if (tvalid) {
         const int x = xs + 4 * lane;
         const bool inrange = x < W;
-        float dv[4] = {0.f, 0.f, 0.f, 0.f}, mk[4] = {1.f, 1.f, 1.f, 1.f};
-        float cr[4], cg[4], cb[4];
-        if (inrange) {
-          const float4 d4 = *reinterpret_cast<const float4*>(
-              a.disp + l * d.disp_sl + b * d.disp_sb + y * d.disp_sy + x);
-          dv[0] = d4.x; dv[1] = d4.y; dv[2] = d4.z; dv[3] = d4.w;
-          const float* tp = a.tex + l * d.tex_sl + b * d.tex_sb + y * d.tex_sy;
-          if (LAYOUT == 0) {
-            const float4* t4 = reinterpret_cast<const float4*>(tp + 3 * x);
-            const float4 t0 = t4[0], t1 = t4[1], t2 = t4[2];
-            cr[0] = t0.x; cg[0] = t0.y; cb[0] = t0.z;
-            cr[1] = t0.w; cg[1] = t1.x; cb[1] = t1.y;
-            cr[2] = t1.z; cg[2] = t1.w; cb[2] = t2.x;
-            cr[3] = t2.y; cg[3] = t2.z; cb[3] = t2.w;
-          } else {
-            const float4 r4 = *reinterpret_cast<const float4*>(tp + x);
-            const float4 g4 =
-                *reinterpret_cast<const float4*>(tp + d.tex_sc + x);
-            const float4 b4 =
-                *reinterpret_cast<const float4*>(tp + 2 * d.tex_sc + x);
-            cr[0] = r4.x; cr[1] = r4.y; cr[2] = r4.z; cr[3] = r4.w;
-            cg[0] = g4.x; cg[1] = g4.y; cg[2] = g4.z; cg[3] = g4.w;
-            cb[0] = b4.x; cb[1] = b4.y; cb[2] = b4.z; cb[3] = b4.w;
-          }
-          if (has_mask) {
-            const float4 m4 = *reinterpret_cast<const float4*>(
-                a.mask + l * d.mask_sl + b * d.mask_sb + y * d.mask_sy + x);
-            mk[0] = m4.x; mk[1] = m4.y; mk[2] = m4.z; mk[3] = m4.w;
-          }
-        } else {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) { cr[i] = cg[i] = cb[i] = 0.f; }
-        }
         const float py = (float)y + 0.5f;
+        // row-uniform pieces of q = M p, in the contract's rounding order
+        const float pym01 = py * m[1];
+        const float pym31 = py * m[13];
+        const float rn = SIMPLE ? 1.0f : div_rn(1.0f, nden);
+        const float inv_md = div_rn(1.0f, max_disp);
         const float wy0 = ti.wy0, wy1 = ti.wy1;
+        // smallest non-zero row weight: a side is exactly factorisable iff its
+        // product with this one survives the 1e-3 clamp (rounding is monotone)
+        const float wymin = (wy0 == 0.f) ? wy1 : ((wy1 == 0.f) ? wy0
+                                                               : fminf(wy0, wy1));
         const float wlo_f = (float)ti.wlo;
         const float whi_f = (float)(ti.wlo + ti.wwin - 2);  // last left cell
 
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float px = (float)(x + i) + 0.5f;
-          const float q0 = mrow(m, 0, px, py, dv[i]);
-          const float q3 = mrow(m, 3, px, py, dv[i]);
-          const float X = div_rn(q0, nden) * s - 0.5f;
-          // a non-finite disparity poisons q1/n in the reference too: dropped
-          const bool ok = inrange && finite_f(X) && finite_f(dv[i]);
-          const float dd = div_rn(q3, nden);
-          const float pw = zbuffer_weight(div_rn(dd, d.max_disp), d.zbuf_scale) *
-                           mk[i];
-          const Axis ax = splat_axis(X, xmax);
-          const float x0raw = floorf(X);
-          const bool active = ok && (pw != 0.0f);
-          // exact corner weights of the reference
-          const float p00 = ax.w0 * wy0, p10 = ax.w1 * wy0;
-          const float p01 = ax.w0 * wy1, p11 = ax.w1 * wy1;
-          // the factorised form is exact iff no non-zero product is clamped
-          const bool sep_ok = (p00 > 1e-3f || p00 == 0.f) &&
-                              (p10 > 1e-3f || p10 == 0.f) &&
-                              (p01 > 1e-3f || p01 == 0.f) &&
-                              (p11 > 1e-3f || p11 == 0.f);
-          const bool inwin = (x0raw >= wlo_f) && (x0raw <= whi_f);
-          const bool fast = active && sep_ok && inwin;
-          const bool slow = active && !fast;
-          const float4 V = make_float4(cr[i] * pw, cg[i] * pw, cb[i] * pw, pw);
+        struct PxData { float4 d4, t0, t1, t2, m4; };
+        auto load_layer = [&](int l, PxData& o) {
+          if (!inrange) return;
+          o.d4 = *reinterpret_cast<const float4*>(
+              g_disp + l * disp_sl + b * disp_sb + y * disp_sy + x);
+          const float* tp = g_tex + l * tex_sl + b * tex_sb + y * tex_sy;
+          if (LAYOUT == 0) {
+            const float4* t4 = reinterpret_cast<const float4*>(tp + 3 * x);
+            o.t0 = t4[0]; o.t1 = t4[1]; o.t2 = t4[2];
+          } else {
+            o.t0 = *reinterpret_cast<const float4*>(tp + x);
+            o.t1 = *reinterpret_cast<const float4*>(tp + tex_sc + x);
+            o.t2 = *reinterpret_cast<const float4*>(tp + 2 * tex_sc + x);
+          }
+          if (has_mask)
+            o.m4 = *reinterpret_cast<const float4*>(
+                g_mask + l * mask_sl + b * mask_sb + y * mask_sy + x);
+        };
 
-          if (slow) {  // exact, rare: fp32 LDS atomics into the extras tile
-            const float wc[4] = {clamp_small(p00), clamp_small(p10),
-                                 clamp_small(p01), clamp_small(p11)};
-            const int cx[2] = {(int)ax.c0s, (int)ax.c1s};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              const int r = ti.row0 + (k >> 1);
-              if (wc[k] == 0.0f || r < 0 || r >= rows) continue;
-              float* e = extras + ((size_t)r * Wt + cx[k & 1]) * 4;
-              atomic_add_f32(e + 0, V.x * wc[k]);
-              atomic_add_f32(e + 1, V.y * wc[k]);
-              atomic_add_f32(e + 2, V.z * wc[k]);
-              atomic_add_f32(e + 3, V.w * wc[k]);
-            }
+        PxData nxt;
+        nxt.d4 = nxt.t0 = nxt.t1 = nxt.t2 = make_float4(0.f, 0.f, 0.f, 0.f);
+        nxt.m4 = make_float4(1.f, 1.f, 1.f, 1.f);
+        load_layer(l_begin, nxt);
+        for (int l = l_begin; l < l_begin + Lp; ++l) {
+          const PxData cur = nxt;
+          if (l + 1 < l_begin + Lp) load_layer(l + 1, nxt);
+          const float dv[4] = {cur.d4.x, cur.d4.y, cur.d4.z, cur.d4.w};
+          const float mk[4] = {cur.m4.x, cur.m4.y, cur.m4.z, cur.m4.w};
+          float cr[4], cg[4], cb[4];
+          if (LAYOUT == 0) {
+            cr[0] = cur.t0.x; cg[0] = cur.t0.y; cb[0] = cur.t0.z;
+            cr[1] = cur.t0.w; cg[1] = cur.t1.x; cb[1] = cur.t1.y;
+            cr[2] = cur.t1.z; cg[2] = cur.t1.w; cb[2] = cur.t2.x;
+            cr[3] = cur.t2.y; cg[3] = cur.t2.z; cb[3] = cur.t2.w;
+          } else {
+            cr[0] = cur.t0.x; cr[1] = cur.t0.y; cr[2] = cur.t0.z; cr[3] = cur.t0.w;
+            cg[0] = cur.t1.x; cg[1] = cur.t1.y; cg[2] = cur.t1.z; cg[3] = cur.t1.w;
+            cb[0] = cur.t2.x; cb[1] = cur.t2.y; cb[2] = cur.t2.z; cb[3] = cur.t2.w;
           }
 
-          // ---- conflict-free plain RMW into the private window ------------
-          const int cl = fast ? ((int)x0raw - ti.wlo) : 0;
-          const float prev = __shfl_up(x0raw, 1);
-          const bool mono_lane = (lane == 0) || !inrange || (x0raw > prev);
-          const bool mono = __ballot(mono_lane) == ~0ull;
-          if (mono) {
-            if (fast) rb[cl] = f4_madd(rb[cl], V, ax.w0);
-            LSI_COMPILER_FENCE();
-            if (fast) rb[cl + 1] = f4_madd(rb[cl + 1], V, ax.w1);
-            LSI_COMPILER_FENCE();
-          } else if (__ballot(fast) != 0ull) {
-            unsigned rank = 0u;
-            if (fast) rank = atomicAdd(&cnt[cl], 1u);
-            for (unsigned r = 0;; ++r) {
-              if (__ballot(fast && rank >= r) == 0ull) break;
-              const bool mine = fast && rank == r;
-              if (mine) rb[cl] = f4_madd(rb[cl], V, ax.w0);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float px = (float)(x + i) + 0.5f;
+            // q0 = ((px*m00 + py*m01) + m02) + d*m03, each op rounded
+            float q0 = px * m[0] + pym01;
+            q0 = q0 + m[2];
+            q0 = q0 + dv[i] * m[3];
+            float q3, u;
+            if (SIMPLE) {
+              q3 = dv[i];
+              u = q0;  // index-critical u = q0 / n' with n' == 1 exactly
+            } else {
+              q3 = px * m[12] + pym31;
+              q3 = q3 + m[14];
+              q3 = q3 + dv[i] * m[15];
+              u = div_rn(q0, nden);  // index-critical: IEEE division
+            }
+            const float X = u * s - 0.5f;
+            // non-finite disparity => non-finite X (q0 = .. + d*m03; NaN*0 and
+            // Inf*0 are NaN): the point is dropped, as in the oracle
+            const bool ok = inrange && (fabsf(X) < 1.0e30f);
+            // weights are not index-critical: reciprocal multiplies (<= 2 ulp)
+            const float dd = SIMPLE ? q3 : q3 * rn;
+            const float pw = zbuffer_weight(dd * inv_md, zscale) * mk[i];
+            const Axis ax = splat_axis(X, xmax);
+            const float x0raw = floorf(X);
+            const bool active = ok && (pw != 0.0f);
+            const bool sep_ok =
+                (ax.w0 == 0.f || ax.w0 * wymin > 1e-3f) &&
+                (ax.w1 == 0.f || ax.w1 * wymin > 1e-3f);
+            const bool inwin = (x0raw >= wlo_f) && (x0raw <= whi_f);
+            const bool fast = active && sep_ok && inwin;
+            const bool slow = active && !fast;
+            const float4 V =
+                make_float4(cr[i] * pw, cg[i] * pw, cb[i] * pw, pw);
+
+            if (slow && !(dbg & 1)) {
+              // exact, rare: fp32 LDS atomics into the extras tile
+              const float wc[4] = {
+                  clamp_small(ax.w0 * wy0), clamp_small(ax.w1 * wy0),
+                  clamp_small(ax.w0 * wy1), clamp_small(ax.w1 * wy1)};
+              const int cx[2] = {(int)ax.c0s, (int)ax.c1s};
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                const int r = ti.row0 + (k >> 1);
+                if (wc[k] == 0.0f || r < 0 || r >= rows) continue;
+                float* e = extras + ((size_t)r * Wt + cx[k & 1]) * 4;
+                atomic_add_f32(e + 0, V.x * wc[k]);
+                atomic_add_f32(e + 1, V.y * wc[k]);
+                atomic_add_f32(e + 2, V.z * wc[k]);
+                atomic_add_f32(e + 3, V.w * wc[k]);
+              }
+            }
+
+            // ---- conflict-free plain RMW into the private window ----------
+            const int cl = fast ? ((int)x0raw - ti.wlo) : 0;
+            const float prev = __shfl_up(x0raw, 1);
+            const bool mono_lane = (lane == 0) || !inrange || (x0raw > prev);
+            const bool mono =
+                (__ballot(mono_lane) == ~0ull) || (dbg & 2);
+            if (mono) {
+              if (fast) rb[cl] = f4_fma(rb[cl], V, ax.w0);
               LSI_COMPILER_FENCE();
-              if (mine) rb[cl + 1] = f4_madd(rb[cl + 1], V, ax.w1);
+              if (fast) rb[cl + 1] = f4_fma(rb[cl + 1], V, ax.w1);
+              LSI_COMPILER_FENCE();
+            } else if (__ballot(fast) != 0ull) {
+              unsigned rank = 0u;
+              if (fast) rank = atomicAdd(&cnt[cl], 1u);
+              for (unsigned r = 0;; ++r) {
+                if (__ballot(fast && rank >= r) == 0ull) break;
+                const bool mine = fast && rank == r;
+                if (mine) rb[cl] = f4_fma(rb[cl], V, ax.w0);
+                LSI_COMPILER_FENCE();
+                if (mine) rb[cl + 1] = f4_fma(rb[cl + 1], V, ax.w1);
+                LSI_COMPILER_FENCE();
+              }
+              if (fast) cnt[cl] = 0u;
               LSI_COMPILER_FENCE();
             }
-            if (fast) cnt[cl] = 0u;
-            LSI_COMPILER_FENCE();
           }
         }
       }
+      LSI_TSTAMP();
       __syncthreads();
+      LSI_TSTAMP();
 
       // ================= merge: cell owners gather the windows =============
-#pragma unroll
-      for (int u = 0; u < MAXU; ++u) {
-        const int unit = wave + u * NW;
-        if (unit >= nunits) continue;
-        const int r = unit / NB;
-        const int cell = (unit - r * NB) * 64 + lane;
+      {
+        // lane t holds task t's table entry; entries are broadcast per task
+        // with readlane (no LDS round trip per iteration)
+        TaskInfo mine;
+        mine.row0 = -1000000; mine.wy0 = 0.f; mine.wy1 = 0.f;
+        mine.wlo = 0; mine.wwin = 0;
+        if (lane < NW) mine = tinfo[lane];
         for (int t = 0; t < NW; ++t) {
-          const TaskInfo q = tinfo[t];
-          float wy;
-          if (q.row0 == r) wy = q.wy0;
-          else if (q.row0 + 1 == r) wy = q.wy1;
-          else continue;
-          if (wy == 0.0f) continue;
-          const int rel = cell - q.wlo;
-          if (rel >= 0 && rel < q.wwin && cell < Wt)
-            acc[u] = f4_madd(acc[u], rb_all[t * WMAX + rel], wy);
+          const int q_row0 = __builtin_amdgcn_readlane(mine.row0, t);
+          const int q_wlo = __builtin_amdgcn_readlane(mine.wlo, t);
+          const int q_wwin = __builtin_amdgcn_readlane(mine.wwin, t);
+          const float q_wy0 = __int_as_float(
+              __builtin_amdgcn_readlane(__float_as_int(mine.wy0), t));
+          const float q_wy1 = __int_as_float(
+              __builtin_amdgcn_readlane(__float_as_int(mine.wy1), t));
+#pragma unroll
+          for (int u = 0; u < MAXU; ++u) {
+            const int unit = wave + u * NW;
+            if (unit >= nunits) continue;
+            const int r = unit / NB;
+            float wy;
+            if (q_row0 == r) wy = q_wy0;
+            else if (q_row0 + 1 == r) wy = q_wy1;
+            else continue;
+            if (wy == 0.0f) continue;
+            const int cell = (unit - r * NB) * 64 + lane;
+            const int rel = cell - q_wlo;
+            if (rel >= 0 && rel < q_wwin && cell < Wt)
+              acc[u] = f4_fma(acc[u], rb_all[t * WMAX + rel], wy);
+          }
         }
       }
+      LSI_TSTAMP();
       __syncthreads();
+      LSI_TSTAMP();
       // re-zero this wave's window for its next task
       for (int c = lane; c < ti.wwin; c += 64)
         rb[c] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 
     // ================= epilogue for this pass ===============================
-    const float lbg = compose ? (float)d.L * bg : bg;
+    const float lbg = compose ? (float)nlayers * bg : bg;
     const int lo_ = compose ? 0 : pass;
 #pragma unroll
     for (int u = 0; u < MAXU; ++u) {
@@ -344,6 +418,7 @@ __global__ __launch_bounds__(1024) void splat_stream_kernel(SplatArgs a,
       a.out_wts[o] = Wsum;
       if (pass + 1 < npass) { e[0] = 0.f; e[1] = 0.f; e[2] = 0.f; e[3] = 0.f; }
     }
+    LSI_TSTAMP();
     __syncthreads();
   }
 }
@@ -380,9 +455,13 @@ extern "C" int lsi_stream_ok(const LsiSplatDesc* d, const float* M) {
     return 0;
   const float s = d->trg_downsampling;
   float need = 0.0f;
+  bool simple = true;
   for (int b = 0; b < d->B; ++b) {
     const float* m = M + 16 * b;
     if (m[4] != 0.0f || m[8] != 0.0f) return 0;  // M[1][0], M[2][0]
+    if (!(m[9] == 0.0f && m[10] == 1.0f && m[12] == 0.0f && m[13] == 0.0f &&
+          m[14] == 0.0f && m[15] == 1.0f))
+      simple = false;
     // normaliser over the rows (independent of x here)
     const float n0 = m[9] * 0.5f + m[10];
     const float n1 = m[9] * ((float)d->H - 0.5f) + m[10];
@@ -396,7 +475,7 @@ extern "C" int lsi_stream_ok(const LsiSplatDesc* d, const float* M) {
   win = (win + 63) / 64 * 64;
   if (win < 64) win = 64;
   if (win > 512) win = 512;  // beyond this the excess takes the exact slow path
-  return win;
+  return win | (simple ? LSI_STREAM_SIMPLE_BIT : 0);
 }
 
 int lsi_stream_launch(const SplatArgs& a, hipStream_t stream) {
@@ -407,14 +486,12 @@ int lsi_stream_launch(const SplatArgs& a, hipStream_t stream) {
   if (!aligned16(a.tex) || !aligned16(a.disp) ||
       ((d->flags & LSI_HAS_MASK) && !aligned16(a.mask)))
     return LSI_EINVAL;
-  if (d->tune_window <= 0) return LSI_EINVAL;  // from lsi_stream_ok
-  int threads = d->tune_threads > 0 ? d->tune_threads : 768;
-  threads = (threads + 63) / 64 * 64;
-  if (threads > 1024) threads = 1024;
-  const int nw = threads / 64;
+  if ((d->tune_window & ~LSI_STREAM_SIMPLE_BIT) <= 0)
+    return LSI_EINVAL;  // from lsi_stream_ok
   const int NB = (d->Wt + 63) / 64;
+  const int nseg = (d->W + SEG - 1) / SEG;
   StreamCfg cfg;
-  cfg.wmax = d->tune_window;
+  cfg.wmax = d->tune_window & ~LSI_STREAM_SIMPLE_BIT;
   int R = d->tune_rows;
   if (R <= 0) {  // tallest band that still gives >= 256 workgroups
     R = 1;
@@ -423,28 +500,47 @@ int lsi_stream_launch(const SplatArgs& a, hipStream_t stream) {
       R = c;
     }
   }
-  while (R > 1 && (R * NB > MAXU * nw ||
-                   stream_lds_bytes(d, R, nw, cfg.wmax) > 150 * 1024))
+  int nw = 0;
+  for (;;) {
+    // source rows per band ~ (R + 1) / s; one task per (row, segment)
+    const int ntask =
+        (int)ceilf((float)(R + 1) / d->trg_downsampling) * nseg;
+    if (d->tune_threads > 0) {
+      nw = (d->tune_threads + 63) / 64;
+      if (nw > MAXNW) nw = MAXNW;
+    } else {  // waves per workgroup: least idle slots in the last step
+      int best_waste = 1 << 30;
+      for (int c = MAXNW; c >= 6; --c) {
+        if (R * NB > MAXU * c) continue;
+        const int waste = (ntask + c - 1) / c * c - ntask;
+        if (waste < best_waste) { best_waste = waste; nw = c; }
+      }
+    }
+    if (nw > 0 && R * NB <= MAXU * nw &&
+        stream_lds_bytes(d, R, nw, cfg.wmax) <= 150 * 1024)
+      break;
+    if (R == 1) return LSI_EINVAL;
     R /= 2;
-  if (R * NB > MAXU * nw) return LSI_EINVAL;
+    nw = 0;
+  }
+  const int threads = nw * 64;
   const size_t lds = stream_lds_bytes(d, R, nw, cfg.wmax);
   if (lds > 160 * 1024) return LSI_EINVAL;
   cfg.R = R;
   dim3 grid((d->Ht + R - 1) / R, d->B);
-  if (layout == 0) {
-    if (hipFuncSetAttribute((const void*)splat_stream_kernel<0>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds) != hipSuccess)
-      return LSI_ELAUNCH;
-    hipLaunchKernelGGL(splat_stream_kernel<0>, grid, dim3(threads), lds, stream,
-                       a, cfg);
-  } else {
-    if (hipFuncSetAttribute((const void*)splat_stream_kernel<1>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds) != hipSuccess)
-      return LSI_ELAUNCH;
-    hipLaunchKernelGGL(splat_stream_kernel<1>, grid, dim3(threads), lds, stream,
-                       a, cfg);
-  }
+  const bool simple = (d->tune_window & LSI_STREAM_SIMPLE_BIT) != 0;
+  const void* fn;
+  if (layout == 0)
+    fn = simple ? (const void*)splat_stream_kernel<0, true>
+                : (const void*)splat_stream_kernel<0, false>;
+  else
+    fn = simple ? (const void*)splat_stream_kernel<1, true>
+                : (const void*)splat_stream_kernel<1, false>;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)lds) != hipSuccess)
+    return LSI_ELAUNCH;
+  void* kargs[2] = {const_cast<SplatArgs*>(&a), &cfg};
+  if (hipLaunchKernel(fn, grid, dim3(threads), kargs, lds, stream) != hipSuccess)
+    return LSI_ELAUNCH;
   return hipGetLastError() == hipSuccess ? LSI_OK : LSI_ELAUNCH;
 }
