@@ -58,18 +58,35 @@ def box_blur(x, radius):
   return torch.nn.functional.avg_pool2d(pad, k, stride=1)
 
 
-def make_inputs(nl, b, h, w, cams, max_disp, seed, dev):
-  """Seeded synthetic LDI + cameras."""
+def make_inputs(nl, b, h, w, cams, max_disp, seed, dev, disp_kind='smooth'):
+  """Seeded synthetic LDI + cameras.
+
+  disp_kind:
+    'smooth'  the survey's definition: max_disp * sigmoid(field) * (L-l)/L with
+              field = box-blur(radius 8) of U[0,1) noise -- neighbouring pixels
+              move coherently, layers are ordered front to back;
+    'rough'   the same field contrast-stretched to the sigmoid's full range
+              (target x-coordinate folds over itself every few pixels);
+    'stress'  i.i.d. U[0.01, 1] * max_disp (worst-case scatter locality).
+  """
   gen = torch.Generator(device='cpu').manual_seed(seed)
   tex = torch.rand((nl, b, h, w, 3), generator=gen).to(dev)
   noise = torch.rand((nl * b, 1, h, w), generator=gen).to(dev)
-  field = box_blur(noise, 8)
-  field = (field - field.amin(dim=(2, 3), keepdim=True)) / (
-      field.amax(dim=(2, 3), keepdim=True) - field.amin(dim=(2, 3), keepdim=True)
-      + 1e-12)
-  field = torch.sigmoid(4.0 * (field - 0.5)).reshape(nl, b, h, w, 1)
+  if disp_kind == 'stress':
+    field = (0.01 + 0.99 * noise).reshape(nl, b, h, w, 1)
+  else:
+    field = box_blur(noise, 8)
+    if disp_kind == 'rough':
+      lo = field.amin(dim=(2, 3), keepdim=True)
+      hi = field.amax(dim=(2, 3), keepdim=True)
+      field = torch.sigmoid(4.0 * ((field - lo) / (hi - lo + 1e-12) - 0.5))
+    else:
+      field = torch.sigmoid(field)
+    field = field.reshape(nl, b, h, w, 1)
   scale = torch.tensor([(nl - l) / nl for l in range(nl)],
                        device=dev).view(nl, 1, 1, 1, 1)
+  if disp_kind == 'stress':
+    scale = torch.ones_like(scale)
   if cams == 'kitti':
     disp = (max_disp * field * scale).contiguous()
     k = torch.tensor([[0.58 * w, 0, w / 2.0], [0, 0.58 * w, h / 2.0],
@@ -132,6 +149,26 @@ class Renderer(object):
       _C.check(rc, 'lsi_splat_fwd')
 
 
+def shard_batch(workload, world):
+  """Per-rank batch and scaling mode: independent LDIs shard along B with no
+  data-path collective."""
+  nl, h, w, batch, per_gpu, cams, max_disp, bg = WORKLOADS[workload]
+  if per_gpu:
+    return batch, 'weak'
+  if batch % world:
+    raise SystemExit('batch %d does not split over %d ranks' % (batch, world))
+  return batch // world, 'strong'
+
+
+def reduce_max(values, dist, device):
+  """MAX over ranks of a list of floats (timings); identity without dist."""
+  if dist is None:
+    return [float(v) for v in values]
+  t = torch.tensor(values, device=device, dtype=torch.float64)
+  dist.all_reduce(t, op=dist.ReduceOp.MAX)
+  return [float(v) for v in t]
+
+
 def cpu_baseline(nl, b, h, w, cams, max_disp, bg, budget_s=15.0):
   """The plain-C oracle port timed on this host's cores, on a bounded sample of
   the same workload (same shapes/cameras; batch capped at 2)."""
@@ -171,6 +208,8 @@ def main():
   ap.add_argument('--threads', type=int, default=0)
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--debug-flags', type=int, default=0)
+  ap.add_argument('--disp', default='smooth',
+                  choices=['smooth', 'rough', 'stress'])
   args = ap.parse_args()
 
   world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -187,14 +226,9 @@ def main():
   dev = torch.device('cuda', local_rank)
 
   nl, h, w, batch, per_gpu, cams, max_disp, bg = WORKLOADS[args.workload]
-  if per_gpu:
-    b_local, scaling = batch, 'weak'
-  else:
-    if batch % world:
-      raise SystemExit('batch %d does not split over %d ranks' % (batch, world))
-    b_local, scaling = batch // world, 'strong'
+  b_local, scaling = shard_batch(args.workload, world)
   tex, disp, mat = make_inputs(nl, b_local, h, w, cams, max_disp, 1000 + rank,
-                               dev)
+                               dev, args.disp)
   r = Renderer(tex, disp, mat, max_disp, bg, args.path, args.band_rows,
                args.threads)
   r.desc.reserved = args.debug_flags
@@ -237,10 +271,7 @@ def main():
     elapsed = time.perf_counter() - t0
     ev_ms = ev0.elapsed_time(ev1)
 
-  if dist is not None:
-    tmax = torch.tensor([elapsed, ev_ms], device=dev, dtype=torch.float64)
-    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    elapsed, ev_ms = float(tmax[0]), float(tmax[1])
+  elapsed, ev_ms = reduce_max([elapsed, ev_ms], dist, dev)
 
   if rank == 0:
     views = b_local * world * args.steps
@@ -261,9 +292,10 @@ def main():
         'data': 'synthetic',
         'config': {
             'workload': '%s: %d-layer LDI %dx%d, batch %d per GPU (%d total), '
-                        'trg_downsampling 0.5, %s cameras, compose_layers' %
+                        'trg_downsampling 0.5, %s cameras, compose_layers, '
+                        '%s disparities' %
                         (args.workload, nl, h, w, b_local, b_local * world,
-                         cams),
+                         cams, args.disp),
             'kernel_path': r.path_name, 'launch': launch_mode,
             'parallelism': 'batch-sharded replicas x%d (no collective)' % world,
         },

@@ -51,7 +51,7 @@ namespace {
 
 constexpr int SEG = 256;   // source pixels per task (64 lanes x 4)
 constexpr int MAXU = 2;    // target-cell units (64 cells) owned per wave
-constexpr int MAXNW = 16;
+constexpr int MAXNW = 12;
 // lsi_stream_ok's return value: window cells, plus this bit when every batch
 // element has normaliser == 1 and M row 3 == (0,0,0,1) (division-free kernel)
 constexpr int LSI_STREAM_SIMPLE_BIT = 1 << 20;
@@ -64,7 +64,8 @@ struct TaskInfo {
 
 struct StreamCfg {
   int R;      // target rows per workgroup
-  int wmax;   // window cells per wave
+  int wmax;   // window cells per task
+  int tpw;    // tasks (windows) per wave per step
 };
 
 #define LSI_COMPILER_FENCE() asm volatile("" ::: "memory")
@@ -76,29 +77,64 @@ __device__ __forceinline__ float4 f4_fma(float4 t, float4 v, float w) {
   return t;
 }
 
+// Exact slow path for one source pixel (rare): recomputes the reference's
+// x-axis footprint with clipped cells and adds the up-to-four corners with
+// their exact weights clamp(wx*wy) into the extras tile by fp32 LDS atomics.
+__device__ __forceinline__ void slow_corners(float* extras, float4 V, float X,
+                                             float xmax, float wy0, float wy1,
+                                             int row0, int rows, int Wt) {
+  const Axis ax = splat_axis(X, xmax);
+  const float wc[4] = {clamp_small(ax.w0 * wy0), clamp_small(ax.w1 * wy0),
+                       clamp_small(ax.w0 * wy1), clamp_small(ax.w1 * wy1)};
+  const int cx[2] = {(int)ax.c0s, (int)ax.c1s};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = row0 + (k >> 1);
+    if (wc[k] == 0.0f || r < 0 || r >= rows) continue;
+    float* e = extras + ((size_t)r * Wt + cx[k & 1]) * 4;
+    atomic_add_f32(e + 0, V.x * wc[k]);
+    atomic_add_f32(e + 1, V.y * wc[k]);
+    atomic_add_f32(e + 2, V.z * wc[k]);
+    atomic_add_f32(e + 3, V.w * wc[k]);
+  }
+}
+
 // SIMPLE: the normaliser is exactly 1 and row 3 of M is (0,0,0,1) for every
 // batch element (rectified stereo): u = q0 and D = d with no division.
 template <int LAYOUT, bool SIMPLE>  // LAYOUT 0: channels-last RGB, 1: planar
-__global__ __launch_bounds__(1024) void splat_stream_kernel(SplatArgs a,
-                                                            StreamCfg cfg) {
+__global__ __launch_bounds__(768) void splat_stream_kernel(SplatArgs a,
+                                                           StreamCfg cfg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const LsiSplatDesc& d = a.d;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int T = blockDim.x, NW = T >> 6;
-  const int R = cfg.R, WMAX = cfg.wmax;
+  const int R = cfg.R, WMAX = cfg.wmax, TPW = cfg.tpw;
+  const int NWIN = NW * TPW;  // windows (= tasks) per step, <= 64
   const int Wt = d.Wt, Ht = d.Ht, W = d.W;
-  const int b = blockIdx.y;
-  const int row0 = blockIdx.x * R;
+  // XCD-aware placement (speed only): workgroup i runs on XCD i % 8, each with
+  // its own L2.  Neighbouring bands re-read each other's halo rows, so give
+  // every XCD a contiguous run of bands (bijective remap, any grid size).
+  int b, band;
+  {
+    const unsigned nwg = gridDim.x * gridDim.y;
+    const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
+    const unsigned xcd = lin & 7u, q = nwg >> 3, r8 = nwg & 7u;
+    const unsigned base =
+        xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q;
+    const unsigned id = base + (lin >> 3);
+    band = id % gridDim.x;
+    b = id / gridDim.x;
+  }
+  const int row0 = band * R;
   const int rows = min(R, Ht - row0);
   const int NB = (Wt + 63) >> 6;
   const int nunits = rows * NB;
 
-  float4* rb_all = reinterpret_cast<float4*>(smem_raw);          // [NW][WMAX]
-  unsigned* cnt_all = reinterpret_cast<unsigned*>(rb_all + NW * WMAX);
+  float4* rb_all = reinterpret_cast<float4*>(smem_raw);  // [NWIN][WMAX]
+  unsigned* cnt_all = reinterpret_cast<unsigned*>(rb_all + NWIN * WMAX);
   float* extras = reinterpret_cast<float*>(cnt_all + NW * WMAX);  // [R][Wt][4]
-  TaskInfo* tinfo = reinterpret_cast<TaskInfo*>(extras + R * Wt * 4);
-  int* yrange = reinterpret_cast<int*>(tinfo + MAXNW);
-  float4* rb = rb_all + wave * WMAX;
+  TaskInfo* tinfo = reinterpret_cast<TaskInfo*>(extras + R * Wt * 4);  // [64]
+  int* yrange = reinterpret_cast<int*>(tinfo + 64);
   unsigned* cnt = cnt_all + wave * WMAX;
 
   // Everything read from global / kernarg memory inside the loops is copied to
@@ -121,27 +157,44 @@ __global__ __launch_bounds__(1024) void splat_stream_kernel(SplatArgs a,
   const float xmax = (float)Wt - 1.0f, ymax = (float)Ht - 1.0f;
   const bool has_mask = d.flags & LSI_HAS_MASK;
   const bool compose = d.flags & LSI_COMPOSE;
+  const float inv_md = div_rn(1.0f, max_disp);
 
-  long long* tdbg = (a.d.reserved & 4) ? reinterpret_cast<long long*>(a.canvas) +
-                        ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 32 : nullptr;
+  long long* tdbg = (a.d.reserved & 4)
+                        ? reinterpret_cast<long long*>(a.canvas) +
+                              ((size_t)b * gridDim.x + band) * 32
+                        : nullptr;
   int tslot = 0;
-#define LSI_TSTAMP() do { if (tdbg && tid == 0 && tslot < 32) tdbg[tslot++] = (long long)__builtin_readcyclecounter(); } while (0)
+#define LSI_TSTAMP()                                               \
+  do {                                                             \
+    if (tdbg && tid == 0 && tslot < 32)                            \
+      tdbg[tslot++] = (long long)__builtin_readcyclecounter();     \
+  } while (0)
   LSI_TSTAMP();
+
+  // Row-uniform target coordinate Y(y) = (q1/n')*s - 0.5 (exact op order).
+  auto row_Y = [&](int y, float& nden) {
+    const float py = (float)y + 0.5f;
+    const float q1 = mrow(m, 1, 0.5f, py, 0.0f);
+    if (SIMPLE) {
+      nden = 1.0f;
+      return q1 * s - 0.5f;
+    }
+    nden = safe_den(mrow(m, 2, 0.5f, py, 0.0f));
+    return div_rn(q1, nden) * s - 0.5f;
+  };
+
   // ---- one-time init ------------------------------------------------------
-  for (int i = tid; i < NW * WMAX; i += T) {
+  for (int i = tid; i < NWIN * WMAX; i += T)
     rb_all[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    cnt_all[i] = 0u;
-  }
+  for (int i = tid; i < NW * WMAX; i += T) cnt_all[i] = 0u;
   for (int i = tid; i < R * Wt * 4; i += T) extras[i] = 0.0f;
   if (tid == 0) { yrange[0] = d.H; yrange[1] = -1; }
   __syncthreads();
   {  // source rows whose target rows (y0, y0+1) intersect the band
     int lo = d.H, hi = -1;
     for (int y = tid; y < d.H; y += T) {
-      const float py = (float)y + 0.5f;
-      const float q1 = mrow(m, 1, 0.5f, py, 0.0f);
-      const float nd = safe_den(mrow(m, 2, 0.5f, py, 0.0f));
-      const float Y = div_rn(q1, nd) * s - 0.5f;
+      float nd;
+      const float Y = row_Y(y, nd);
       if (!finite_f(Y)) continue;
       const float y0 = floorf(Y);
       if (y0 >= (float)(row0 - 1) && y0 <= (float)(row0 + rows - 1)) {
@@ -155,6 +208,7 @@ __global__ __launch_bounds__(1024) void splat_stream_kernel(SplatArgs a,
   const int y_lo = yrange[0], y_hi = yrange[1];
   const int nsrc = (y_hi >= y_lo) ? (y_hi - y_lo + 1) : 0;
   const int nseg = (W + SEG - 1) / SEG;
+  const float inv_nseg = 1.0f / (float)nseg;
   const float bg = d.bg_wt;
   const size_t P = (size_t)Ht * Wt;
 
@@ -166,53 +220,58 @@ __global__ __launch_bounds__(1024) void splat_stream_kernel(SplatArgs a,
     for (int u = 0; u < MAXU; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
     const int l_begin = compose ? 0 : pass;
     const int ntask = nsrc * nseg;
-    const int nstep = (ntask + NW - 1) / NW;
+    const int nstep = (ntask + NWIN - 1) / NWIN;
 
     for (int step = 0; step < nstep; ++step) {
-      // ================= x-pass: one task per wave ========================
-      // task = (source row y, 256-pixel segment j), all layers of the pass
-      const int tg = step * NW + wave;
-      TaskInfo ti;
-      ti.row0 = -1000000; ti.wy0 = 0.f; ti.wy1 = 0.f; ti.wlo = 0; ti.wwin = 0;
-      int y = 0, xs = 0;
-      float nden = 1.0f;
-      bool tvalid = tg < ntask;
-      if (tvalid) {
-        const int j = tg % nseg;
-        y = y_lo + tg / nseg;
-        xs = j * SEG;
-        const float py = (float)y + 0.5f;
-        const float q1 = mrow(m, 1, 0.5f, py, 0.0f);
-        nden = safe_den(mrow(m, 2, 0.5f, py, 0.0f));
-        const float Y = div_rn(q1, nden) * s - 0.5f;
-        tvalid = false;
-        if (finite_f(Y) && fabsf(Y) < 1.0e7f) {
-          const Axis ay = splat_axis(Y, ymax);
-          ti.row0 = (int)floorf(Y) - row0;
-          ti.wy0 = ay.w0;
-          ti.wy1 = ay.w1;
-          tvalid = (ay.w0 != 0.0f) || (ay.w1 != 0.0f);
-          // window hint: cells reachable for d in [0, max_disp] over the segment
-          const int xe = min(xs + SEG, W);
-          float lo = __builtin_inff(), hi = -__builtin_inff();
+      // ================= x-pass: TPW tasks per wave =========================
+      // task = (source row y, 256-pixel segment j), all layers of the pass;
+      // task slot k*NW + wave owns LDS window [slot]
+      for (int k = 0; k < TPW; ++k) {
+        const int slot = k * NW + wave;
+        const int tg = step * NWIN + slot;
+        TaskInfo ti;
+        ti.row0 = -1000000; ti.wy0 = 0.f; ti.wy1 = 0.f; ti.wlo = 0; ti.wwin = 0;
+        int y = 0, xs = 0;
+        float nden = 1.0f;
+        bool tvalid = tg < ntask;
+        if (tvalid) {
+          // tg / nseg without an integer division (tg < 2^20: exact in fp32)
+          const int yi = (int)(((float)tg + 0.5f) * inv_nseg);
+          const int j = tg - yi * nseg;
+          y = y_lo + yi;
+          xs = j * SEG;
+          const float py = (float)y + 0.5f;
+          const float Y = row_Y(y, nden);
+          tvalid = false;
+          if (finite_f(Y) && fabsf(Y) < 1.0e7f) {
+            const Axis ay = splat_axis(Y, ymax);
+            ti.row0 = (int)floorf(Y) - row0;
+            ti.wy0 = ay.w0;
+            ti.wy1 = ay.w1;
+            tvalid = (ay.w0 != 0.0f) || (ay.w1 != 0.0f);
+            // window hint: cells reachable for d in [0, max_disp] on the segment
+            const int xe = min(xs + SEG, W);
+            float lo = __builtin_inff(), hi = -__builtin_inff();
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const float px = (float)((c & 1) ? (xe - 1) : xs) + 0.5f;
-            const float dd = (c & 2) ? max_disp : 0.0f;
-            const float X = div_rn(mrow(m, 0, px, py, dd), nden) * s - 0.5f;
-            lo = fminf(lo, X); hi = fmaxf(hi, X);
-          }
-          if (finite_f(lo) && finite_f(hi) && fabsf(lo) < 1.0e7f &&
-              fabsf(hi) < 1.0e7f) {
-            ti.wlo = (int)floorf(lo) - 1;
-            ti.wwin = min(WMAX, (int)floorf(hi) + 3 - ti.wlo);
+            for (int c = 0; c < 4; ++c) {
+              const float px = (float)((c & 1) ? (xe - 1) : xs) + 0.5f;
+              const float dd = (c & 2) ? max_disp : 0.0f;
+              const float q0 = mrow(m, 0, px, py, dd);
+              const float X = (SIMPLE ? q0 : div_rn(q0, nden)) * s - 0.5f;
+              lo = fminf(lo, X); hi = fmaxf(hi, X);
+            }
+            if (finite_f(lo) && finite_f(hi) && fabsf(lo) < 1.0e7f &&
+                fabsf(hi) < 1.0e7f) {
+              ti.wlo = (int)floorf(lo) - 1;
+              ti.wwin = min(WMAX, (int)floorf(hi) + 3 - ti.wlo);
+            }
           }
         }
-      }
-      if (lane == 0) tinfo[wave] = ti;
-      // this wave's window is zero here (zeroed after the previous merge)
+        if (lane == 0) tinfo[slot] = ti;
+        if (!tvalid) continue;
+        LSI_TSTAMP();
 
-      if (tvalid) {
+        float4* rb = rb_all + slot * WMAX;  // zero here
         const int x = xs + 4 * lane;
         const bool inrange = x < W;
         const float py = (float)y + 0.5f;
@@ -220,12 +279,11 @@ __global__ __launch_bounds__(1024) void splat_stream_kernel(SplatArgs a,
         const float pym01 = py * m[1];
         const float pym31 = py * m[13];
         const float rn = SIMPLE ? 1.0f : div_rn(1.0f, nden);
-        const float inv_md = div_rn(1.0f, max_disp);
         const float wy0 = ti.wy0, wy1 = ti.wy1;
         // smallest non-zero row weight: a side is exactly factorisable iff its
         // product with this one survives the 1e-3 clamp (rounding is monotone)
-        const float wymin = (wy0 == 0.f) ? wy1 : ((wy1 == 0.f) ? wy0
-                                                               : fminf(wy0, wy1));
+        const float wymin =
+            (wy0 == 0.f) ? wy1 : ((wy1 == 0.f) ? wy0 : fminf(wy0, wy1));
         const float wlo_f = (float)ti.wlo;
         const float whi_f = (float)(ti.wlo + ti.wwin - 2);  // last left cell
 
@@ -287,65 +345,57 @@ __global__ __launch_bounds__(1024) void splat_stream_kernel(SplatArgs a,
               u = div_rn(q0, nden);  // index-critical: IEEE division
             }
             const float X = u * s - 0.5f;
-            // non-finite disparity => non-finite X (q0 = .. + d*m03; NaN*0 and
-            // Inf*0 are NaN): the point is dropped, as in the oracle
-            const bool ok = inrange && (fabsf(X) < 1.0e30f);
+            // sampling.py:193-211 on the x axis.  floor / x1-x / x-x0 as in the
+            // reference; the border masks as integer range tests (identical
+            // for every cell index that fits an int, i.e. any in-window lane)
+            const float x0 = floorf(X);
+            const float gx = (x0 + 1.0f) - X;  // x1 - x
+            const float fx = X - x0;           // x  - x0
+            const int xi = (int)x0;
+            const float w0 = ((unsigned)xi < (unsigned)Wt) ? gx : 0.0f;
+            const float w1 = ((unsigned)(xi + 1) < (unsigned)Wt) ? fx : 0.0f;
             // weights are not index-critical: reciprocal multiplies (<= 2 ulp)
             const float dd = SIMPLE ? q3 : q3 * rn;
             const float pw = zbuffer_weight(dd * inv_md, zscale) * mk[i];
-            const Axis ax = splat_axis(X, xmax);
-            const float x0raw = floorf(X);
+            // non-finite disparity => non-finite X (NaN*0, Inf*0 are NaN): the
+            // point is dropped, as in the oracle
+            const bool ok = inrange && (fabsf(X) < 1.0e30f);
             const bool active = ok && (pw != 0.0f);
-            const bool sep_ok =
-                (ax.w0 == 0.f || ax.w0 * wymin > 1e-3f) &&
-                (ax.w1 == 0.f || ax.w1 * wymin > 1e-3f);
-            const bool inwin = (x0raw >= wlo_f) && (x0raw <= whi_f);
+            const bool sep_ok = (w0 == 0.f || w0 * wymin > 1e-3f) &&
+                                (w1 == 0.f || w1 * wymin > 1e-3f);
+            const bool inwin = (x0 >= wlo_f) && (x0 <= whi_f);
             const bool fast = active && sep_ok && inwin;
             const bool slow = active && !fast;
-            const float4 V =
-                make_float4(cr[i] * pw, cg[i] * pw, cb[i] * pw, pw);
+            const float4 V = make_float4(cr[i] * pw, cg[i] * pw, cb[i] * pw, pw);
 
-            if (slow && !(dbg & 1)) {
-              // exact, rare: fp32 LDS atomics into the extras tile
-              const float wc[4] = {
-                  clamp_small(ax.w0 * wy0), clamp_small(ax.w1 * wy0),
-                  clamp_small(ax.w0 * wy1), clamp_small(ax.w1 * wy1)};
-              const int cx[2] = {(int)ax.c0s, (int)ax.c1s};
-#pragma unroll
-              for (int k = 0; k < 4; ++k) {
-                const int r = ti.row0 + (k >> 1);
-                if (wc[k] == 0.0f || r < 0 || r >= rows) continue;
-                float* e = extras + ((size_t)r * Wt + cx[k & 1]) * 4;
-                atomic_add_f32(e + 0, V.x * wc[k]);
-                atomic_add_f32(e + 1, V.y * wc[k]);
-                atomic_add_f32(e + 2, V.z * wc[k]);
-                atomic_add_f32(e + 3, V.w * wc[k]);
-              }
+            if (__ballot(slow) != 0ull && !(dbg & 1)) {
+              if (slow)
+                slow_corners(extras, V, X, xmax, wy0, wy1, ti.row0, rows, Wt);
             }
-
-            // ---- conflict-free plain RMW into the private window ----------
-            const int cl = fast ? ((int)x0raw - ti.wlo) : 0;
-            const float prev = __shfl_up(x0raw, 1);
-            const bool mono_lane = (lane == 0) || !inrange || (x0raw > prev);
-            const bool mono =
-                (__ballot(mono_lane) == ~0ull) || (dbg & 2);
+            // lane l-1's value by DPP wave_shr:1 (VALU, no LDS round trip)
+            const float prev = __int_as_float(__builtin_amdgcn_update_dpp(
+                0, __float_as_int(x0), 0x138, 0xf, 0xf, false));
+            const bool mono_lane = (lane == 0) || !inrange || (x0 > prev);
+            const bool mono = (__ballot(mono_lane) == ~0ull) || (dbg & 2);
+            float4* cell = rb + (fast ? (xi - ti.wlo) : 0);
             if (mono) {
-              if (fast) rb[cl] = f4_fma(rb[cl], V, ax.w0);
+              if (fast) cell[0] = f4_fma(cell[0], V, w0);
               LSI_COMPILER_FENCE();
-              if (fast) rb[cl + 1] = f4_fma(rb[cl + 1], V, ax.w1);
+              if (fast) cell[1] = f4_fma(cell[1], V, w1);
               LSI_COMPILER_FENCE();
             } else if (__ballot(fast) != 0ull) {
+              unsigned* cn = cnt + (fast ? (xi - ti.wlo) : 0);
               unsigned rank = 0u;
-              if (fast) rank = atomicAdd(&cnt[cl], 1u);
+              if (fast) rank = atomicAdd(cn, 1u);
               for (unsigned r = 0;; ++r) {
                 if (__ballot(fast && rank >= r) == 0ull) break;
                 const bool mine = fast && rank == r;
-                if (mine) rb[cl] = f4_fma(rb[cl], V, ax.w0);
+                if (mine) cell[0] = f4_fma(cell[0], V, w0);
                 LSI_COMPILER_FENCE();
-                if (mine) rb[cl + 1] = f4_fma(rb[cl + 1], V, ax.w1);
+                if (mine) cell[1] = f4_fma(cell[1], V, w1);
                 LSI_COMPILER_FENCE();
               }
-              if (fast) cnt[cl] = 0u;
+              if (fast) *cn = 0u;
               LSI_COMPILER_FENCE();
             }
           }
@@ -357,43 +407,70 @@ __global__ __launch_bounds__(1024) void splat_stream_kernel(SplatArgs a,
 
       // ================= merge: cell owners gather the windows =============
       {
-        // lane t holds task t's table entry; entries are broadcast per task
-        // with readlane (no LDS round trip per iteration)
+        // lane t holds task slot t's table entry; the slots that touch a unit
+        // are found with one ballot and their entries broadcast by readlane
         TaskInfo mine;
         mine.row0 = -1000000; mine.wy0 = 0.f; mine.wy1 = 0.f;
         mine.wlo = 0; mine.wwin = 0;
-        if (lane < NW) mine = tinfo[lane];
-        for (int t = 0; t < NW; ++t) {
-          const int q_row0 = __builtin_amdgcn_readlane(mine.row0, t);
-          const int q_wlo = __builtin_amdgcn_readlane(mine.wlo, t);
-          const int q_wwin = __builtin_amdgcn_readlane(mine.wwin, t);
-          const float q_wy0 = __int_as_float(
-              __builtin_amdgcn_readlane(__float_as_int(mine.wy0), t));
-          const float q_wy1 = __int_as_float(
-              __builtin_amdgcn_readlane(__float_as_int(mine.wy1), t));
+        if (lane < NWIN) mine = tinfo[lane];
 #pragma unroll
-          for (int u = 0; u < MAXU; ++u) {
-            const int unit = wave + u * NW;
-            if (unit >= nunits) continue;
-            const int r = unit / NB;
-            float wy;
-            if (q_row0 == r) wy = q_wy0;
-            else if (q_row0 + 1 == r) wy = q_wy1;
-            else continue;
-            if (wy == 0.0f) continue;
-            const int cell = (unit - r * NB) * 64 + lane;
+        for (int u = 0; u < MAXU; ++u) {
+          const int unit = wave + u * NW;
+          if (unit >= nunits) continue;
+          const int r = unit / NB;
+          const int c0 = (unit - r * NB) * 64;
+          const int cell = c0 + lane;
+          const bool hit =
+              ((mine.row0 == r && mine.wy0 != 0.f) ||
+               (mine.row0 + 1 == r && mine.wy1 != 0.f)) &&
+              (mine.wlo <= c0 + 63) && (mine.wlo + mine.wwin > c0);
+          unsigned long long todo = __ballot(hit);
+          // entry t of the table, broadcast; value of window t at this lane's
+          // cell (0 outside the window) and the row weight that applies
+          auto fetch = [&](int t, float4& v, float& wy) {
+            const int q_row0 = __builtin_amdgcn_readlane(mine.row0, t);
+            const int q_wlo = __builtin_amdgcn_readlane(mine.wlo, t);
+            const int q_wwin = __builtin_amdgcn_readlane(mine.wwin, t);
+            const float q_wy0 = __int_as_float(
+                __builtin_amdgcn_readlane(__float_as_int(mine.wy0), t));
+            const float q_wy1 = __int_as_float(
+                __builtin_amdgcn_readlane(__float_as_int(mine.wy1), t));
+            wy = (q_row0 == r) ? q_wy0 : q_wy1;
             const int rel = cell - q_wlo;
-            if (rel >= 0 && rel < q_wwin && cell < Wt)
-              acc[u] = f4_fma(acc[u], rb_all[t * WMAX + rel], wy);
+            const bool in = rel >= 0 && rel < q_wwin && cell < Wt;
+            v = rb_all[t * WMAX + (in ? rel : 0)];
+            if (!in) wy = 0.0f;
+          };
+          while (todo) {  // two independent LDS reads in flight per iteration
+            const int t0 = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            float4 va, vb = make_float4(0.f, 0.f, 0.f, 0.f);
+            float wa, wb = 0.0f;
+            fetch(t0, va, wa);
+            if (todo) {
+              const int t1 = __builtin_ctzll(todo);
+              todo &= todo - 1;
+              fetch(t1, vb, wb);
+            }
+            acc[u] = f4_fma(acc[u], va, wa);
+            acc[u] = f4_fma(acc[u], vb, wb);
           }
         }
       }
       LSI_TSTAMP();
       __syncthreads();
       LSI_TSTAMP();
-      // re-zero this wave's window for its next task
-      for (int c = lane; c < ti.wwin; c += 64)
-        rb[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+      // re-zero this wave's windows for the next step / pass
+      if (step + 1 < nstep || pass + 1 < npass) {
+        for (int k = 0; k < TPW; ++k) {
+          const int slot = k * NW + wave;
+          const int ww = tinfo[slot].wwin;
+          float4* rbz = rb_all + slot * WMAX;
+          for (int c = lane; c < ww; c += 64)
+            rbz[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __syncthreads();
+      }
     }
 
     // ================= epilogue for this pass ===============================
@@ -423,9 +500,10 @@ __global__ __launch_bounds__(1024) void splat_stream_kernel(SplatArgs a,
   }
 }
 
-size_t stream_lds_bytes(const LsiSplatDesc* d, int R, int nw, int wmax) {
-  return (size_t)nw * wmax * 16 + (size_t)nw * wmax * 4 +
-         (size_t)R * d->Wt * 16 + MAXNW * sizeof(TaskInfo) + 16;
+size_t stream_lds_bytes(const LsiSplatDesc* d, int R, int nw, int wmax,
+                        int tpw) {
+  return (size_t)nw * tpw * wmax * 16 + (size_t)nw * wmax * 4 +
+         (size_t)R * d->Wt * 16 + 64 * sizeof(TaskInfo) + 16;
 }
 
 // layout class of the texture strides: 0 channels-last, 1 planar, -1 neither
@@ -500,32 +578,36 @@ int lsi_stream_launch(const SplatArgs& a, hipStream_t stream) {
       R = c;
     }
   }
-  int nw = 0;
+  const int tpw_override = (d->reserved >> 8) & 0xff;  // experiments only
+  int nw = 0, tpw = 1;
   for (;;) {
     // source rows per band ~ (R + 1) / s; one task per (row, segment)
     const int ntask =
         (int)ceilf((float)(R + 1) / d->trg_downsampling) * nseg;
-    if (d->tune_threads > 0) {
-      nw = (d->tune_threads + 63) / 64;
-      if (nw > MAXNW) nw = MAXNW;
-    } else {  // waves per workgroup: least idle slots in the last step
-      int best_waste = 1 << 30;
-      for (int c = MAXNW; c >= 6; --c) {
-        if (R * NB > MAXU * c) continue;
-        const int waste = (ntask + c - 1) / c * c - ntask;
-        if (waste < best_waste) { best_waste = waste; nw = c; }
+    long best = -1;
+    nw = 0;
+    for (int c = MAXNW; c >= 4; --c) {
+      if (d->tune_threads > 0 && c != (d->tune_threads + 63) / 64) continue;
+      if (R * NB > MAXU * c) continue;
+      for (int t = 1; t <= 6 && c * t <= 64; ++t) {
+        if (tpw_override && t != tpw_override) continue;
+        if (stream_lds_bytes(d, R, c, cfg.wmax, t) > 150 * 1024) break;
+        const int steps = (ntask + c * t - 1) / (c * t);
+        const int waste = steps * c * t - ntask;
+        // fewest steps (barrier rounds), then fewest idle task slots, then
+        // more waves (latency hiding)
+        const long score = -(long)steps * 1000000 - (long)waste * 1000 + c;
+        if (nw == 0 || score > best) { best = score; nw = c; tpw = t; }
       }
     }
-    if (nw > 0 && R * NB <= MAXU * nw &&
-        stream_lds_bytes(d, R, nw, cfg.wmax) <= 150 * 1024)
-      break;
+    if (nw > 0) break;
     if (R == 1) return LSI_EINVAL;
     R /= 2;
-    nw = 0;
   }
   const int threads = nw * 64;
-  const size_t lds = stream_lds_bytes(d, R, nw, cfg.wmax);
+  const size_t lds = stream_lds_bytes(d, R, nw, cfg.wmax, tpw);
   if (lds > 160 * 1024) return LSI_EINVAL;
+  cfg.tpw = tpw;
   cfg.R = R;
   dim3 grid((d->Ht + R - 1) / R, d->B);
   const bool simple = (d->tune_window & LSI_STREAM_SIMPLE_BIT) != 0;
