@@ -50,8 +50,8 @@ using namespace lsi;
 namespace {
 
 constexpr int SEG = 256;   // source pixels per task (64 lanes x 4)
-constexpr int MAXU = 2;    // target-cell units (64 cells) owned per wave
-constexpr int MAXNW = 12;
+constexpr int MAXU = 3;    // target-cell units (64 cells) owned per wave
+constexpr int MAXNW = 16;
 // lsi_stream_ok's return value: window cells, plus this bit when every batch
 // element has normaliser == 1 and M row 3 == (0,0,0,1) (division-free kernel)
 constexpr int LSI_STREAM_SIMPLE_BIT = 1 << 20;
@@ -69,6 +69,22 @@ struct StreamCfg {
 };
 
 #define LSI_COMPILER_FENCE() asm volatile("" ::: "memory")
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// exp(a) for a packed pair; same compensated scheme as lsi::exp_accurate
+__device__ __forceinline__ f2 exp_accurate2(f2 a) {
+  const float L2E_HI = 1.44269502e+00f, L2E_LO = 1.92596299e-08f;
+  const float LN2 = 6.93147182e-01f;
+  const f2 t = a * L2E_HI;
+  f2 r = {__fmaf_rn(a.x, L2E_HI, -t.x), __fmaf_rn(a.y, L2E_HI, -t.y)};
+  r.x = __fmaf_rn(a.x, L2E_LO, r.x);
+  r.y = __fmaf_rn(a.y, L2E_LO, r.y);
+  const f2 e = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+  const f2 rl = r * LN2;
+  f2 o = {__fmaf_rn(e.x, rl.x, e.x), __fmaf_rn(e.y, rl.y, e.y)};
+  return o;
+}
 
 // accumulations are not index-critical: fused multiply-add
 __device__ __forceinline__ float4 f4_fma(float4 t, float4 v, float w) {
@@ -102,7 +118,7 @@ __device__ __forceinline__ void slow_corners(float* extras, float4 V, float X,
 // SIMPLE: the normaliser is exactly 1 and row 3 of M is (0,0,0,1) for every
 // batch element (rectified stereo): u = q0 and D = d with no division.
 template <int LAYOUT, bool SIMPLE>  // LAYOUT 0: channels-last RGB, 1: planar
-__global__ __launch_bounds__(768) void splat_stream_kernel(SplatArgs a,
+__global__ __launch_bounds__(1024) void splat_stream_kernel(SplatArgs a,
                                                            StreamCfg cfg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const LsiSplatDesc& d = a.d;
@@ -262,8 +278,12 @@ __global__ __launch_bounds__(768) void splat_stream_kernel(SplatArgs a,
             }
             if (finite_f(lo) && finite_f(hi) && fabsf(lo) < 1.0e7f &&
                 fabsf(hi) < 1.0e7f) {
-              ti.wlo = (int)floorf(lo) - 1;
-              ti.wwin = min(WMAX, (int)floorf(hi) + 3 - ti.wlo);
+              // cells [wlo, wlo+wwin) confined to the image: a fast lane then
+              // needs no border mask (both its cells are valid)
+              const int c_lo = max((int)floorf(lo) - 1, 0);
+              const int c_hi = min((int)floorf(hi) + 2, Wt - 1);
+              ti.wlo = c_lo;
+              ti.wwin = max(0, min(WMAX, c_hi - c_lo + 1));
             }
           }
         }
@@ -284,6 +304,10 @@ __global__ __launch_bounds__(768) void splat_stream_kernel(SplatArgs a,
         // product with this one survives the 1e-3 clamp (rounding is monotone)
         const float wymin =
             (wy0 == 0.f) ? wy1 : ((wy1 == 0.f) ? wy0 : fminf(wy0, wy1));
+        // the larger x weight is >= ~0.5: its products with the row weights
+        // survive the clamp unless a row weight is itself tiny -- then the
+        // whole task takes the exact path
+        const bool wy_small = wymin <= 2.1e-3f;
         const float wlo_f = (float)ti.wlo;
         const float whi_f = (float)(ti.wlo + ti.wwin - 2);  // last left cell
 
@@ -306,15 +330,19 @@ __global__ __launch_bounds__(768) void splat_stream_kernel(SplatArgs a,
                 g_mask + l * mask_sl + b * mask_sb + y * mask_sy + x);
         };
 
-        PxData nxt;
-        nxt.d4 = nxt.t0 = nxt.t1 = nxt.t2 = make_float4(0.f, 0.f, 0.f, 0.f);
-        nxt.m4 = make_float4(1.f, 1.f, 1.f, 1.f);
-        load_layer(l_begin, nxt);
-        for (int l = l_begin; l < l_begin + Lp; ++l) {
-          const PxData cur = nxt;
-          if (l + 1 < l_begin + Lp) load_layer(l + 1, nxt);
+        // exact threshold test for the clamp: a side's products survive iff
+        // fl(w*wymin) > 1e-3; w > thr is a (slightly conservative) sufficient
+        // condition evaluated with one compare per side
+        const float thr = wy_small ? __builtin_inff()
+                                   : div_rn(1e-3f, wymin) * 1.000001f;
+        const int wspan = ti.wwin - 2;  // last admissible left-cell offset
+
+        // One layer of the lane's 4 pixels.  Hot path: every lane of the wave
+        // is either out of range or "fast" (both cells inside the in-image
+        // window, no clamped corner) and floor(X) is strictly increasing
+        // across the wave -> plain RMW.  Anything else takes general_px().
+        auto do_layer = [&](const PxData& cur) {
           const float dv[4] = {cur.d4.x, cur.d4.y, cur.d4.z, cur.d4.w};
-          const float mk[4] = {cur.m4.x, cur.m4.y, cur.m4.z, cur.m4.w};
           float cr[4], cg[4], cb[4];
           if (LAYOUT == 0) {
             cr[0] = cur.t0.x; cg[0] = cur.t0.y; cb[0] = cur.t0.z;
@@ -326,81 +354,138 @@ __global__ __launch_bounds__(768) void splat_stream_kernel(SplatArgs a,
             cg[0] = cur.t1.x; cg[1] = cur.t1.y; cg[2] = cur.t1.z; cg[3] = cur.t1.w;
             cb[0] = cur.t2.x; cb[1] = cur.t2.y; cb[2] = cur.t2.z; cb[3] = cur.t2.w;
           }
-
+          // ---- projection of the 4 pixels as two packed pairs (v_pk_*_f32) --
+          float x0v[4], w0v[4], w1v[4], pwv[4];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const float px = (float)(x + i) + 0.5f;
+          for (int h = 0; h < 2; ++h) {
+            const f2 px = {(float)(x + 2 * h) + 0.5f, (float)(x + 2 * h) + 1.5f};
+            const f2 dvp = {dv[2 * h], dv[2 * h + 1]};
             // q0 = ((px*m00 + py*m01) + m02) + d*m03, each op rounded
-            float q0 = px * m[0] + pym01;
+            f2 q0 = px * m[0] + pym01;
             q0 = q0 + m[2];
-            q0 = q0 + dv[i] * m[3];
-            float q3, u;
+            q0 = q0 + dvp * m[3];
+            f2 q3, u;
             if (SIMPLE) {
-              q3 = dv[i];
+              q3 = dvp;
               u = q0;  // index-critical u = q0 / n' with n' == 1 exactly
             } else {
               q3 = px * m[12] + pym31;
               q3 = q3 + m[14];
-              q3 = q3 + dv[i] * m[15];
-              u = div_rn(q0, nden);  // index-critical: IEEE division
+              q3 = q3 + dvp * m[15];
+              u.x = div_rn(q0.x, nden);  // index-critical: IEEE division
+              u.y = div_rn(q0.y, nden);
             }
-            const float X = u * s - 0.5f;
-            // sampling.py:193-211 on the x axis.  floor / x1-x / x-x0 as in the
-            // reference; the border masks as integer range tests (identical
-            // for every cell index that fits an int, i.e. any in-window lane)
-            const float x0 = floorf(X);
-            const float gx = (x0 + 1.0f) - X;  // x1 - x
-            const float fx = X - x0;           // x  - x0
-            const int xi = (int)x0;
-            const float w0 = ((unsigned)xi < (unsigned)Wt) ? gx : 0.0f;
-            const float w1 = ((unsigned)(xi + 1) < (unsigned)Wt) ? fx : 0.0f;
+            const f2 X = u * s - 0.5f;
+            // sampling.py:193-211 on the x axis: floor, x1 - x, x - x0
+            const f2 x0 = {floorf(X.x), floorf(X.y)};
+            const f2 gx = (x0 + 1.0f) - X;
+            const f2 fx = X - x0;
             // weights are not index-critical: reciprocal multiplies (<= 2 ulp)
-            const float dd = SIMPLE ? q3 : q3 * rn;
-            const float pw = zbuffer_weight(dd * inv_md, zscale) * mk[i];
-            // non-finite disparity => non-finite X (NaN*0, Inf*0 are NaN): the
-            // point is dropped, as in the oracle
-            const bool ok = inrange && (fabsf(X) < 1.0e30f);
-            const bool active = ok && (pw != 0.0f);
-            const bool sep_ok = (w0 == 0.f || w0 * wymin > 1e-3f) &&
-                                (w1 == 0.f || w1 * wymin > 1e-3f);
-            const bool inwin = (x0 >= wlo_f) && (x0 <= whi_f);
-            const bool fast = active && sep_ok && inwin;
-            const bool slow = active && !fast;
-            const float4 V = make_float4(cr[i] * pw, cg[i] * pw, cb[i] * pw, pw);
-
-            if (__ballot(slow) != 0ull && !(dbg & 1)) {
-              if (slow)
-                slow_corners(extras, V, X, xmax, wy0, wy1, ti.row0, rows, Wt);
+            const f2 dd = SIMPLE ? q3 : q3 * rn;
+            const f2 xn = dd * inv_md;
+            // helpers.py:180-193: exp((clip(x,0,1) - 0.5)*scale) * [x > 0]
+            f2 c = {__builtin_amdgcn_fmed3f(xn.x, 0.0f, 1.0f),
+                    __builtin_amdgcn_fmed3f(xn.y, 0.0f, 1.0f)};
+            c = (c - 0.5f) * zscale;
+            f2 e = exp_accurate2(c);
+            e.x = xn.x > 0.0f ? e.x : 0.0f;  // NaN disparity -> weight 0
+            e.y = xn.y > 0.0f ? e.y : 0.0f;
+            if (has_mask) {
+              const f2 mkp = {h == 0 ? cur.m4.x : cur.m4.z,
+                              h == 0 ? cur.m4.y : cur.m4.w};
+              e = e * mkp;
             }
-            // lane l-1's value by DPP wave_shr:1 (VALU, no LDS round trip)
+            x0v[2 * h] = x0.x; x0v[2 * h + 1] = x0.y;
+            w0v[2 * h] = gx.x; w0v[2 * h + 1] = gx.y;
+            w1v[2 * h] = fx.x; w1v[2 * h + 1] = fx.y;
+            pwv[2 * h] = e.x; pwv[2 * h + 1] = e.y;
+          }
+
+          // ---- LDS phase, pixel by pixel (cells of one lane's pixels overlap)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float x0 = x0v[i], w0 = w0v[i], w1 = w1v[i], pw = pwv[i];
+            // left-cell offset in the window; +-Inf saturates, NaN has pw == 0
+            const int cl = (int)(x0 - wlo_f);
+            const bool fast = inrange && ((unsigned)cl <= (unsigned)wspan) &&
+                              (w0 > thr) && (w1 > thr);
+            const float4 V = make_float4(cr[i] * pw, cg[i] * pw, cb[i] * pw, pw);
+            // lane l-1's floor(X) by DPP wave_shr:1 (VALU, no LDS round trip)
             const float prev = __int_as_float(__builtin_amdgcn_update_dpp(
                 0, __float_as_int(x0), 0x138, 0xf, 0xf, false));
             const bool mono_lane = (lane == 0) || !inrange || (x0 > prev);
-            const bool mono = (__ballot(mono_lane) == ~0ull) || (dbg & 2);
-            float4* cell = rb + (fast ? (xi - ti.wlo) : 0);
-            if (mono) {
-              if (fast) cell[0] = f4_fma(cell[0], V, w0);
-              LSI_COMPILER_FENCE();
-              if (fast) cell[1] = f4_fma(cell[1], V, w1);
-              LSI_COMPILER_FENCE();
-            } else if (__ballot(fast) != 0ull) {
-              unsigned* cn = cnt + (fast ? (xi - ti.wlo) : 0);
-              unsigned rank = 0u;
-              if (fast) rank = atomicAdd(cn, 1u);
-              for (unsigned r = 0;; ++r) {
-                if (__ballot(fast && rank >= r) == 0ull) break;
-                const bool mine = fast && rank == r;
-                if (mine) cell[0] = f4_fma(cell[0], V, w0);
+            const bool clean = ((__ballot(mono_lane && (fast || !inrange)) == ~0ull)
+                                && !(dbg & 16)) || (dbg & 32);
+            float4* cell = rb + (fast ? cl : 0);
+            if (clean) {
+              if (fast) {
+                cell[0] = f4_fma(cell[0], V, w0);
                 LSI_COMPILER_FENCE();
-                if (mine) cell[1] = f4_fma(cell[1], V, w1);
+                cell[1] = f4_fma(cell[1], V, w1);
+              }
+              LSI_COMPILER_FENCE();
+              continue;
+            }
+            // ---- general px: exact slow corners + (ranked) RMW ---------------
+            {
+              // lanes that are not fast but can still touch the image: exact
+              // slow path.  (non-finite X fails the range tests: dropped)
+              const bool slow = inrange && !fast && (pw != 0.0f) &&
+                                (x0 >= -1.0f) && (x0 <= xmax);
+              if (__ballot(slow) != 0ull && !(dbg & 1)) {
+                if (slow) {
+                  // X recomputed exactly as in the projection above
+                  float q0 = ((float)(x + i) + 0.5f) * m[0] + pym01;
+                  q0 = q0 + m[2];
+                  q0 = q0 + dv[i] * m[3];
+                  const float u = SIMPLE ? q0 : div_rn(q0, nden);
+                  slow_corners(extras, V, u * s - 0.5f, xmax, wy0, wy1, ti.row0,
+                               rows, Wt);
+                }
+              }
+              const bool mono = (__ballot(mono_lane) == ~0ull) || (dbg & 2);
+              if (mono) {
+                if (fast) {
+                  cell[0] = f4_fma(cell[0], V, w0);
+                  LSI_COMPILER_FENCE();
+                  cell[1] = f4_fma(cell[1], V, w1);
+                }
+                LSI_COMPILER_FENCE();
+              } else if (__ballot(fast) != 0ull) {
+                unsigned* cn = cnt + (fast ? cl : 0);
+                unsigned rank = 0u;
+                if (fast) rank = atomicAdd(cn, 1u);
+                for (unsigned r = 0;; ++r) {
+                  if (__ballot(fast && rank >= r) == 0ull) break;
+                  if (fast && rank == r) {
+                    cell[0] = f4_fma(cell[0], V, w0);
+                    LSI_COMPILER_FENCE();
+                    cell[1] = f4_fma(cell[1], V, w1);
+                  }
+                  LSI_COMPILER_FENCE();
+                }
+                if (fast) *cn = 0u;
                 LSI_COMPILER_FENCE();
               }
-              if (fast) *cn = 0u;
-              LSI_COMPILER_FENCE();
             }
           }
+        };
+
+        // the next layer's loads are in flight while the current one is
+        // processed (one copy of the loop body: the kernel must stay small
+        // enough for the instruction cache)
+        PxData nxt;
+        nxt.d4 = nxt.t0 = nxt.t1 = nxt.t2 = make_float4(0.f, 0.f, 0.f, 0.f);
+        nxt.m4 = make_float4(1.f, 1.f, 1.f, 1.f);
+        const int l_end = l_begin + Lp;
+        load_layer(l_begin, nxt);
+        for (int l = l_begin; l < l_end; ++l) {
+          const PxData cur = nxt;
+          if (l + 1 < l_end) load_layer(l + 1, nxt);
+          do_layer(cur);
         }
       }
+      if (tdbg && lane == 0 && step == 0) tdbg[16 + wave] = (long long)__builtin_readcyclecounter();
       LSI_TSTAMP();
       __syncthreads();
       LSI_TSTAMP();
@@ -593,10 +678,9 @@ int lsi_stream_launch(const SplatArgs& a, hipStream_t stream) {
         if (tpw_override && t != tpw_override) continue;
         if (stream_lds_bytes(d, R, c, cfg.wmax, t) > 150 * 1024) break;
         const int steps = (ntask + c * t - 1) / (c * t);
-        const int waste = steps * c * t - ntask;
-        // fewest steps (barrier rounds), then fewest idle task slots, then
-        // more waves (latency hiding)
-        const long score = -(long)steps * 1000000 - (long)waste * 1000 + c;
+        // shortest per-wave chain of tasks, then fewest barrier rounds, then
+        // more waves (idle waves are free; busy ones hide each other's latency)
+        const long score = -(long)steps * t * 1000000 - (long)steps * 1000 + c;
         if (nw == 0 || score > best) { best = score; nw = c; tpw = t; }
       }
     }

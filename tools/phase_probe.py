@@ -26,3 +26,7 @@ print('workgroups', len(t), 'stamps', n)
 print('median phase stamps (cycles since WG start):', np.median(rel[:, :n], axis=0).astype(int).tolist())
 print('max:', rel[:, :n].max(axis=0).astype(int).tolist())
 print('WG start spread (cycles):', int(t[:, 0].max() - t[:, 0].min()), ' kernel span:', int(t[:, :n].max() - t[:, 0].min()))
+
+pw = t[:, 16:32]
+pw = np.where(pw != 0, pw - t[:, :1], 0)
+print('per-wave x-pass end (median over WGs):', np.median(pw, axis=0).astype(int).tolist())
