@@ -1,0 +1,261 @@
+"""Script for training an LDI predictor via the view-synthesis loss: the eager,
+MI355X counterpart of the reference's `ldi_enc_dec.py` (same flag names and
+defaults, same dataset-dependent overrides, same six loss terms).
+
+  python layered-scene-inference_amd/ldi_enc_dec.py --dataset=kitti \\
+      --batch_size=4 --n_layers=2 --img_height=256 --img_width=768 ...
+  python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 \\
+      layered-scene-inference_amd/ldi_enc_dec.py ...      # DDP over RCCL
+
+KITTI and the SUN/PASCAL synthetic scenes are not available here (no datasets,
+no network): `--dataset` selects the camera model and the dataset-dependent
+constants (ldi_enc_dec.py:415-427) and the images are procedural (a smooth
+random texture seen from the two cameras through one fronto-parallel plane, so
+that the view-synthesis loss has something consistent to explain).
+"""
+import argparse
+import math
+import os
+import sys
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+if _HERE not in sys.path:
+  sys.path.insert(0, _HERE)
+
+from lsi.geometry import ldi as ldi_utils  # noqa: E402
+from lsi.loss import loss  # noqa: E402
+from lsi.nnutils import helpers as nn_helpers  # noqa: E402
+from lsi.nnutils import nets  # noqa: E402
+from lsi.nnutils import train_utils  # noqa: E402
+
+
+def _bool(v):
+  return str(v).lower() in ('1', 'true', 'yes')
+
+
+def build_parser():
+  p = argparse.ArgumentParser(description=__doc__)
+  train_utils.define_default_flags(p)
+  a = p.add_argument
+  # experiment flags: names and defaults of reference ldi_enc_dec.py:39-123
+  a('--exp_name', default='synth_ldi_pred_encdec')
+  a('--n_layers', type=int, default=2)
+  a('--pred_ldi_masks', type=_bool, default=False)
+  a('--dataset', default='synthetic', choices=['synthetic', 'kitti'])
+  a('--self_cons_wt', type=float, default=1.0)
+  a('--l0_self_cons', type=_bool, default=False)
+  a('--indep_splat_wt', type=float, default=1.0)
+  a('--compose_splat_wt', type=float, default=1.0)
+  a('--splat_bdry_ignore', type=float, default=0.1)
+  a('--zbuf_scale', type=float, default=50)
+  a('--trg_splat_downsampling', type=float, default=0.5)
+  a('--disp_smoothness_wt', type=float, default=0.1)
+  a('--incr_depth_wt', type=float, default=10.0)
+  a('--use_unet', type=_bool, default=True)
+  a('--n_layerwise_steps', type=int, default=3)
+  a('--bg_layer_disp', type=float, default=1e-6)
+  a('--depth_softmax_temp', type=float, default=1e-6)
+  a('--max_disp', type=float, default=0)
+  # build-specific switches
+  a('--bf16', type=_bool, default=False, help='bf16 autocast for the convs')
+  a('--channels_last', type=_bool, default=True)
+  a('--cpu', type=_bool, default=False, help='CPU run (no splat losses)')
+  return p
+
+
+def apply_dataset_overrides(opts):
+  """ldi_enc_dec.py:415-427."""
+  opts.checkpoint_dir = os.path.join(opts.checkpoint_dir, opts.exp_name)
+  if opts.dataset == 'synthetic':
+    opts.bg_layer_disp = 2e-1
+    opts.depth_softmax_temp = 0.4
+    if opts.max_disp == 0:
+      opts.max_disp = 1.0
+  elif opts.dataset == 'kitti':
+    opts.bg_layer_disp = 1e-3
+    opts.depth_softmax_temp = 0.4
+    if opts.max_disp == 0:
+      opts.max_disp = 0.4
+  return opts
+
+
+class LdiNet(torch.nn.Module):
+  """encoder-decoder + per-layer LDI heads (define_pred_graph,
+  ldi_enc_dec.py:175-228); the same weights process src and trg images."""
+
+  def __init__(self, opts):
+    super().__init__()
+    if opts.use_unet:
+      self.enc_dec = nets.encoder_decoder_unet(
+          nl_diff_enc_dec=opts.n_layerwise_steps)
+    else:
+      self.enc_dec = nets.encoder_decoder_simple(
+          nl_diff_enc_dec=opts.n_layerwise_steps,
+          in_hw=(opts.img_height, opts.img_width))
+    self.ldi_tex_disp = nets.ldi_predictor(
+        self.enc_dec.out_channels, n_layers=opts.n_layers,
+        n_layerwise_steps=opts.n_layerwise_steps,
+        skip_channels=self.enc_dec.skip_channels,
+        pred_masks=opts.pred_ldi_masks)
+    self.max_disp = opts.max_disp
+
+  def predict(self, imgs):
+    _, feat_dec, skip_feat, _ = self.enc_dec(imgs)
+    tex, masks, disps = self.ldi_tex_disp(feat_dec, skip_feat)
+    return [tex.float(), None if masks is None else masks.float(),
+            disps.float() * self.max_disp]
+
+  def forward(self, imgs_src, imgs_trg):
+    return self.predict(imgs_src), self.predict(imgs_trg)
+
+
+class SyntheticPairs(object):
+  """Procedural stereo-like pairs with the dataset's camera model."""
+
+  def __init__(self, opts, device, seed):
+    self.opts, self.device = opts, device
+    self.gen = torch.Generator(device='cpu').manual_seed(seed)
+
+  def forward(self, bs):
+    o = self.opts
+    h, w = o.img_height, o.img_width
+    lo = torch.rand((bs, 3, h // 16 + 2, w // 16 + 2), generator=self.gen)
+    img = torch.nn.functional.interpolate(lo, size=(h, w + 64), mode='bicubic',
+                                          align_corners=False).clamp(0, 1)
+    shift = 16  # pixels of parallax of the (single, fronto-parallel) plane
+    src = img[..., 32:32 + w].permute(0, 2, 3, 1).contiguous()
+    trg = img[..., 32 - shift:32 - shift + w].permute(0, 2, 3, 1).contiguous()
+    if o.dataset == 'kitti':
+      k = torch.tensor([[0.58 * w, 0, w / 2.0], [0, 0.58 * w, h / 2.0],
+                        [0, 0, 1.0]])
+      t = torch.tensor([[-0.532], [0.0], [0.0]])
+    else:
+      k = torch.tensor([[float(w), 0, w / 2.0], [0, float(h), h / 2.0],
+                        [0, 0, 1.0]])
+      t = torch.tensor([[-0.3], [0.0], [0.0]])
+    k = k.expand(bs, 3, 3).contiguous()
+    rot = torch.eye(3).expand(bs, 3, 3).contiguous()
+    t = t.expand(bs, 3, 1).contiguous()
+    return (src.to(self.device), trg.to(self.device), k, k.clone(), rot, t)
+
+
+class Trainer(train_utils.Trainer):
+  """LDI prediction trainer (reference ldi_enc_dec.py:126-410)."""
+
+  def define_data_loader(self):
+    self.data_loader = SyntheticPairs(self.opts, self.device, 1234 + self.rank)
+    bs = self.opts.batch_size
+    self.pixel_coords = nn_helpers.pixel_coords(bs, self.opts.img_height,
+                                                self.opts.img_width)
+
+  def build_model(self):
+    return LdiNet(self.opts)
+
+  def feed(self):
+    return self.data_loader.forward(self.opts.batch_size)
+
+  def compute_losses(self, batch):
+    opts = self.opts
+    imgs_src, imgs_trg, k_s, k_t, rot_mat, trans_mat = batch
+    inv_rot_mat = nn_helpers.transpose(rot_mat)
+    inv_trans_mat = -torch.matmul(inv_rot_mat, trans_mat)
+    amp = (torch.autocast('cuda', dtype=torch.bfloat16) if
+           (opts.bf16 and self.device.type == 'cuda') else _NullCtx())
+    with amp:
+      ldi_src, ldi_trg = self.train_model(imgs_src, imgs_trg)
+
+    def ones_like_mask(l):
+      return l[1] if l[1] is not None else torch.ones_like(l[2])
+
+    # self-consistency (ldi_enc_dec.py:269-294)
+    if opts.l0_self_cons:
+      sc_src = torch.mean(torch.abs(imgs_src - ldi_src[0][0]))
+      sc_trg = torch.mean(torch.abs(imgs_trg - ldi_trg[0][0]))
+    else:
+      sc_src = loss.zbuffer_composition_loss(
+          ldi_src[0], ones_like_mask(ldi_src), ldi_src[2], imgs_src,
+          zbuf_scale=opts.zbuf_scale, bg_layer_disp=opts.bg_layer_disp,
+          max_disp=opts.max_disp)
+      sc_trg = loss.zbuffer_composition_loss(
+          ldi_trg[0], ones_like_mask(ldi_trg), ldi_trg[2], imgs_trg,
+          zbuf_scale=opts.zbuf_scale, bg_layer_disp=opts.bg_layer_disp,
+          max_disp=opts.max_disp)
+    self_cons_loss = sc_src + sc_trg
+
+    # view synthesis via forward splatting (ldi_enc_dec.py:296-357)
+    zero = imgs_src.new_zeros(())
+    indep_splat_loss, compose_splat_loss = zero, zero
+    for use_compose, wt in ((False, opts.indep_splat_wt),
+                            (True, opts.compose_splat_wt)):
+      if wt <= 0 or self.device.type != 'cuda':
+        continue
+      for which in ('trg', 'src'):
+        if which == 'trg':
+          target, l, cams = imgs_trg, ldi_src, (k_s, k_t, rot_mat, trans_mat)
+        else:
+          target, l, cams = imgs_src, ldi_trg, (k_t, k_s, inv_rot_mat,
+                                                inv_trans_mat)
+        recons_splat, _ = ldi_utils.forward_splat(
+            l, self.pixel_coords, *cams, compose_layers=use_compose,
+            trg_downsampling=opts.trg_splat_downsampling,
+            zbuf_scale=opts.zbuf_scale, bg_layer_disp=opts.bg_layer_disp,
+            max_disp=opts.max_disp)
+        term = loss.view_synthesis_loss(recons_splat, target,
+                                        opts.splat_bdry_ignore)
+        if use_compose:
+          compose_splat_loss = compose_splat_loss + term
+        else:
+          indep_splat_loss = indep_splat_loss + term
+
+    # regularisers (ldi_enc_dec.py:388-396)
+    disp_smoothness_loss = (ldi_utils.disp_smoothness_loss(ldi_src[2]) +
+                            ldi_utils.disp_smoothness_loss(ldi_trg[2]))
+    incr_depth_loss = (loss.decreasing_disp_loss(ldi_src[2]) +
+                       loss.decreasing_disp_loss(ldi_trg[2]))
+
+    total = zero
+    if opts.self_cons_wt > 0:
+      total = total + opts.self_cons_wt * self_cons_loss
+    if opts.compose_splat_wt > 0:
+      total = total + opts.compose_splat_wt * compose_splat_loss
+    if opts.indep_splat_wt > 0:
+      total = total + opts.indep_splat_wt * indep_splat_loss
+    if opts.incr_depth_wt > 0:
+      total = total + (opts.incr_depth_wt / opts.max_disp) * incr_depth_loss
+    if opts.disp_smoothness_wt > 0:
+      total = total + (opts.disp_smoothness_wt /
+                       (opts.max_disp * opts.max_disp)) * disp_smoothness_loss
+    scalars = {
+        'self_cons_loss': self_cons_loss,
+        'compose_splat_loss': compose_splat_loss,
+        'indep_splat_loss': indep_splat_loss,
+        'incr_depth_loss': incr_depth_loss,
+        'disp_smoothness_loss': disp_smoothness_loss,
+        'total_loss': total,
+    }
+    return total, scalars
+
+
+class _NullCtx(object):
+
+  def __enter__(self):
+    return self
+
+  def __exit__(self, *a):
+    return False
+
+
+def main(argv=None):
+  opts = apply_dataset_overrides(build_parser().parse_args(argv))
+  trainer = Trainer(opts)
+  trainer.setup()
+  trainer.train()
+  if trainer.dist is not None:
+    trainer.dist.destroy_process_group()
+  return trainer
+
+
+if __name__ == '__main__':
+  main()

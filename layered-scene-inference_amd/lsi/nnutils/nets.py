@@ -1,0 +1,371 @@
+"""CNN definitions (mirror of the reference's lsi/nnutils/nets.py) as
+torch.nn.Modules on PyTorch-ROCm (convolutions run on MIOpen's MFMA kernels;
+channels-last memory format and bf16 autocast are supported by the callers).
+
+Conventions kept from the reference (tf.contrib.slim, nets.py:29-348):
+  * tensors at the module boundary are B x H x W x C (channels-last logical
+    shape); modules permute to NCHW views internally -- with the
+    channels_last memory format that permute is free;
+  * slim.conv2d: TF 'SAME' padding (asymmetric for stride 2: k=7 pads 2/3,
+    k=5 pads 1/2, k=3 pads 0/1), no bias when followed by batch norm, ReLU,
+    xavier-uniform weights;
+  * slim.batch_norm defaults: no scale (gamma), learned offset (beta) only,
+    epsilon 1e-3, and -- because the reference's train op never runs the
+    UPDATE_OPS (train_utils.py:107-117) and evaluation defaults to
+    batch_norm_training=True (ldi_pred_eval.py:45-46) -- always batch
+    statistics; the moving averages stay at their initial values;
+  * slim.conv2d_transpose [4,4] stride 2 'SAME' == ConvTranspose2d(4, 2, 1);
+  * the l2 weights_regularizer is declared but never added to the loss
+    (ldi_enc_dec.py:398-410): no weight decay.
+Parameters the reference creates but never trains when n_layerwise_steps=3
+(the `fc` stack on the bottleneck, upcnv3..icnv1) are only built on request
+(`with_fc`, `nl_diff_enc_dec`), so that DDP's reducer never waits for them.
+"""
+import math
+
+import torch
+from torch import nn
+import torch.nn.functional as F
+
+from lsi.nnutils import helpers as nn_helpers
+
+
+def _same_pad(n, k, stride):
+  """TF 'SAME' padding (before, after) along one axis of length n:
+  total = max((ceil(n/stride) - 1)*stride + k - n, 0), the extra pixel after."""
+  total = max((-(-n // stride) - 1) * stride + k - n, 0)
+  return total // 2, total - total // 2
+
+
+class SlimBatchNorm(nn.Module):
+  """slim.batch_norm defaults: center=True, scale=False, epsilon=1e-3."""
+
+  def __init__(self, channels, eps=1e-3):
+    super().__init__()
+    self.beta = nn.Parameter(torch.zeros(channels))
+    self.register_buffer('moving_mean', torch.zeros(channels))
+    self.register_buffer('moving_variance', torch.ones(channels))
+    self.eps = eps
+    self.is_training = True
+
+  def forward(self, x):
+    if self.is_training:
+      if x.numel() // x.shape[1] > 1:
+        return F.batch_norm(x, None, None, None, self.beta, True, 0.0, self.eps)
+      # one value per channel (1x1 bottleneck at batch 1): TF normalises with
+      # variance 0, torch's fused kernel refuses -- same arithmetic by hand
+      var, mean = torch.var_mean(x, dim=(0, 2, 3), unbiased=False, keepdim=True)
+      return (x - mean) * torch.rsqrt(var + self.eps) + self.beta.view(1, -1, 1, 1)
+    return F.batch_norm(x, self.moving_mean, self.moving_variance, None,
+                        self.beta, False, 0.0, self.eps)
+
+
+class SlimConv2d(nn.Module):
+  """slim.conv2d(inputs, num_outputs, [k, k], stride) with the arg_scope of
+  nets.py (batch norm + ReLU), or bias + custom activation when normalizer is
+  None (the `pred_l` heads, nets.py:143-154)."""
+
+  def __init__(self, cin, cout, k, stride=1, batch_norm=True, activation='relu'):
+    super().__init__()
+    self.k, self.stride = k, stride
+    self.conv = nn.Conv2d(cin, cout, k, stride=stride, padding=0,
+                          bias=not batch_norm)
+    nn.init.xavier_uniform_(self.conv.weight)
+    if self.conv.bias is not None:
+      nn.init.zeros_(self.conv.bias)
+    self.bn = SlimBatchNorm(cout) if batch_norm else None
+    self.activation = activation
+
+  def forward(self, x):
+    ph = _same_pad(x.shape[2], self.k, self.stride)
+    pw = _same_pad(x.shape[3], self.k, self.stride)
+    if ph[0] or ph[1] or pw[0] or pw[1]:
+      x = F.pad(x, (pw[0], pw[1], ph[0], ph[1]))
+    x = self.conv(x)
+    if self.bn is not None:
+      x = self.bn(x)
+    if self.activation == 'relu':
+      return F.relu(x)
+    if self.activation == 'sigmoid':
+      return torch.sigmoid(x)
+    return x
+
+
+class SlimConvTranspose2d(nn.Module):
+  """slim.conv2d_transpose(inputs, num_outputs, [4, 4], stride=2) + BN + ReLU."""
+
+  def __init__(self, cin, cout):
+    super().__init__()
+    self.conv = nn.ConvTranspose2d(cin, cout, 4, stride=2, padding=1,
+                                   bias=False)
+    nn.init.xavier_uniform_(self.conv.weight)
+    self.bn = SlimBatchNorm(cout)
+
+  def forward(self, x):
+    return F.relu(self.bn(self.conv(x)))
+
+
+class SlimFC(nn.Module):
+  """slim.fully_connected + BN + ReLU (the `fc` stack, nets.py:66-67, 290-291)."""
+
+  def __init__(self, cin, cout):
+    super().__init__()
+    self.fc = nn.Linear(cin, cout, bias=False)
+    nn.init.xavier_uniform_(self.fc.weight)
+    self.beta = nn.Parameter(torch.zeros(cout))
+    self.eps = 1e-3
+
+  def forward(self, x):
+    x = self.fc(x)
+    return F.relu(F.batch_norm(x, None, None, None, self.beta, True, 0.0,
+                               self.eps))
+
+
+def set_is_training(module, is_training):
+  """slim's `is_training` switch for every batch norm below `module`."""
+  for m in module.modules():
+    if isinstance(m, SlimBatchNorm):
+      m.is_training = bool(is_training)
+  return module
+
+
+def _nhwc_to_nchw(x):
+  return x.permute(0, 3, 1, 2)
+
+
+def _nchw_to_nhwc(x):
+  return x.permute(0, 2, 3, 1)
+
+
+_ENC = [('cnv1', 32, 7, 2), ('cnv1b', 32, 7, 1), ('cnv2', 64, 5, 2),
+        ('cnv2b', 64, 5, 1), ('cnv3', 128, 3, 2), ('cnv3b', 128, 3, 1),
+        ('cnv4', 256, 3, 2), ('cnv4b', 256, 3, 1), ('cnv5', 512, 3, 2),
+        ('cnv5b', 512, 3, 1), ('cnv6', 512, 3, 2), ('cnv6b', 512, 3, 1),
+        ('cnv7', 512, 3, 2), ('cnv7b', 512, 3, 1)]
+
+
+class _Encoder14(nn.Module):
+  """The 14-conv stride-2 encoder shared by encoder_simple and the U-Net."""
+
+  def __init__(self, cin=3):
+    super().__init__()
+    for name, cout, k, s in _ENC:
+      setattr(self, name, SlimConv2d(cin, cout, k, s))
+      cin = cout
+
+  def forward(self, x):
+    feats = {}
+    for name, _, _, _ in _ENC:
+      x = getattr(self, name)(x)
+      feats[name] = x
+    return feats
+
+
+class EncoderSimple(nn.Module):
+  """encoder_simple (reference nets.py:29-70): B x H x W x C -> B x nz."""
+
+  def __init__(self, nz=1000, in_hw=(256, 256), in_channels=3):
+    super().__init__()
+    self.encoder = _Encoder14(in_channels)
+    flat = 512 * (in_hw[0] // 128) * (in_hw[1] // 128)
+    self.fc = nn.Sequential(SlimFC(flat, 2 * nz), SlimFC(2 * nz, nz),
+                            SlimFC(nz, nz))
+
+  def forward(self, inp_img):
+    feats = self.encoder(_nhwc_to_nchw(inp_img))
+    flat = _nchw_to_nhwc(feats['cnv7b']).reshape(inp_img.shape[0], -1)
+    return self.fc(flat), feats
+
+
+class DecoderSimple(nn.Module):
+  """decoder_simple (reference nets.py:73-114): nconv up-convolution stages
+  upcnv{nc} (4x4 transposed, stride 2) [+ skip concat] + upcnv{nc}b (3x3).
+
+  skip_channels: channel counts of the skip_feat list the caller will pass
+  (skip_feat[-nc + 1] is concatenated at stage nc > 1)."""
+
+  def __init__(self, cin, nconv=7, skip_channels=None):
+    super().__init__()
+    n_filters = [32, 64, 128, 256] + [512] * max(nconv - 4, 0)
+    self.nconv = nconv
+    for nc in range(nconv, 0, -1):
+      n_filt = n_filters[nc - 1]
+      setattr(self, 'upcnv%d' % nc, SlimConvTranspose2d(cin, n_filt))
+      cin_b = n_filt
+      if nc > 1 and skip_channels is not None:
+        cin_b += skip_channels[-nc + 1]
+      setattr(self, 'upcnv%db' % nc, SlimConv2d(cin_b, n_filt, 3, 1))
+      cin = n_filt
+    self.out_channels = cin
+
+  def forward(self, feat, skip_feat=None):
+    if feat.dim() == 2:
+      feat = feat[:, :, None, None]
+    for nc in range(self.nconv, 0, -1):
+      feat = getattr(self, 'upcnv%d' % nc)(feat)
+      if nc > 1 and skip_feat is not None:
+        feat = torch.cat([feat, skip_feat[-nc + 1]], dim=1)
+      feat = getattr(self, 'upcnv%db' % nc)(feat)
+    return feat
+
+
+class PixelwisePredictor(nn.Module):
+  """pixelwise_predictor (reference nets.py:117-161): per layer an own
+  DecoderSimple (n_layerwise_steps stages) and a 3x3 sigmoid head with bias.
+  Returns L x B x H x W x nc (a planar-strided view: no NHWC copy)."""
+
+  def __init__(self, cin, nc=3, n_layers=1, n_layerwise_steps=0,
+               skip_channels=None):
+    super().__init__()
+    self.n_layers = n_layers
+    self.decoders = nn.ModuleList()
+    self.preds = nn.ModuleList()
+    for _ in range(n_layers):
+      dec = DecoderSimple(cin, nconv=n_layerwise_steps,
+                          skip_channels=skip_channels)
+      self.decoders.append(dec)
+      self.preds.append(SlimConv2d(dec.out_channels, nc, 3, 1, batch_norm=False,
+                                   activation='sigmoid'))
+
+  def forward(self, feat, skip_feat=None):
+    preds = []
+    for dec, head in zip(self.decoders, self.preds):
+      preds.append(head(dec(feat, skip_feat)))
+    stacked = torch.stack(preds, dim=0)        # L x B x nc x H x W
+    return stacked.permute(0, 1, 3, 4, 2)      # L x B x H x W x nc (view)
+
+
+class LdiPredictor(nn.Module):
+  """ldi_predictor (reference nets.py:164-208): [textures, masks, disps]."""
+
+  def __init__(self, cin, n_layers=1, n_layerwise_steps=0, skip_channels=None,
+               pred_masks=False):
+    super().__init__()
+    self.pred_masks = pred_masks
+    nc = 3 + 1 + (1 if pred_masks else 0)
+    self.pixelwise_pred = PixelwisePredictor(
+        cin, nc=nc, n_layers=n_layers, n_layerwise_steps=n_layerwise_steps,
+        skip_channels=skip_channels)
+
+  def forward(self, feat, skip_feat=None):
+    pred = self.pixelwise_pred(feat, skip_feat)
+    if self.pred_masks:
+      tex, masks, disps = pred[..., 0:3], pred[..., 3:4], pred[..., 4:5]
+      # the reference applies the sigmoid a second time here (nets.py:202)
+      masks = nn_helpers.enforce_bg_occupied(torch.sigmoid(masks))
+    else:
+      tex, disps = pred[..., 0:3], pred[..., 3:4]
+      masks = None   # all ones (nets.py:204); None = ones for the renderer
+    return [tex, masks, disps]
+
+
+class EncoderDecoderUnet(nn.Module):
+  """encoder_decoder_unet (reference nets.py:244-348).
+
+  forward(inp_img B x H x W x C) -> (feat, feat_dec, skip_feat, end_points):
+  feat_dec = feats_dec[-1 - nl_diff_enc_dec] (NCHW), skip_feat =
+  [cnv6b, cnv5b, cnv4b, cnv3b, cnv2b, cnv1b] (NCHW), feat = bottleneck `fc`
+  features (None unless with_fc).  H and W must be multiples of 128.
+  Decoder stages below the returned one are not built."""
+
+  _DEC = [('7', 512, 'cnv6b'), ('6', 512, 'cnv5b'), ('5', 256, 'cnv4b'),
+          ('4', 128, 'cnv3b'), ('3', 64, 'cnv2b'), ('2', 32, 'cnv1b'),
+          ('1', 32, None)]
+
+  def __init__(self, nz=1000, nl_diff_enc_dec=0, in_channels=3, with_fc=False,
+               in_hw=None):
+    super().__init__()
+    self.encoder = _Encoder14(in_channels)
+    self.nl_diff_enc_dec = nl_diff_enc_dec
+    self.n_dec = 7 - nl_diff_enc_dec
+    skip_c = {'cnv6b': 512, 'cnv5b': 512, 'cnv4b': 256, 'cnv3b': 128,
+              'cnv2b': 64, 'cnv1b': 32}
+    cin = 512
+    for tag, cout, skip in self._DEC[:self.n_dec]:
+      setattr(self, 'upcnv' + tag, SlimConvTranspose2d(cin, cout))
+      setattr(self, 'icnv' + tag,
+              SlimConv2d(cout + (skip_c[skip] if skip else 0), cout, 3, 1))
+      cin = cout
+    self.out_channels = cin
+    self.skip_channels = [512, 512, 256, 128, 64, 32]
+    self.fc = None
+    if with_fc:
+      flat = 512 * (in_hw[0] // 128) * (in_hw[1] // 128)
+      self.fc = nn.Sequential(SlimFC(flat, 2 * nz), SlimFC(2 * nz, nz),
+                              SlimFC(nz, nz))
+
+  def forward(self, inp_img):
+    if inp_img.shape[1] % 128 or inp_img.shape[2] % 128:
+      raise ValueError('encoder_decoder_unet needs H and W divisible by 128')
+    feats = self.encoder(_nhwc_to_nchw(inp_img))
+    feat = None
+    if self.fc is not None:
+      feat = self.fc(_nchw_to_nhwc(feats['cnv7b']).reshape(inp_img.shape[0], -1))
+    x = feats['cnv7b']
+    for tag, _, skip in self._DEC[:self.n_dec]:
+      x = getattr(self, 'upcnv' + tag)(x)
+      if skip is not None:
+        x = torch.cat([x, feats[skip]], dim=1)
+      x = getattr(self, 'icnv' + tag)(x)
+      feats['icnv' + tag] = x
+    skip_feat = [feats[k] for k in ('cnv6b', 'cnv5b', 'cnv4b', 'cnv3b', 'cnv2b',
+                                    'cnv1b')]
+    return feat, x, skip_feat, feats
+
+
+class EncoderDecoderSimple(nn.Module):
+  """encoder_decoder_simple (reference nets.py:211-241): FC bottleneck, then
+  nupconv - nl_diff_enc_dec up-convolutions from a 1x1 map."""
+
+  def __init__(self, nz=1000, nupconv=8, nl_diff_enc_dec=0, in_hw=(256, 256),
+               in_channels=3):
+    super().__init__()
+    self.encoder = EncoderSimple(nz=nz, in_hw=in_hw, in_channels=in_channels)
+    self.decoder = DecoderSimple(nz, nconv=nupconv - nl_diff_enc_dec)
+    self.out_channels = self.decoder.out_channels
+    self.skip_channels = None
+
+  def forward(self, inp_img):
+    feat, enc_int = self.encoder(inp_img)
+    feat_dec = self.decoder(feat)
+    return feat, feat_dec, None, enc_int
+
+
+# Factory functions with the reference's names and keyword arguments.  TF's
+# `reuse=True` (second call shares weights) is expressed in torch by calling
+# the same module instance again.
+def encoder_simple(nz=1000, is_training=True, **kw):
+  return set_is_training(EncoderSimple(nz=nz, **kw), is_training)
+
+
+def decoder_simple(cin, nconv=7, is_training=True, skip_channels=None):
+  return set_is_training(DecoderSimple(cin, nconv, skip_channels), is_training)
+
+
+def pixelwise_predictor(cin, nc=3, n_layers=1, n_layerwise_steps=0,
+                        skip_channels=None, is_training=True):
+  return set_is_training(
+      PixelwisePredictor(cin, nc, n_layers, n_layerwise_steps, skip_channels),
+      is_training)
+
+
+def ldi_predictor(cin, n_layers=1, n_layerwise_steps=0, skip_channels=None,
+                  pred_masks=False, is_training=True):
+  return set_is_training(
+      LdiPredictor(cin, n_layers, n_layerwise_steps, skip_channels, pred_masks),
+      is_training)
+
+
+def encoder_decoder_simple(nz=1000, nupconv=8, is_training=True,
+                           nl_diff_enc_dec=0, **kw):
+  return set_is_training(
+      EncoderDecoderSimple(nz, nupconv, nl_diff_enc_dec, **kw), is_training)
+
+
+def encoder_decoder_unet(nz=1000, is_training=True, nl_diff_enc_dec=0, **kw):
+  return set_is_training(
+      EncoderDecoderUnet(nz, nl_diff_enc_dec, **kw), is_training)
+
+
+def count_parameters(module):
+  return sum(p.numel() for p in module.parameters() if p.requires_grad)

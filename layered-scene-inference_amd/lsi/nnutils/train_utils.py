@@ -1,0 +1,147 @@
+"""Eager training harness (counterpart of the reference's
+lsi/nnutils/train_utils.py `Trainer` template, without TF sessions).
+
+Keeps the reference's template methods (define_data_loader, define_pred_graph
+-> build_model, define_loss_graph -> compute_losses, feed, train, save), its
+default flags, optimiser (Adam lr 1e-4, beta1 0.9: train_utils.py:107-117) and
+checkpoint cadence (`latest` every save_latest_freq, numbered every
+checkpoint_freq, keep 10, auto-resume: train_utils.py:172-232).  Multi-GPU is
+plain data parallelism: one process per GPU, the minibatch sharded, gradients
+all-reduced by DistributedDataParallel over RCCL -- and nothing else (batch norm
+stays per replica, like the reference's single-GPU batch-4 statistics).
+"""
+import glob
+import json
+import os
+import time
+
+import torch
+
+
+def define_default_flags(parser):
+  """The reference's default trainer flags (train_utils.py:31-57)."""
+  a = parser.add_argument
+  a('--checkpoint_dir', default='cachedir/snapshots/')
+  a('--pretrain_name', default='')
+  a('--pretrain_iter', type=int, default=100000)
+  a('--batch_size', type=int, default=2)
+  a('--num_iter', type=int, default=100000)
+  a('--img_height', type=int, default=256)
+  a('--img_width', type=int, default=256)
+  a('--log_freq', type=int, default=5)
+  a('--checkpoint_freq', type=int, default=50000)
+  a('--save_latest_freq', type=int, default=2000)
+  a('--learning_rate', type=float, default=0.0001)
+  a('--beta1', type=float, default=0.9)
+  return parser
+
+
+class Trainer(object):
+  """Template-method trainer; subclasses provide data, model and losses."""
+
+  def __init__(self, opts):
+    self.opts = opts
+    self.world = int(os.environ.get('WORLD_SIZE', '1'))
+    self.rank = int(os.environ.get('RANK', '0'))
+    self.local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    self.dist = None
+    self.device = torch.device('cpu')
+    self.global_step = 0
+
+  # ---- to be provided by the experiment -----------------------------------
+  def define_data_loader(self):
+    raise NotImplementedError
+
+  def build_model(self):
+    """Returns the torch.nn.Module holding every trainable parameter."""
+    raise NotImplementedError
+
+  def compute_losses(self, batch):
+    """Returns (total_loss, dict of named scalar losses)."""
+    raise NotImplementedError
+
+  def feed(self):
+    raise NotImplementedError
+
+  # ---- harness ---------------------------------------------------------------
+  def setup(self, backend=None):
+    opts = self.opts
+    use_gpu = torch.cuda.is_available() and not getattr(opts, 'cpu', False)
+    if use_gpu:
+      torch.cuda.set_device(self.local_rank)
+      self.device = torch.device('cuda', self.local_rank)
+    if self.world > 1:
+      import torch.distributed as dist
+      if not dist.is_initialized():
+        dist.init_process_group(backend or ('nccl' if use_gpu else 'gloo'))
+      self.dist = dist
+    torch.manual_seed(0)  # same initial weights on every rank
+    self.define_data_loader()
+    self.model = self.build_model().to(self.device)
+    if getattr(opts, 'channels_last', False):
+      self.model = self.model.to(memory_format=torch.channels_last)
+    self.train_model = self.model
+    if self.world > 1:
+      from torch.nn.parallel import DistributedDataParallel as DDP
+      self.train_model = DDP(
+          self.model, device_ids=[self.local_rank] if use_gpu else None,
+          bucket_cap_mb=25, gradient_as_bucket_view=True)
+    self.optim = torch.optim.Adam(self.model.parameters(),
+                                  lr=opts.learning_rate,
+                                  betas=(opts.beta1, 0.999), eps=1e-8)
+    self.resume()
+
+  def resume(self):
+    """Latest checkpoint in checkpoint_dir if any (train_utils.py:190-195).
+    Like the reference, only model variables + global_step are saved: Adam's
+    moments restart."""
+    path = os.path.join(self.opts.checkpoint_dir, 'model.latest')
+    if os.path.exists(path):
+      state = torch.load(path, map_location=self.device)
+      self.model.load_state_dict(state['model'])
+      self.global_step = int(state['global_step'])
+
+  def save(self, name):
+    if self.rank != 0:
+      return
+    os.makedirs(self.opts.checkpoint_dir, exist_ok=True)
+    path = os.path.join(self.opts.checkpoint_dir, name)
+    torch.save({'model': self.model.state_dict(),
+                'global_step': self.global_step}, path)
+    numbered = sorted(glob.glob(os.path.join(self.opts.checkpoint_dir,
+                                             'model-*')),
+                      key=os.path.getmtime)
+    for old in numbered[:-10]:  # max_to_keep=10
+      os.remove(old)
+
+  def train_step(self):
+    batch = self.feed()
+    self.optim.zero_grad(set_to_none=True)
+    total, scalars = self.compute_losses(batch)
+    total.backward()
+    self.optim.step()
+    self.global_step += 1
+    return total, scalars
+
+  def train(self, log_file=None):
+    opts = self.opts
+    if not hasattr(self, 'model'):
+      self.setup()
+    t0 = time.time()
+    while self.global_step < opts.num_iter:
+      total, scalars = self.train_step()
+      step = self.global_step
+      if step % opts.log_freq == 0 and self.rank == 0:
+        rec = {'iter': step, 'total_loss': float(total),
+               'time': time.time() - t0}
+        rec.update({k: float(v) for k, v in scalars.items()})
+        line = json.dumps(rec)
+        print(line, flush=True)
+        if log_file:
+          with open(log_file, 'a') as f:
+            f.write(line + '\n')
+      if step % opts.save_latest_freq == 0:
+        self.save('model.latest')
+      if step % opts.checkpoint_freq == 0:
+        self.save('model-%d' % step)
+    return self

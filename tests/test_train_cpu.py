@@ -1,0 +1,148 @@
+"""CNN mirror (lsi.nnutils.nets), eager trainer and DDP wiring on CPU.
+
+The splat losses need the GPU (no CPU fallback), so the CPU runs switch them off
+(--indep_splat_wt 0 --compose_splat_wt 0) and exercise everything else: the
+U-Net + LDI heads, the self-consistency / smoothness / ordering losses, Adam,
+checkpoint cadence + resume, and gradient all-reduce over two gloo ranks."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import PKG
+
+sys.path.insert(0, PKG)
+from lsi.nnutils import nets  # noqa: E402
+
+
+def test_parameter_counts_match_the_reference_graph():
+  # live parameters 37.65 M (L=2) and 39.07 M (L=4)
+  for nl, want in ((2, 37645736), (4, 39072304)):
+    unet = nets.encoder_decoder_unet(nl_diff_enc_dec=3)
+    head = nets.ldi_predictor(unet.out_channels, n_layers=nl,
+                              n_layerwise_steps=3,
+                              skip_channels=unet.skip_channels)
+    assert nets.count_parameters(unet) + nets.count_parameters(head) == want
+  assert unet.out_channels == 128          # icnv4 (nets.py:348 with nl_diff=3)
+
+
+def test_tf_same_padding_and_slim_batch_norm():
+  torch.manual_seed(0)
+  # stride-2 7x7: TF SAME pads 2 before / 3 after on an even input
+  conv = nets.SlimConv2d(1, 1, 7, 2, batch_norm=False, activation=None)
+  x = torch.zeros(1, 1, 8, 8)
+  x[0, 0, 0, 0] = 1.0
+  y = conv(x)
+  assert y.shape == (1, 1, 4, 4)
+  w = conv.conv.weight[0, 0]
+  # output (0,0) sees input (0,0) through kernel tap (2,2); output (1,1)
+  # sees it through tap (0,0)
+  assert torch.allclose(y[0, 0, 0, 0], w[2, 2] + conv.conv.bias[0])
+  assert torch.allclose(y[0, 0, 1, 1], w[0, 0] + conv.conv.bias[0])
+  assert nets._same_pad(8, 5, 2) == (1, 2) and nets._same_pad(8, 3, 2) == (0, 1)
+  assert nets._same_pad(8, 3, 1) == (1, 1) and nets._same_pad(7, 3, 2) == (1, 1)
+  # batch norm: batch statistics, beta only, eps 1e-3
+  bn = nets.SlimBatchNorm(3)
+  assert [n for n, _ in bn.named_parameters()] == ['beta']
+  z = torch.randn(4, 3, 5, 5) * 3 + 2
+  out = bn(z)
+  assert abs(float(out.mean())) < 1e-5
+  assert abs(float(out.var(unbiased=False)) - 1) < 1e-2
+  up = nets.SlimConvTranspose2d(2, 3)
+  assert up(torch.randn(1, 2, 4, 6)).shape == (1, 3, 8, 12)
+
+
+def test_unet_and_heads_shapes_and_layout():
+  torch.manual_seed(0)
+  unet = nets.encoder_decoder_unet(nl_diff_enc_dec=3)
+  head = nets.ldi_predictor(unet.out_channels, n_layers=2, n_layerwise_steps=3,
+                            skip_channels=unet.skip_channels)
+  imgs = torch.rand(1, 128, 128, 3)
+  feat, feat_dec, skip_feat, end_points = unet(imgs)
+  assert feat is None and feat_dec.shape == (1, 128, 16, 16)
+  assert [s.shape[1] for s in skip_feat] == [512, 512, 256, 128, 64, 32]
+  assert end_points['cnv7b'].shape == (1, 512, 1, 1)
+  tex, masks, disps = head(feat_dec, skip_feat)
+  assert tex.shape == (2, 1, 128, 128, 3) and disps.shape == (2, 1, 128, 128, 1)
+  assert masks is None
+  assert tex.stride()[3] == 1 and tex.stride()[4] == 128 * 128   # planar view
+  assert float(tex.min()) >= 0 and float(tex.max()) <= 1          # sigmoid head
+  with pytest.raises(ValueError):
+    unet(torch.rand(1, 64, 64, 3))       # Appendix A.17: H, W multiples of 128
+  masked = nets.ldi_predictor(128, n_layers=2, n_layerwise_steps=3,
+                              skip_channels=unet.skip_channels, pred_masks=True)
+  _, m, _ = masked(feat_dec, skip_feat)
+  assert float(m[-1].min()) == 1.0        # background layer fully occupied
+
+
+def _opts(tmpdir, **kw):
+  sys.path.insert(0, PKG)
+  import ldi_enc_dec as script
+  args = ['--dataset', 'kitti', '--batch_size', '1', '--n_layers', '2',
+          '--img_height', '128', '--img_width', '128', '--num_iter', '2',
+          '--indep_splat_wt', '0', '--compose_splat_wt', '0', '--cpu', 'true',
+          '--log_freq', '1', '--save_latest_freq', '2',
+          '--checkpoint_dir', str(tmpdir)]
+  for k, v in kw.items():
+    args += ['--' + k, str(v)]
+  return script, script.apply_dataset_overrides(script.build_parser().parse_args(args))
+
+
+def test_eager_trainer_steps_saves_and_resumes(tmp_path):
+  script, opts = _opts(tmp_path)
+  assert opts.bg_layer_disp == 1e-3 and opts.max_disp == 0.4   # kitti overrides
+  tr = script.Trainer(opts)
+  tr.setup()
+  before = [p.detach().clone() for p in tr.model.parameters()]
+  total, scalars = tr.train_step()
+  assert set(scalars) == {'self_cons_loss', 'compose_splat_loss',
+                          'indep_splat_loss', 'incr_depth_loss',
+                          'disp_smoothness_loss', 'total_loss'}
+  assert np.isfinite(float(total))
+  assert all(p.grad is not None for p in tr.model.parameters())  # no dead params
+  assert any(not torch.equal(a, b) for a, b in zip(before, tr.model.parameters()))
+  tr.train()
+  assert tr.global_step == 2
+  assert os.path.exists(os.path.join(opts.checkpoint_dir, 'model.latest'))
+  tr2 = script.Trainer(opts)
+  tr2.setup()
+  assert tr2.global_step == 2            # auto-resume (train_utils.py:190-195)
+  for a, b in zip(tr.model.parameters(), tr2.model.parameters()):
+    assert torch.equal(a, b)
+
+
+def _free_port():
+  s = socket.socket()
+  s.bind(('127.0.0.1', 0))
+  port = s.getsockname()[1]
+  s.close()
+  return port
+
+
+def _ddp_worker(rank, world, port, tmpdir, out):
+  os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                    RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+  torch.set_num_threads(2)
+  script, opts = _opts(tmpdir, num_iter=1)
+  tr = script.Trainer(opts)
+  tr.setup(backend='gloo')
+  tr.train_step()
+  flat = torch.cat([p.detach().reshape(-1) for p in tr.model.parameters()])
+  out[rank] = (float(flat.double().sum()), float(flat.abs().double().sum()),
+               float(tr.feed()[0].sum()))
+  tr.dist.destroy_process_group()
+
+
+def test_ddp_gradient_allreduce_two_gloo_ranks(tmp_path):
+  world = 2
+  mgr = mp.Manager()
+  out = mgr.dict()
+  mp.spawn(_ddp_worker, args=(world, _free_port(), str(tmp_path), out),
+           nprocs=world, join=True)
+  # different data shards, identical parameters after the all-reduced step
+  assert out[0][2] != out[1][2]
+  assert out[0][0] == out[1][0] and out[0][1] == out[1][1]
