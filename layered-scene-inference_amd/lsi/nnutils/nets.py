@@ -43,20 +43,28 @@ class SlimBatchNorm(nn.Module):
   def __init__(self, channels, eps=1e-3):
     super().__init__()
     self.beta = nn.Parameter(torch.zeros(channels))
+    # constant gamma = 1 (slim: scale=False); a buffer, never trained.  Passed
+    # explicitly because MIOpen's batch-norm backward needs a weight tensor.
+    self.register_buffer('gamma', torch.ones(channels))
     self.register_buffer('moving_mean', torch.zeros(channels))
     self.register_buffer('moving_variance', torch.ones(channels))
     self.eps = eps
     self.is_training = True
 
   def forward(self, x):
+    # statistics in fp32 also under bf16 autocast (the reference is fp32, and
+    # MIOpen's bf16 batch norm crashed on small bottleneck maps)
+    x = x.float()
     if self.is_training:
-      if x.numel() // x.shape[1] > 1:
-        return F.batch_norm(x, None, None, None, self.beta, True, 0.0, self.eps)
-      # one value per channel (1x1 bottleneck at batch 1): TF normalises with
-      # variance 0, torch's fused kernel refuses -- same arithmetic by hand
+      if x.numel() // x.shape[1] > 64:
+        return F.batch_norm(x, None, None, self.gamma, self.beta, True, 0.0,
+                            self.eps)
+      # few values per channel (the 1x1 .. 2x6 bottleneck maps; with one value
+      # TF normalises with variance 0 and torch's fused kernel refuses): the
+      # same arithmetic by hand
       var, mean = torch.var_mean(x, dim=(0, 2, 3), unbiased=False, keepdim=True)
       return (x - mean) * torch.rsqrt(var + self.eps) + self.beta.view(1, -1, 1, 1)
-    return F.batch_norm(x, self.moving_mean, self.moving_variance, None,
+    return F.batch_norm(x, self.moving_mean, self.moving_variance, self.gamma,
                         self.beta, False, 0.0, self.eps)
 
 
@@ -113,11 +121,12 @@ class SlimFC(nn.Module):
     self.fc = nn.Linear(cin, cout, bias=False)
     nn.init.xavier_uniform_(self.fc.weight)
     self.beta = nn.Parameter(torch.zeros(cout))
+    self.register_buffer('gamma', torch.ones(cout))
     self.eps = 1e-3
 
   def forward(self, x):
     x = self.fc(x)
-    return F.relu(F.batch_norm(x, None, None, None, self.beta, True, 0.0,
+    return F.relu(F.batch_norm(x, None, None, self.gamma, self.beta, True, 0.0,
                                self.eps))
 
 
