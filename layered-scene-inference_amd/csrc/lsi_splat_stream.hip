@@ -200,8 +200,7 @@ __global__ __launch_bounds__(1024) void splat_stream_kernel(SplatArgs a,
   };
 
   // ---- one-time init ------------------------------------------------------
-  for (int i = tid; i < NWIN * WMAX; i += T)
-    rb_all[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  // (task windows are zeroed by their owning wave when the task starts)
   for (int i = tid; i < NW * WMAX; i += T) cnt_all[i] = 0u;
   for (int i = tid; i < R * Wt * 4; i += T) extras[i] = 0.0f;
   if (tid == 0) { yrange[0] = d.H; yrange[1] = -1; }
@@ -268,13 +267,21 @@ __global__ __launch_bounds__(1024) void splat_stream_kernel(SplatArgs a,
             // window hint: cells reachable for d in [0, max_disp] on the segment
             const int xe = min(xs + SEG, W);
             float lo = __builtin_inff(), hi = -__builtin_inff();
+            auto x_of = [&](int xx, float dd) {
+              const float q0 = mrow(m, 0, (float)xx + 0.5f, py, dd);
+              return (SIMPLE ? q0 : div_rn(q0, nden)) * s - 0.5f;
+            };
+            if (m[0] > 0.0f) {  // X increases with x; with d by the sign of m03
+              const bool neg = m[3] < 0.0f;
+              lo = x_of(xs, neg ? max_disp : 0.0f);
+              hi = x_of(xe - 1, neg ? 0.0f : max_disp);
+            } else {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-              const float px = (float)((c & 1) ? (xe - 1) : xs) + 0.5f;
-              const float dd = (c & 2) ? max_disp : 0.0f;
-              const float q0 = mrow(m, 0, px, py, dd);
-              const float X = (SIMPLE ? q0 : div_rn(q0, nden)) * s - 0.5f;
-              lo = fminf(lo, X); hi = fmaxf(hi, X);
+              for (int c = 0; c < 4; ++c) {
+                const float X = x_of((c & 1) ? (xe - 1) : xs,
+                                     (c & 2) ? max_disp : 0.0f);
+                lo = fminf(lo, X); hi = fmaxf(hi, X);
+              }
             }
             if (finite_f(lo) && finite_f(hi) && fabsf(lo) < 1.0e7f &&
                 fabsf(hi) < 1.0e7f) {
@@ -291,7 +298,7 @@ __global__ __launch_bounds__(1024) void splat_stream_kernel(SplatArgs a,
         if (!tvalid) continue;
         LSI_TSTAMP();
 
-        float4* rb = rb_all + slot * WMAX;  // zero here
+        float4* rb = rb_all + slot * WMAX;
         const int x = xs + 4 * lane;
         const bool inrange = x < W;
         const float py = (float)y + 0.5f;
@@ -479,6 +486,11 @@ __global__ __launch_bounds__(1024) void splat_stream_kernel(SplatArgs a,
         nxt.m4 = make_float4(1.f, 1.f, 1.f, 1.f);
         const int l_end = l_begin + Lp;
         load_layer(l_begin, nxt);
+        // zero this task's window while the first loads are in flight (same
+        // wave, in-order LDS: no barrier needed before its own RMWs)
+        for (int c = lane; c < ti.wwin; c += 64)
+          rb[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        LSI_COMPILER_FENCE();
         for (int l = l_begin; l < l_end; ++l) {
           const PxData cur = nxt;
           if (l + 1 < l_end) load_layer(l + 1, nxt);
@@ -545,17 +557,6 @@ __global__ __launch_bounds__(1024) void splat_stream_kernel(SplatArgs a,
       LSI_TSTAMP();
       __syncthreads();
       LSI_TSTAMP();
-      // re-zero this wave's windows for the next step / pass
-      if (step + 1 < nstep || pass + 1 < npass) {
-        for (int k = 0; k < TPW; ++k) {
-          const int slot = k * NW + wave;
-          const int ww = tinfo[slot].wwin;
-          float4* rbz = rb_all + slot * WMAX;
-          for (int c = lane; c < ww; c += 64)
-            rbz[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        __syncthreads();
-      }
     }
 
     // ================= epilogue for this pass ===============================
