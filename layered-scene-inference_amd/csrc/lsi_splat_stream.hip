@@ -51,7 +51,7 @@ namespace {
 
 constexpr int SEG = 256;   // source pixels per task (64 lanes x 4)
 constexpr int MAXU = 3;    // target-cell units (64 cells) owned per wave
-constexpr int MAXNW = 16;
+constexpr int MAXNW = 12;
 // lsi_stream_ok's return value: window cells, plus this bit when every batch
 // element has normaliser == 1 and M row 3 == (0,0,0,1) (division-free kernel)
 constexpr int LSI_STREAM_SIMPLE_BIT = 1 << 20;
@@ -118,7 +118,7 @@ __device__ __forceinline__ void slow_corners(float* extras, float4 V, float X,
 // SIMPLE: the normaliser is exactly 1 and row 3 of M is (0,0,0,1) for every
 // batch element (rectified stereo): u = q0 and D = d with no division.
 template <int LAYOUT, bool SIMPLE>  // LAYOUT 0: channels-last RGB, 1: planar
-__global__ __launch_bounds__(1024) void splat_stream_kernel(SplatArgs a,
+__global__ __launch_bounds__(768) void splat_stream_kernel(SplatArgs a,
                                                            StreamCfg cfg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const LsiSplatDesc& d = a.d;
