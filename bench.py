@@ -169,6 +169,39 @@ def reduce_max(values, dist, device):
   return [float(v) for v in t]
 
 
+def time_backward(r, iters=50):
+  """Average time of lsi_splat_bwd (gradient w.r.t. textures and disparities of
+  the same launch) on the renderer's inputs, HIP events on the launch stream."""
+  lib = _C.lib()
+  dev = r.dev
+  nl, b, h, w, _ = r.tex.shape
+  g_img = torch.rand_like(r.img)
+  g_tex = torch.empty((nl, b, h, w, 3), device=dev)
+  g_disp = torch.empty((nl, b, h, w, 1), device=dev)
+  ws_bytes = int(lib.lsi_splat_bwd_workspace_bytes(ctypes.byref(r.desc)))
+  ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+
+  def launch():
+    rc = lib.lsi_splat_bwd(ctypes.byref(r.desc), _C.ptr(r.tex), _C.ptr(r.disp),
+                           None, _C.ptr(r.mat), _C.ptr(r.img), _C.ptr(r.wts),
+                           _C.ptr(g_img), None, _C.ptr(g_tex), _C.ptr(g_disp),
+                           None, _C.ptr(ws), ws_bytes, _C.stream_ptr(dev))
+    if rc != 0:
+      _C.check(rc, 'lsi_splat_bwd')
+
+  for _ in range(5):
+    launch()
+  e0 = torch.cuda.Event(enable_timing=True)
+  e1 = torch.cuda.Event(enable_timing=True)
+  torch.cuda.synchronize()
+  e0.record()
+  for _ in range(iters):
+    launch()
+  e1.record()
+  torch.cuda.synchronize()
+  return e0.elapsed_time(e1) * 1e3 / iters
+
+
 def cpu_baseline(nl, b, h, w, cams, max_disp, bg, budget_s=15.0):
   """The plain-C oracle port timed on this host's cores, on a bounded sample of
   the same workload (same shapes/cameras; batch capped at 2)."""
@@ -308,6 +341,14 @@ def main():
             'avg_launch_us': kern_s * 1e6,
         },
     }
+    if world == 1:
+      bwd_us = time_backward(r)
+      out['extra'] = {
+          'backward_us_per_launch': bwd_us,
+          'fwd_bwd_views_per_s': b_local / ((kern_s * 1e6 + bwd_us) * 1e-6),
+          'note': 'lsi_splat_bwd (gather kernel, eager launches) on the same '
+                  'inputs; not part of `value`',
+      }
     if world == 1 and not args.no_cpu_baseline:
       out['cpu_baseline'] = cpu_baseline(nl, b_local, h, w, cams, max_disp, bg)
     print(json.dumps(out))

@@ -87,6 +87,9 @@ class SlimConv2d(nn.Module):
   def forward(self, x):
     ph = _same_pad(x.shape[2], self.k, self.stride)
     pw = _same_pad(x.shape[3], self.k, self.stride)
+    # explicit padding also for the symmetric (stride-1) case: with implicit
+    # padding MIOpen (ROCm 7.2) fell back to naive kernels for several bf16
+    # layer shapes (66 ms vs 39 ms per step, tools/train_bench.py)
     if ph[0] or ph[1] or pw[0] or pw[1]:
       x = F.pad(x, (pw[0], pw[1], ph[0], ph[1]))
     x = self.conv(x)
