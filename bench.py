@@ -252,9 +252,12 @@ def main():
     raise SystemExit('launch with torch.distributed.run --nproc-per-node %d'
                      % args.gpus)
   dist = None
-  if world > 1:
+  if world > 1 or 'RANK' in os.environ:  # launched by torch.distributed.run
     import torch.distributed as dist
-    dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29500')
+    dist.init_process_group('nccl', rank=rank, world_size=world,
+                            device_id=torch.device('cuda', local_rank))
   torch.cuda.set_device(local_rank)
   dev = torch.device('cuda', local_rank)
 
