@@ -53,15 +53,39 @@ def bilinear(imgs, coords, compose=True):
   Args:
     imgs: B x H_s x W_s x C
     coords: B x H_t x W_t x 2, source pixel to copy from
-    compose: only True is implemented (the reference's 4-tap/4-weight variant
-      has no caller: `grep compose=False` finds none).
+    compose: False returns ([4 masked taps], [4 weights]) like the reference.
   Returns:
     B x H_t x W_t x C; coordinates outside the image sample 0.
   """
   if not compose:
-    raise NotImplementedError('bilinear(compose=False) has no caller in the '
-                              'reference and is not implemented')
+    return _bilinear_taps(imgs, coords)
   return _Bilinear.apply(imgs, coords)
+
+
+def _bilinear_taps(imgs, coords):
+  """compose=False (reference sampling.py:124-130): the four border-masked taps
+  and the four un-masked weights, tap order (x0,y0), (x0,y1), (x1,y0), (x1,y1).
+  No caller in the reference uses this form; it is a plain torch gather."""
+  b, hs, ws, c = imgs.shape
+  x = coords[..., 0:1] - 0.5
+  y = coords[..., 1:2] - 0.5
+  x0 = torch.floor(x); x1 = x0 + 1; y0 = torch.floor(y); y1 = y0 + 1
+  x0s, x1s = x0.clamp(0, ws - 1), x1.clamp(0, ws - 1)
+  y0s, y1s = y0.clamp(0, hs - 1), y1.clamp(0, hs - 1)
+  dt = imgs.dtype
+  vx0, vx1 = (x0 == x0s).to(dt), (x1 == x1s).to(dt)
+  vy0, vy1 = (y0 == y0s).to(dt), (y1 == y1s).to(dt)
+  flat = imgs.reshape(b, hs * ws, c)
+
+  def tap(xs_, ys_):
+    idx = (xs_ + ys_ * ws).long().reshape(b, -1, 1).expand(-1, -1, c)
+    return torch.gather(flat, 1, idx).reshape(coords.shape[:-1] + (c,))
+
+  ims = [vx0 * vy0 * tap(x0s, y0s), vx0 * vy1 * tap(x0s, y1s),
+         vx1 * vy0 * tap(x1s, y0s), vx1 * vy1 * tap(x1s, y1s)]
+  wts = [(x1 - x) * (y1 - y), (x1 - x) * (y - y0), (x - x0) * (y1 - y),
+         (x - x0) * (y - y0)]
+  return ims, wts
 
 
 def bilinear_wrapper(imgs, coords, compose=True):
@@ -72,7 +96,11 @@ def bilinear_wrapper(imgs, coords, compose=True):
   init_dims = list(imgs.shape[:-3])
   out = bilinear(imgs.reshape([-1] + list(imgs.shape[-3:])),
                  coords.reshape([-1] + list(coords.shape[-3:])), compose=compose)
-  return out.reshape(init_dims + list(out.shape[-3:]))
+  if compose:
+    return out.reshape(init_dims + list(out.shape[-3:]))
+  ims, wts = out
+  return ([t.reshape(init_dims + list(t.shape[-3:])) for t in ims],
+          [t.reshape(init_dims + list(t.shape[-3:])) for t in wts])
 
 
 class _Splat(torch.autograd.Function):

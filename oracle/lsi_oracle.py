@@ -296,6 +296,36 @@ def bilinear(imgs, coords):
   return out.astype(np.float32)
 
 
+def bilinear_taps(imgs, coords):
+  """sampling.py:41-132 with compose=False: the four border-masked taps
+  (order 00, 01, 10, 11 = (x0,y0), (x0,y1), (x1,y0), (x1,y1)) and the four
+  un-masked weights."""
+  imgs, coords = _f32(imgs), _f32(coords)
+  b, hs, ws, c = imgs.shape
+  x = coords[..., 0:1] - F(0.5)
+  y = coords[..., 1:2] - F(0.5)
+  x0 = np.floor(x); x1 = x0 + F(1); y0 = np.floor(y); y1 = y0 + F(1)
+  x_max, y_max = F(ws - 1), F(hs - 1)
+  x0s = np.minimum(np.maximum(x0, F(0)), x_max)
+  x1s = np.minimum(np.maximum(x1, F(0)), x_max)
+  y0s = np.minimum(np.maximum(y0, F(0)), y_max)
+  y1s = np.minimum(np.maximum(y1, F(0)), y_max)
+  vx0 = (x0 == x0s).astype(np.float32); vx1 = (x1 == x1s).astype(np.float32)
+  vy0 = (y0 == y0s).astype(np.float32); vy1 = (y1 == y1s).astype(np.float32)
+  flat = imgs.reshape(b, hs * ws, c)
+  bidx = np.arange(b).reshape((b,) + (1,) * (coords.ndim - 2))
+
+  def tap(xs_, ys_):
+    idx = np.trunc(xs_ + ys_ * F(ws)).astype(np.int64)[..., 0]
+    return flat[bidx, idx]
+
+  ims = [vx0 * vy0 * tap(x0s, y0s), vx0 * vy1 * tap(x0s, y1s),
+         vx1 * vy0 * tap(x1s, y0s), vx1 * vy1 * tap(x1s, y1s)]
+  wts = [(x1 - x) * (y1 - y), (x1 - x) * (y - y0), (x - x0) * (y1 - y),
+         (x - x0) * (y - y0)]
+  return ims, wts
+
+
 def bilinear_wrapper(imgs, coords):
   """sampling.py:135-168 -- arbitrary leading dims."""
   imgs, coords = _f32(imgs), _f32(coords)

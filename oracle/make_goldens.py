@@ -234,6 +234,9 @@ def make_bilinear(mods):
   imgs5 = rs.rand(2, 3, 6, 7, 4).astype(np.float32)
   coords5 = np.stack([rs.uniform(-1, 8, (2, 3, 5, 4)),
                       rs.uniform(-1, 7, (2, 3, 5, 4))], -1).astype(np.float32)
+  ims4, wts4 = samp.bilinear(T(imgs), T(coords), compose=False)
+  out['taps_ims'] = np.stack([t.a for t in ims4])
+  out['taps_wts'] = np.stack([t.a for t in wts4])
   out['imgs5'], out['coords5'] = imgs5, coords5
   out['out5'] = samp.bilinear_wrapper(T(imgs5), T(coords5)).a
   np.savez_compressed(os.path.join(OUT, 'bilinear.npz'), **out)

@@ -112,3 +112,14 @@ def test_view_synthesis_loss():
   d = torch.rand(3, 1, 4, 4, 1, requires_grad=True)
   loss.decreasing_disp_loss(d).backward()
   assert float(d.grad[0].abs().sum()) == 0
+
+
+def test_bilinear_taps_variant_on_cpu():
+  # compose=False is a plain torch gather (no HIP kernel): runs anywhere
+  from lsi.geometry import sampling
+  g = golden('bilinear.npz')
+  ims, wts = sampling.bilinear(T(g['imgs']), T(g['coords']), compose=False)
+  np.testing.assert_allclose(torch.stack(ims).numpy(), g['taps_ims'], rtol=0,
+                             atol=0)
+  np.testing.assert_allclose(torch.stack(wts).numpy(), g['taps_wts'], rtol=1e-6,
+                             atol=1e-7)

@@ -102,6 +102,9 @@ def test_bilinear_and_wrapper():
   g = golden('bilinear.npz')
   assert rel_err(O.bilinear(g['imgs'], g['coords']), g['out']) <= 1e-6
   assert rel_err(O.bilinear_wrapper(g['imgs5'], g['coords5']), g['out5']) <= 1e-6
+  ims, wts = O.bilinear_taps(g['imgs'], g['coords'])
+  np.testing.assert_array_equal(np.stack(ims), g['taps_ims'])
+  np.testing.assert_array_equal(np.stack(wts), g['taps_wts'])
 
 
 def test_layers_and_homography():

@@ -83,8 +83,9 @@ def test_bilinear_goldens(dev):
   got5 = sampling.bilinear_wrapper(T(g['imgs5'], dev), T(g['coords5'], dev))
   np.testing.assert_allclose(got5.cpu().numpy(), g['out5'], rtol=1e-6,
                              atol=1e-7)
-  with pytest.raises(NotImplementedError):
-    sampling.bilinear(T(g['imgs'], dev), T(g['coords'], dev), compose=False)
+  ims, wts = sampling.bilinear(T(g['imgs'], dev), T(g['coords'], dev),
+                               compose=False)
+  np.testing.assert_array_equal(torch.stack(ims).cpu().numpy(), g['taps_ims'])
 
 
 def test_bilinear_and_splat_gradients(dev):
