@@ -165,3 +165,38 @@ def test_disocclusion_mask_on_gpu(dev):
   # threshold to flip under a different matmul rounding
   mism = float((got.cpu().numpy() != g['mask']).mean())
   assert mism <= 0.005, mism
+
+
+def test_eval_metrics_against_numpy_restatement(dev):
+  """Masked L1 / PSNR / disparity metrics of ldi_pred_eval.py:297-548 on the
+  KITTI-like golden LDI, vs the same arithmetic on the oracle's outputs."""
+  import types
+  from lsi.nnutils import eval_metrics, helpers
+  g = golden('fs_kitti_L2_s05.npz')
+  s, bg, md, zb = [float(v) for v in g['params']]
+  opts = types.SimpleNamespace(trg_splat_downsampling=s, zbuf_scale=zb,
+                               bg_layer_disp=bg, max_disp=md,
+                               splat_bdry_ignore=0.1)
+  nl, b, h, w, _ = g['tex'].shape
+  rs = np.random.RandomState(0)
+  target = rs.rand(b, h, w, 3).astype(np.float32)
+  gt_disp = (0.4 * rs.rand(b, h, w, 1)).astype(np.float32)
+  ldi_src = [T(g[k], dev) for k in ('tex', 'mask', 'disp')]
+  got = eval_metrics.view_synthesis_metrics(
+      ldi_src, helpers.pixel_coords(b, h, w), torch.tensor(g['k_s']),
+      torch.tensor(g['k_t']), torch.tensor(g['rot']), torch.tensor(g['t']),
+      T(target, dev), opts, gt_disp_trg=T(gt_disp, dev))
+  ht, wt = int(h * s), int(w * s)
+  tds = O.area_downsample(target, ht, wt)
+  centre = np.zeros((b, ht, wt), np.float32)
+  x_min, y_min = O.py2_round(wt * 0.1), O.py2_round(ht * 0.1)
+  centre[:, y_min:ht - y_min, x_min:wt - x_min] = 1
+  pw = np.mean(np.abs(tds - g['compose_img'][0]), axis=3) * centre
+  assert abs(float(got['compose_splat_loss'][0]) - pw.sum()) < 1e-3 * pw.sum()
+  assert float(got['compose_splat_loss'][1]) == centre.sum()
+  gds = O.area_downsample(gt_disp, ht, wt)
+  pd = np.mean(np.abs(gds - g['compose_disp'][0]), axis=3) * centre
+  assert abs(float(got['depth_splat_loss'][0]) - pd.sum()) < 1e-3 * pd.sum()
+  agg = eval_metrics.aggregate([got, got])
+  assert abs(agg['compose_splat_loss'] - pw.sum() / centre.sum()) < 1e-5
+  assert 0 < agg['psnr'] < 60
