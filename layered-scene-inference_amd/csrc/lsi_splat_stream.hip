@@ -56,16 +56,27 @@ constexpr int MAXNW = 12;
 // element has normaliser == 1 and M row 3 == (0,0,0,1) (division-free kernel)
 constexpr int LSI_STREAM_SIMPLE_BIT = 1 << 20;
 
-struct TaskInfo {
+// Per-task table entries, filled for a whole chunk of tasks at once by all
+// threads (one task per thread) so that no wave recomputes row geometry.
+struct __attribute__((aligned(16))) TaskA {  // what the merge needs
   int row0;        // target row of the task's top contribution, band-relative
-  float wy0, wy1;  // row weights incl. border masks (sampling.py:210-211)
-  int wlo, wwin;   // window: absolute first cell, number of cells
+  float wy0, wy1;  // row weights incl. border masks (sampling.py:210-211);
+                   // both 0: the task has nothing to do
+  int win;         // window: absolute first cell | number of cells << 16
+};
+struct __attribute__((aligned(16))) TaskB {
+  float nden, rn;  // normaliser n'(y) and its reciprocal
+  int y, xs;       // source row, first source pixel of the segment
 };
 
 struct StreamCfg {
   int R;      // target rows per workgroup
   int wmax;   // window cells per task
   int tpw;    // tasks (windows) per wave per step
+  int cap;    // task-table entries, a multiple of nw * tpw
+  int nb;     // 64-cell units per target row
+  int steps_per_chunk;  // cap / (nw * tpw)
+  float inv_nb, inv_nwin, inv_gx;  // reciprocals for division-free indexing
 };
 
 #define LSI_COMPILER_FENCE() asm volatile("" ::: "memory")
@@ -86,6 +97,15 @@ __device__ __forceinline__ f2 exp_accurate2(f2 a) {
   return o;
 }
 
+// n / d for 0 <= n < 2^22, d > 0, rcp = fl(1/d): no integer-division sequence
+__device__ __forceinline__ int div_small(int n, int d, float rcp) {
+  int q = (int)((float)n * rcp);
+  const int r = n - q * d;
+  q += (r >= d) ? 1 : 0;
+  q -= (r < 0) ? 1 : 0;
+  return q;
+}
+
 // accumulations are not index-critical: fused multiply-add
 __device__ __forceinline__ float4 f4_fma(float4 t, float4 v, float w) {
   t.x = __fmaf_rn(v.x, w, t.x); t.y = __fmaf_rn(v.y, w, t.y);
@@ -93,25 +113,31 @@ __device__ __forceinline__ float4 f4_fma(float4 t, float4 v, float w) {
   return t;
 }
 
-// Exact slow path for one source pixel (rare): recomputes the reference's
-// x-axis footprint with clipped cells and adds the up-to-four corners with
-// their exact weights clamp(wx*wy) into the extras tile by fp32 LDS atomics.
-__device__ __forceinline__ void slow_corners(float* extras, float4 V, float X,
-                                             float xmax, float wy0, float wy1,
-                                             int row0, int rows, int Wt) {
-  const Axis ax = splat_axis(X, xmax);
-  const float wc[4] = {clamp_small(ax.w0 * wy0), clamp_small(ax.w1 * wy0),
-                       clamp_small(ax.w0 * wy1), clamp_small(ax.w1 * wy1)};
-  const int cx[2] = {(int)ax.c0s, (int)ax.c1s};
+// Exact slow path for one source pixel (rare): the reference's x-axis
+// footprint with clipped cells (sampling.py:193-211) from floor(X) and the two
+// un-masked side weights; the up-to-four corners are added with their exact
+// weights clamp(wx*wy) to the extras tile by fp32 LDS atomics.  Selects, not
+// multiplies, apply the masks: non-finite inputs add nothing.
+__device__ __forceinline__ void slow_corners(float* extras, float4 V, float x0,
+                                             float gx, float fx, float xmax,
+                                             float wy0, float wy1, int row0,
+                                             int rows, int Wt) {
+  const float x1 = x0 + 1.0f;
+  const float x0s = fminf(fmaxf(x0, 0.0f), xmax);
+  const float x1s = fminf(fmaxf(x1, 0.0f), xmax);
+  const float wx[2] = {(x0 == x0s) ? gx : 0.0f, (x1 == x1s) ? fx : 0.0f};
+  const int cx[2] = {(int)x0s, (int)x1s};
+  const float wy[2] = {wy0, wy1};
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int r = row0 + (k >> 1);
-    if (wc[k] == 0.0f || r < 0 || r >= rows) continue;
+    const float c = wx[k & 1] * wy[k >> 1];
+    if (!(c > 1.0e-3f) || r < 0 || r >= rows) continue;
     float* e = extras + ((size_t)r * Wt + cx[k & 1]) * 4;
-    atomic_add_f32(e + 0, V.x * wc[k]);
-    atomic_add_f32(e + 1, V.y * wc[k]);
-    atomic_add_f32(e + 2, V.z * wc[k]);
-    atomic_add_f32(e + 3, V.w * wc[k]);
+    atomic_add_f32(e + 0, V.x * c);
+    atomic_add_f32(e + 1, V.y * c);
+    atomic_add_f32(e + 2, V.z * c);
+    atomic_add_f32(e + 3, V.w * c);
   }
 }
 
@@ -138,19 +164,26 @@ __global__ __launch_bounds__(768) void splat_stream_kernel(SplatArgs a,
     const unsigned base =
         xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q;
     const unsigned id = base + (lin >> 3);
-    band = id % gridDim.x;
-    b = id / gridDim.x;
+    if (nwg < (1u << 22)) {
+      b = div_small((int)id, (int)gridDim.x, cfg.inv_gx);
+      band = (int)id - b * (int)gridDim.x;
+    } else {
+      band = id % gridDim.x;
+      b = id / gridDim.x;
+    }
   }
   const int row0 = band * R;
   const int rows = min(R, Ht - row0);
-  const int NB = (Wt + 63) >> 6;
+  const int NB = cfg.nb;
   const int nunits = rows * NB;
 
   float4* rb_all = reinterpret_cast<float4*>(smem_raw);  // [NWIN][WMAX]
   unsigned* cnt_all = reinterpret_cast<unsigned*>(rb_all + NWIN * WMAX);
   float* extras = reinterpret_cast<float*>(cnt_all + NW * WMAX);  // [R][Wt][4]
-  TaskInfo* tinfo = reinterpret_cast<TaskInfo*>(extras + R * Wt * 4);  // [64]
-  int* yrange = reinterpret_cast<int*>(tinfo + 64);
+  const int CAP = cfg.cap;
+  TaskA* taskA = reinterpret_cast<TaskA*>(extras + R * Wt * 4);  // [CAP]
+  TaskB* taskB = reinterpret_cast<TaskB*>(taskA + CAP);           // [CAP]
+  int* yrange = reinterpret_cast<int*>(taskB + CAP);  // [0..1] rows, [2] slot ticket
   unsigned* cnt = cnt_all + wave * WMAX;
 
   // Everything read from global / kernarg memory inside the loops is copied to
@@ -203,8 +236,10 @@ __global__ __launch_bounds__(768) void splat_stream_kernel(SplatArgs a,
   // (task windows are zeroed by their owning wave when the task starts)
   for (int i = tid; i < NW * WMAX; i += T) cnt_all[i] = 0u;
   for (int i = tid; i < R * Wt * 4; i += T) extras[i] = 0.0f;
-  if (tid == 0) { yrange[0] = d.H; yrange[1] = -1; }
+  if (tid == 0) { yrange[0] = d.H; yrange[1] = -1; yrange[2] = 0; }
+  LSI_TSTAMP();
   __syncthreads();
+  LSI_TSTAMP();
   {  // source rows whose target rows (y0, y0+1) intersect the band
     int lo = d.H, hi = -1;
     for (int y = tid; y < d.H; y += T) {
@@ -235,35 +270,31 @@ __global__ __launch_bounds__(768) void splat_stream_kernel(SplatArgs a,
     for (int u = 0; u < MAXU; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
     const int l_begin = compose ? 0 : pass;
     const int ntask = nsrc * nseg;
-    const int nstep = (ntask + NWIN - 1) / NWIN;
+    const int nstep = div_small(ntask + NWIN - 1, NWIN, cfg.inv_nwin);
 
-    for (int step = 0; step < nstep; ++step) {
-      // ================= x-pass: TPW tasks per wave =========================
-      // task = (source row y, 256-pixel segment j), all layers of the pass;
-      // task slot k*NW + wave owns LDS window [slot]
-      for (int k = 0; k < TPW; ++k) {
-        const int slot = k * NW + wave;
-        const int tg = step * NWIN + slot;
-        TaskInfo ti;
-        ti.row0 = -1000000; ti.wy0 = 0.f; ti.wy1 = 0.f; ti.wlo = 0; ti.wwin = 0;
-        int y = 0, xs = 0;
-        float nden = 1.0f;
-        bool tvalid = tg < ntask;
-        if (tvalid) {
+    // task table for tasks [tg0, tg0 + CAP): one task per thread
+    auto fill_tasks = [&](int tg0) {
+      for (int t = tid; t < CAP; t += T) {
+        const int tg = tg0 + t;
+        TaskA ta; ta.row0 = -1000000; ta.wy0 = 0.f; ta.wy1 = 0.f; ta.win = 0;
+        TaskB tb; tb.nden = 1.0f; tb.rn = 1.0f; tb.y = 0; tb.xs = 0;
+        if (tg < ntask) {
           // tg / nseg without an integer division (tg < 2^20: exact in fp32)
           const int yi = (int)(((float)tg + 0.5f) * inv_nseg);
-          const int j = tg - yi * nseg;
-          y = y_lo + yi;
-          xs = j * SEG;
+          const int y = y_lo + yi;
+          const int xs = (tg - yi * nseg) * SEG;
           const float py = (float)y + 0.5f;
+          float nden;
           const float Y = row_Y(y, nden);
-          tvalid = false;
           if (finite_f(Y) && fabsf(Y) < 1.0e7f) {
             const Axis ay = splat_axis(Y, ymax);
-            ti.row0 = (int)floorf(Y) - row0;
-            ti.wy0 = ay.w0;
-            ti.wy1 = ay.w1;
-            tvalid = (ay.w0 != 0.0f) || (ay.w1 != 0.0f);
+            ta.row0 = (int)floorf(Y) - row0;
+            ta.wy0 = ay.w0;
+            ta.wy1 = ay.w1;
+            tb.nden = nden;
+            tb.rn = SIMPLE ? 1.0f : div_rn(1.0f, nden);
+            tb.y = y;
+            tb.xs = xs;
             // window hint: cells reachable for d in [0, max_disp] on the segment
             const int xe = min(xs + SEG, W);
             float lo = __builtin_inff(), hi = -__builtin_inff();
@@ -285,18 +316,50 @@ __global__ __launch_bounds__(768) void splat_stream_kernel(SplatArgs a,
             }
             if (finite_f(lo) && finite_f(hi) && fabsf(lo) < 1.0e7f &&
                 fabsf(hi) < 1.0e7f) {
-              // cells [wlo, wlo+wwin) confined to the image: a fast lane then
-              // needs no border mask (both its cells are valid)
+              // cells [wlo, wlo+wwin) confined to the image: an in-window lane
+              // then needs no border mask (both its cells are valid)
               const int c_lo = max((int)floorf(lo) - 1, 0);
               const int c_hi = min((int)floorf(hi) + 2, Wt - 1);
-              ti.wlo = c_lo;
-              ti.wwin = max(0, min(WMAX, c_hi - c_lo + 1));
+              const int wwin = max(0, min(WMAX, c_hi - c_lo + 1));
+              ta.win = c_lo | (wwin << 16);
             }
           }
         }
-        if (lane == 0) tinfo[slot] = ti;
-        if (!tvalid) continue;
+        taskA[t] = ta;
+        taskB[t] = tb;
+      }
+    };
+    const int steps_per_chunk = cfg.steps_per_chunk;
+
+    for (int step = 0, sidx = 0; step < nstep; ++step, ++sidx) {
+      if (sidx == steps_per_chunk) sidx = 0;
+      if (sidx == 0) {  // (the previous step's closing barrier protects the table)
+        fill_tasks(step * NWIN);
         LSI_TSTAMP();
+        __syncthreads();
+      }
+      LSI_TSTAMP();
+      // ================= x-pass ==============================================
+      // task = (source row y, 256-pixel segment j), all layers of the pass.
+      // Waves draw task slots from a ticket counter (tasks differ in cost);
+      // the wave that draws slot t owns LDS window [t] until the merge.
+      for (;;) {
+        int slot = 0;
+        if (lane == 0) slot = atomicAdd(&yrange[2], 1);
+        slot = __builtin_amdgcn_readfirstlane(slot);
+        if (slot >= NWIN) break;
+        const TaskA ta = taskA[sidx * NWIN + slot];  // LDS broadcast reads
+        const TaskB tb = taskB[sidx * NWIN + slot];
+        // wave-uniform by construction; tell the compiler (scalar registers)
+        const int t_valid = __builtin_amdgcn_readfirstlane(
+            (ta.wy0 != 0.0f || ta.wy1 != 0.0f) ? 1 : 0);
+        if (!t_valid || (dbg & 64)) continue;  // dbg 64: overhead-only timing
+        const int t_row0 = __builtin_amdgcn_readfirstlane(ta.row0);
+        const int t_win = __builtin_amdgcn_readfirstlane(ta.win);
+        const int t_wlo = t_win & 0xffff, t_wwin = t_win >> 16;
+        const int y = __builtin_amdgcn_readfirstlane(tb.y);
+        const int xs = __builtin_amdgcn_readfirstlane(tb.xs);
+        const float nden = tb.nden;
 
         float4* rb = rb_all + slot * WMAX;
         const int x = xs + 4 * lane;
@@ -305,196 +368,234 @@ __global__ __launch_bounds__(768) void splat_stream_kernel(SplatArgs a,
         // row-uniform pieces of q = M p, in the contract's rounding order
         const float pym01 = py * m[1];
         const float pym31 = py * m[13];
-        const float rn = SIMPLE ? 1.0f : div_rn(1.0f, nden);
-        const float wy0 = ti.wy0, wy1 = ti.wy1;
+        const float rn = tb.rn;
+        const float wy0 = ta.wy0, wy1 = ta.wy1;
         // smallest non-zero row weight: a side is exactly factorisable iff its
         // product with this one survives the 1e-3 clamp (rounding is monotone)
         const float wymin =
             (wy0 == 0.f) ? wy1 : ((wy1 == 0.f) ? wy0 : fminf(wy0, wy1));
-        // the larger x weight is >= ~0.5: its products with the row weights
-        // survive the clamp unless a row weight is itself tiny -- then the
-        // whole task takes the exact path
-        const bool wy_small = wymin <= 2.1e-3f;
-        const float wlo_f = (float)ti.wlo;
-        const float whi_f = (float)(ti.wlo + ti.wwin - 2);  // last left cell
+        const float wlo_f = (float)t_wlo;
 
         struct PxData { float4 d4, t0, t1, t2, m4; };
-        auto load_layer = [&](int l, PxData& o) {
-          if (!inrange) return;
-          o.d4 = *reinterpret_cast<const float4*>(
-              g_disp + l * disp_sl + b * disp_sb + y * disp_sy + x);
-          const float* tp = g_tex + l * tex_sl + b * tex_sb + y * tex_sy;
-          if (LAYOUT == 0) {
-            const float4* t4 = reinterpret_cast<const float4*>(tp + 3 * x);
-            o.t0 = t4[0]; o.t1 = t4[1]; o.t2 = t4[2];
-          } else {
-            o.t0 = *reinterpret_cast<const float4*>(tp + x);
-            o.t1 = *reinterpret_cast<const float4*>(tp + tex_sc + x);
-            o.t2 = *reinterpret_cast<const float4*>(tp + 2 * tex_sc + x);
+        // per-lane source pointers, advanced by one layer stride per load
+        const float* p_disp = g_disp + l_begin * disp_sl + b * disp_sb +
+                              y * disp_sy + x;
+        const float* p_tex = g_tex + l_begin * tex_sl + b * tex_sb + y * tex_sy +
+                             (LAYOUT == 0 ? 3 * x : x);
+        const float* p_mask = has_mask ? g_mask + l_begin * mask_sl +
+                                             b * mask_sb + y * mask_sy + x
+                                       : nullptr;
+        auto load_layer = [&](PxData& o) {
+          if (inrange) {
+            o.d4 = *reinterpret_cast<const float4*>(p_disp);
+            if (LAYOUT == 0) {
+              const float4* t4 = reinterpret_cast<const float4*>(p_tex);
+              o.t0 = t4[0]; o.t1 = t4[1]; o.t2 = t4[2];
+            } else {
+              o.t0 = *reinterpret_cast<const float4*>(p_tex);
+              o.t1 = *reinterpret_cast<const float4*>(p_tex + tex_sc);
+              o.t2 = *reinterpret_cast<const float4*>(p_tex + 2 * tex_sc);
+            }
+            if (has_mask) o.m4 = *reinterpret_cast<const float4*>(p_mask);
           }
-          if (has_mask)
-            o.m4 = *reinterpret_cast<const float4*>(
-                g_mask + l * mask_sl + b * mask_sb + y * mask_sy + x);
+          p_disp += disp_sl;
+          p_tex += tex_sl;
+          if (has_mask) p_mask += mask_sl;
         };
 
-        // exact threshold test for the clamp: a side's products survive iff
-        // fl(w*wymin) > 1e-3; w > thr is a (slightly conservative) sufficient
-        // condition evaluated with one compare per side
-        const float thr = wy_small ? __builtin_inff()
-                                   : div_rn(1e-3f, wymin) * 1.000001f;
-        const int wspan = ti.wwin - 2;  // last admissible left-cell offset
+        // Clamp handling (sampling.py:218-222): corner weight w_x*w_y survives
+        // iff fl(w_x*w_y) > 1e-3.  A side whose product with the SMALLER row
+        // weight survives factorises exactly (rounding is monotone) and goes
+        // to the window; otherwise it is taken out of the window (weight 0)
+        // and only its product with the LARGER row weight can survive: that
+        // one corner is added to the extras tile.
+        const float wymax = fmaxf(wy0, wy1);
+        const int rmax = t_row0 + ((wy1 > wy0) ? 1 : 0);
+        const int has_max = __builtin_amdgcn_readfirstlane(
+            ((wymax != wymin) && rmax >= 0 && rmax < rows && !(dbg & 1)) ? 1
+                                                                         : 0);
+        float* const emax = extras + ((long)rmax * Wt + t_wlo) * 4;
+        const unsigned wspan = (unsigned)(t_wwin - 2);  // last left-cell offset
+        // lanes exempt from the "strictly increasing" test: lane 0, and the
+        // tail lanes beyond the image (no in-window lane follows them)
+        const unsigned long long inr_mask = __ballot(inrange);
+        const unsigned long long edge_mask = ~inr_mask | 1ull;
+        const int l_end = l_begin + Lp;
 
-        // One layer of the lane's 4 pixels.  Hot path: every lane of the wave
-        // is either out of range or "fast" (both cells inside the in-image
-        // window, no clamped corner) and floor(X) is strictly increasing
-        // across the wave -> plain RMW.  Anything else takes general_px().
-        auto do_layer = [&](const PxData& cur) {
-          const float dv[4] = {cur.d4.x, cur.d4.y, cur.d4.z, cur.d4.w};
-          float cr[4], cg[4], cb[4];
-          if (LAYOUT == 0) {
-            cr[0] = cur.t0.x; cg[0] = cur.t0.y; cb[0] = cur.t0.z;
-            cr[1] = cur.t0.w; cg[1] = cur.t1.x; cb[1] = cur.t1.y;
-            cr[2] = cur.t1.z; cg[2] = cur.t1.w; cb[2] = cur.t2.x;
-            cr[3] = cur.t2.y; cg[3] = cur.t2.z; cb[3] = cur.t2.w;
-          } else {
-            cr[0] = cur.t0.x; cr[1] = cur.t0.y; cr[2] = cur.t0.z; cr[3] = cur.t0.w;
-            cg[0] = cur.t1.x; cg[1] = cur.t1.y; cg[2] = cur.t1.z; cg[3] = cur.t1.w;
-            cb[0] = cur.t2.x; cb[1] = cur.t2.y; cb[2] = cur.t2.z; cb[3] = cur.t2.w;
-          }
+        PxData cur;
+        cur.d4 = cur.t0 = cur.t1 = cur.t2 = make_float4(0.f, 0.f, 0.f, 0.f);
+        cur.m4 = make_float4(1.f, 1.f, 1.f, 1.f);
+        load_layer(cur);
+        // zero this task's window while the first loads are in flight (same
+        // wave, in-order LDS: no barrier needed before its own RMWs)
+        for (int c = lane; c < t_wwin; c += 64)
+          rb[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        LSI_COMPILER_FENCE();
+
+        for (int l = l_begin; l < l_end; ++l) {
           // ---- projection of the 4 pixels as two packed pairs (v_pk_*_f32) --
-          float x0v[4], w0v[4], w1v[4], pwv[4];
+          float x0v[4], w0v[4], w1v[4];
+          float4 Vv[4];
+          {
+            const float dv[4] = {cur.d4.x, cur.d4.y, cur.d4.z, cur.d4.w};
+            float pwv[4];
 #pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const f2 px = {(float)(x + 2 * h) + 0.5f, (float)(x + 2 * h) + 1.5f};
-            const f2 dvp = {dv[2 * h], dv[2 * h + 1]};
-            // q0 = ((px*m00 + py*m01) + m02) + d*m03, each op rounded
-            f2 q0 = px * m[0] + pym01;
-            q0 = q0 + m[2];
-            q0 = q0 + dvp * m[3];
-            f2 q3, u;
-            if (SIMPLE) {
-              q3 = dvp;
-              u = q0;  // index-critical u = q0 / n' with n' == 1 exactly
+            for (int h = 0; h < 2; ++h) {
+              const f2 px = {(float)(x + 2 * h) + 0.5f,
+                             (float)(x + 2 * h) + 1.5f};
+              const f2 dvp = {dv[2 * h], dv[2 * h + 1]};
+              // q0 = ((px*m00 + py*m01) + m02) + d*m03, each op rounded
+              f2 q0 = px * m[0] + pym01;
+              q0 = q0 + m[2];
+              q0 = q0 + dvp * m[3];
+              f2 q3, u;
+              if (SIMPLE) {
+                q3 = dvp;
+                u = q0;  // index-critical u = q0 / n' with n' == 1 exactly
+              } else {
+                q3 = px * m[12] + pym31;
+                q3 = q3 + m[14];
+                q3 = q3 + dvp * m[15];
+                u.x = div_rn(q0.x, nden);  // index-critical: IEEE division
+                u.y = div_rn(q0.y, nden);
+              }
+              const f2 X = u * s - 0.5f;
+              // sampling.py:193-211 on the x axis: floor, x1 - x, x - x0
+              const f2 x0 = {floorf(X.x), floorf(X.y)};
+              const f2 gx = (x0 + 1.0f) - X;
+              const f2 fx = X - x0;
+              // weights are not index-critical: reciprocal multiplies
+              const f2 dd = SIMPLE ? q3 : q3 * rn;
+              const f2 xn = dd * inv_md;
+              // helpers.py:180-193: exp((clip(x,0,1) - 0.5)*scale) * [x > 0]
+              f2 c = {__builtin_amdgcn_fmed3f(xn.x, 0.0f, 1.0f),
+                      __builtin_amdgcn_fmed3f(xn.y, 0.0f, 1.0f)};
+              c = (c - 0.5f) * zscale;
+              f2 e = exp_accurate2(c);
+              e.x = xn.x > 0.0f ? e.x : 0.0f;  // NaN disparity -> weight 0
+              e.y = xn.y > 0.0f ? e.y : 0.0f;
+              if (has_mask) {
+                const f2 mkp = {h == 0 ? cur.m4.x : cur.m4.z,
+                                h == 0 ? cur.m4.y : cur.m4.w};
+                e = e * mkp;
+              }
+              x0v[2 * h] = x0.x; x0v[2 * h + 1] = x0.y;
+              w0v[2 * h] = gx.x; w0v[2 * h + 1] = gx.y;
+              w1v[2 * h] = fx.x; w1v[2 * h + 1] = fx.y;
+              pwv[2 * h] = e.x; pwv[2 * h + 1] = e.y;
+            }
+            // V = (r, g, b, 1) * pixel weight, for all 4 pixels: after this the
+            // layer's input registers are dead and can take the next loads
+            if (LAYOUT == 0) {
+              Vv[0] = make_float4(cur.t0.x * pwv[0], cur.t0.y * pwv[0],
+                                  cur.t0.z * pwv[0], pwv[0]);
+              Vv[1] = make_float4(cur.t0.w * pwv[1], cur.t1.x * pwv[1],
+                                  cur.t1.y * pwv[1], pwv[1]);
+              Vv[2] = make_float4(cur.t1.z * pwv[2], cur.t1.w * pwv[2],
+                                  cur.t2.x * pwv[2], pwv[2]);
+              Vv[3] = make_float4(cur.t2.y * pwv[3], cur.t2.z * pwv[3],
+                                  cur.t2.w * pwv[3], pwv[3]);
             } else {
-              q3 = px * m[12] + pym31;
-              q3 = q3 + m[14];
-              q3 = q3 + dvp * m[15];
-              u.x = div_rn(q0.x, nden);  // index-critical: IEEE division
-              u.y = div_rn(q0.y, nden);
+              Vv[0] = make_float4(cur.t0.x * pwv[0], cur.t1.x * pwv[0],
+                                  cur.t2.x * pwv[0], pwv[0]);
+              Vv[1] = make_float4(cur.t0.y * pwv[1], cur.t1.y * pwv[1],
+                                  cur.t2.y * pwv[1], pwv[1]);
+              Vv[2] = make_float4(cur.t0.z * pwv[2], cur.t1.z * pwv[2],
+                                  cur.t2.z * pwv[2], pwv[2]);
+              Vv[3] = make_float4(cur.t0.w * pwv[3], cur.t1.w * pwv[3],
+                                  cur.t2.w * pwv[3], pwv[3]);
             }
-            const f2 X = u * s - 0.5f;
-            // sampling.py:193-211 on the x axis: floor, x1 - x, x - x0
-            const f2 x0 = {floorf(X.x), floorf(X.y)};
-            const f2 gx = (x0 + 1.0f) - X;
-            const f2 fx = X - x0;
-            // weights are not index-critical: reciprocal multiplies (<= 2 ulp)
-            const f2 dd = SIMPLE ? q3 : q3 * rn;
-            const f2 xn = dd * inv_md;
-            // helpers.py:180-193: exp((clip(x,0,1) - 0.5)*scale) * [x > 0]
-            f2 c = {__builtin_amdgcn_fmed3f(xn.x, 0.0f, 1.0f),
-                    __builtin_amdgcn_fmed3f(xn.y, 0.0f, 1.0f)};
-            c = (c - 0.5f) * zscale;
-            f2 e = exp_accurate2(c);
-            e.x = xn.x > 0.0f ? e.x : 0.0f;  // NaN disparity -> weight 0
-            e.y = xn.y > 0.0f ? e.y : 0.0f;
-            if (has_mask) {
-              const f2 mkp = {h == 0 ? cur.m4.x : cur.m4.z,
-                              h == 0 ? cur.m4.y : cur.m4.w};
-              e = e * mkp;
-            }
-            x0v[2 * h] = x0.x; x0v[2 * h + 1] = x0.y;
-            w0v[2 * h] = gx.x; w0v[2 * h + 1] = gx.y;
-            w1v[2 * h] = fx.x; w1v[2 * h + 1] = fx.y;
-            pwv[2 * h] = e.x; pwv[2 * h + 1] = e.y;
           }
+          // next layer's loads in flight during the LDS phase, no register copy
+          // The derived values are pinned here so that the projection is not
+          // sunk below the loads: the loads then overwrite dead registers and
+          // need no copies.
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            asm volatile("" : "+v"(Vv[i].x), "+v"(Vv[i].y), "+v"(Vv[i].z),
+                              "+v"(Vv[i].w), "+v"(x0v[i]), "+v"(w0v[i]),
+                              "+v"(w1v[i]));
+          }
+          if (l + 1 < l_end && !(dbg & 256)) load_layer(cur);  // 256: timing
 
           // ---- LDS phase, pixel by pixel (cells of one lane's pixels overlap)
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            const float x0 = x0v[i], w0 = w0v[i], w1 = w1v[i], pw = pwv[i];
-            // left-cell offset in the window; +-Inf saturates, NaN has pw == 0
+            const float x0 = x0v[i];
+            float w0 = w0v[i], w1 = w1v[i];
+            const float4 V = Vv[i];
+            // left-cell offset in the window (+-Inf saturates; NaN gives
+            // offset 0 but both its side weights are then clamped to 0 below)
             const int cl = (int)(x0 - wlo_f);
-            const bool fast = inrange && ((unsigned)cl <= (unsigned)wspan) &&
-                              (w0 > thr) && (w1 > thr);
-            const float4 V = make_float4(cr[i] * pw, cg[i] * pw, cb[i] * pw, pw);
+            // in-window lanes: both cells inside the (in-image) window.  Each
+            // ballot is taken straight from one compare; the masks are
+            // combined with scalar ops.
+            const bool in_b = (unsigned)cl <= wspan;
+            const bool inw = in_b && inrange;
+            const unsigned long long inw_mask = __ballot(in_b) & inr_mask;
             // lane l-1's floor(X) by DPP wave_shr:1 (VALU, no LDS round trip)
-            const float prev = __int_as_float(__builtin_amdgcn_update_dpp(
-                0, __float_as_int(x0), 0x138, 0xf, 0xf, false));
-            const bool mono_lane = (lane == 0) || !inrange || (x0 > prev);
-            const bool clean = ((__ballot(mono_lane && (fast || !inrange)) == ~0ull)
-                                && !(dbg & 16)) || (dbg & 32);
-            float4* cell = rb + (fast ? cl : 0);
-            if (clean) {
-              if (fast) {
+            const float prev = __int_as_float(__builtin_amdgcn_mov_dpp(
+                __float_as_int(x0), 0x138, 0xf, 0xf, true));
+            const unsigned long long mono_ok = __ballot(x0 > prev) | edge_mask;
+            // clamped sides: !(p > 1e-3) is also true for NaN weights
+            const bool c0 = !(w0 * wymin > 1.0e-3f);
+            const bool c1 = !(w1 * wymin > 1.0e-3f);
+            const unsigned long long clamp_mask =
+                (__ballot(c0) | __ballot(c1)) & inw_mask;
+            if (has_max) {
+              if (clamp_mask != 0ull) {
+                const float k0 = w0 * wymax, k1 = w1 * wymax;
+                if (inw && c0 && k0 > 1.0e-3f) {
+                  float* e = emax + cl * 4;
+                  atomic_add_f32(e + 0, V.x * k0);
+                  atomic_add_f32(e + 1, V.y * k0);
+                  atomic_add_f32(e + 2, V.z * k0);
+                  atomic_add_f32(e + 3, V.w * k0);
+                }
+                if (inw && c1 && k1 > 1.0e-3f) {
+                  float* e = emax + cl * 4 + 4;
+                  atomic_add_f32(e + 0, V.x * k1);
+                  atomic_add_f32(e + 1, V.y * k1);
+                  atomic_add_f32(e + 2, V.z * k1);
+                  atomic_add_f32(e + 3, V.w * k1);
+                }
+              }
+            }
+            // lanes outside the window: exact slow path (cells outside the
+            // image and non-finite X fail its range tests and add nothing)
+            if ((inr_mask & ~inw_mask) != 0ull && !(dbg & 1)) {
+              if (inrange && !in_b && V.w != 0.0f)
+                slow_corners(extras, V, x0, w0, w1, xmax, wy0, wy1, t_row0,
+                             rows, Wt);
+            }
+            if (c0) w0 = 0.0f;
+            if (c1) w1 = 0.0f;
+            float4* cell = rb + cl;  // dereferenced by in-window lanes only
+            if (mono_ok == ~0ull || (dbg & 2)) {
+              if (inw && !(dbg & 128)) {  // dbg 128: no window traffic (timing)
                 cell[0] = f4_fma(cell[0], V, w0);
                 LSI_COMPILER_FENCE();
                 cell[1] = f4_fma(cell[1], V, w1);
               }
               LSI_COMPILER_FENCE();
-              continue;
-            }
-            // ---- general px: exact slow corners + (ranked) RMW ---------------
-            {
-              // lanes that are not fast but can still touch the image: exact
-              // slow path.  (non-finite X fails the range tests: dropped)
-              const bool slow = inrange && !fast && (pw != 0.0f) &&
-                                (x0 >= -1.0f) && (x0 <= xmax);
-              if (__ballot(slow) != 0ull && !(dbg & 1)) {
-                if (slow) {
-                  // X recomputed exactly as in the projection above
-                  float q0 = ((float)(x + i) + 0.5f) * m[0] + pym01;
-                  q0 = q0 + m[2];
-                  q0 = q0 + dv[i] * m[3];
-                  const float u = SIMPLE ? q0 : div_rn(q0, nden);
-                  slow_corners(extras, V, u * s - 0.5f, xmax, wy0, wy1, ti.row0,
-                               rows, Wt);
-                }
-              }
-              const bool mono = (__ballot(mono_lane) == ~0ull) || (dbg & 2);
-              if (mono) {
-                if (fast) {
+            } else if (inw_mask != 0ull) {
+              // some lanes may share cells: serialise by arrival rank
+              unsigned* cn = cnt + cl;
+              unsigned rank = 0u;
+              if (inw) rank = atomicAdd(cn, 1u);
+              for (unsigned r = 0;; ++r) {
+                if (__ballot(inw && rank >= r) == 0ull) break;
+                if (inw && rank == r) {
                   cell[0] = f4_fma(cell[0], V, w0);
                   LSI_COMPILER_FENCE();
                   cell[1] = f4_fma(cell[1], V, w1);
                 }
                 LSI_COMPILER_FENCE();
-              } else if (__ballot(fast) != 0ull) {
-                unsigned* cn = cnt + (fast ? cl : 0);
-                unsigned rank = 0u;
-                if (fast) rank = atomicAdd(cn, 1u);
-                for (unsigned r = 0;; ++r) {
-                  if (__ballot(fast && rank >= r) == 0ull) break;
-                  if (fast && rank == r) {
-                    cell[0] = f4_fma(cell[0], V, w0);
-                    LSI_COMPILER_FENCE();
-                    cell[1] = f4_fma(cell[1], V, w1);
-                  }
-                  LSI_COMPILER_FENCE();
-                }
-                if (fast) *cn = 0u;
-                LSI_COMPILER_FENCE();
               }
+              if (inw) *cn = 0u;
+              LSI_COMPILER_FENCE();
             }
           }
-        };
-
-        // the next layer's loads are in flight while the current one is
-        // processed (one copy of the loop body: the kernel must stay small
-        // enough for the instruction cache)
-        PxData nxt;
-        nxt.d4 = nxt.t0 = nxt.t1 = nxt.t2 = make_float4(0.f, 0.f, 0.f, 0.f);
-        nxt.m4 = make_float4(1.f, 1.f, 1.f, 1.f);
-        const int l_end = l_begin + Lp;
-        load_layer(l_begin, nxt);
-        // zero this task's window while the first loads are in flight (same
-        // wave, in-order LDS: no barrier needed before its own RMWs)
-        for (int c = lane; c < ti.wwin; c += 64)
-          rb[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-        LSI_COMPILER_FENCE();
-        for (int l = l_begin; l < l_end; ++l) {
-          const PxData cur = nxt;
-          if (l + 1 < l_end) load_layer(l + 1, nxt);
-          do_layer(cur);
         }
       }
       if (tdbg && lane == 0 && step == 0) tdbg[16 + wave] = (long long)__builtin_readcyclecounter();
@@ -503,31 +604,32 @@ __global__ __launch_bounds__(768) void splat_stream_kernel(SplatArgs a,
       LSI_TSTAMP();
 
       // ================= merge: cell owners gather the windows =============
+      if (tid == 0) yrange[2] = 0;  // next step's tickets (no draws until then)
       {
         // lane t holds task slot t's table entry; the slots that touch a unit
         // are found with one ballot and their entries broadcast by readlane
-        TaskInfo mine;
-        mine.row0 = -1000000; mine.wy0 = 0.f; mine.wy1 = 0.f;
-        mine.wlo = 0; mine.wwin = 0;
-        if (lane < NWIN) mine = tinfo[lane];
+        TaskA mine;
+        mine.row0 = -1000000; mine.wy0 = 0.f; mine.wy1 = 0.f; mine.win = 0;
+        if (lane < NWIN) mine = taskA[sidx * NWIN + lane];
+        const int mine_wlo = mine.win & 0xffff, mine_wwin = mine.win >> 16;
 #pragma unroll
         for (int u = 0; u < MAXU; ++u) {
           const int unit = wave + u * NW;
           if (unit >= nunits) continue;
-          const int r = unit / NB;
+          const int r = div_small(unit, NB, cfg.inv_nb);
           const int c0 = (unit - r * NB) * 64;
           const int cell = c0 + lane;
           const bool hit =
               ((mine.row0 == r && mine.wy0 != 0.f) ||
                (mine.row0 + 1 == r && mine.wy1 != 0.f)) &&
-              (mine.wlo <= c0 + 63) && (mine.wlo + mine.wwin > c0);
+              (mine_wlo <= c0 + 63) && (mine_wlo + mine_wwin > c0);
           unsigned long long todo = __ballot(hit);
           // entry t of the table, broadcast; value of window t at this lane's
           // cell (0 outside the window) and the row weight that applies
           auto fetch = [&](int t, float4& v, float& wy) {
             const int q_row0 = __builtin_amdgcn_readlane(mine.row0, t);
-            const int q_wlo = __builtin_amdgcn_readlane(mine.wlo, t);
-            const int q_wwin = __builtin_amdgcn_readlane(mine.wwin, t);
+            const int q_win = __builtin_amdgcn_readlane(mine.win, t);
+            const int q_wlo = q_win & 0xffff, q_wwin = q_win >> 16;
             const float q_wy0 = __int_as_float(
                 __builtin_amdgcn_readlane(__float_as_int(mine.wy0), t));
             const float q_wy1 = __int_as_float(
@@ -555,7 +657,9 @@ __global__ __launch_bounds__(768) void splat_stream_kernel(SplatArgs a,
         }
       }
       LSI_TSTAMP();
-      __syncthreads();
+      // windows and the task table are reused by the next step; after the
+      // last one every wave goes on to its own cells' epilogue
+      if (step + 1 < nstep) __syncthreads();
       LSI_TSTAMP();
     }
 
@@ -566,7 +670,7 @@ __global__ __launch_bounds__(768) void splat_stream_kernel(SplatArgs a,
     for (int u = 0; u < MAXU; ++u) {
       const int unit = wave + u * NW;
       if (unit >= nunits) continue;
-      const int r = unit / NB;
+      const int r = div_small(unit, NB, cfg.inv_nb);
       const int cell = (unit - r * NB) * 64 + lane;
       if (cell >= Wt) continue;
       float* e = extras + ((size_t)r * Wt + cell) * 4;
@@ -582,14 +686,21 @@ __global__ __launch_bounds__(768) void splat_stream_kernel(SplatArgs a,
       if (pass + 1 < npass) { e[0] = 0.f; e[1] = 0.f; e[2] = 0.f; e[3] = 0.f; }
     }
     LSI_TSTAMP();
-    __syncthreads();
+    if (pass + 1 < npass) __syncthreads();
   }
+}
+
+// task-table entries: whole steps, about 256 tasks per refill
+int stream_cap(int nw, int tpw) {
+  const int nwin = nw * tpw;
+  return nwin * (256 / nwin > 0 ? 256 / nwin : 1);
 }
 
 size_t stream_lds_bytes(const LsiSplatDesc* d, int R, int nw, int wmax,
                         int tpw) {
   return (size_t)nw * tpw * wmax * 16 + (size_t)nw * wmax * 4 +
-         (size_t)R * d->Wt * 16 + 64 * sizeof(TaskInfo) + 16;
+         (size_t)R * d->Wt * 16 +
+         (size_t)stream_cap(nw, tpw) * (sizeof(TaskA) + sizeof(TaskB)) + 16;
 }
 
 // layout class of the texture strides: 0 channels-last, 1 planar, -1 neither
@@ -611,6 +722,7 @@ extern "C" int lsi_stream_ok(const LsiSplatDesc* d, const float* M) {
   if (!lsi_rowband_ok(d, M)) return 0;
   if (d->flags & LSI_WANT_DISP) return 0;
   if (d->W % 4 != 0) return 0;
+  if (d->Wt > 32767) return 0;  // window origin is kept in 16 bits
   if (tex_layout(d) < 0) return 0;
   if (d->disp_sx != 1 || d->disp_sy % 4 || d->disp_sb % 4 || d->disp_sl % 4)
     return 0;
@@ -694,6 +806,12 @@ int lsi_stream_launch(const SplatArgs& a, hipStream_t stream) {
   if (lds > 160 * 1024) return LSI_EINVAL;
   cfg.tpw = tpw;
   cfg.R = R;
+  cfg.cap = stream_cap(nw, tpw);
+  cfg.nb = NB;
+  cfg.steps_per_chunk = cfg.cap / (nw * tpw);
+  cfg.inv_nb = 1.0f / (float)NB;
+  cfg.inv_nwin = 1.0f / (float)(nw * tpw);
+  cfg.inv_gx = 1.0f / (float)((d->Ht + R - 1) / R);
   dim3 grid((d->Ht + R - 1) / R, d->B);
   const bool simple = (d->tune_window & LSI_STREAM_SIMPLE_BIT) != 0;
   const void* fn;
