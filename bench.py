@@ -136,8 +136,9 @@ class Renderer(object):
     self.wts = torch.empty((1, b, ht, wt, 1), device=dev)
     lib = _C.lib()
     self.ws_bytes = int(lib.lsi_splat_workspace_bytes(ctypes.byref(self.desc)))
-    self.ws = torch.empty((max(self.ws_bytes, 16),), dtype=torch.uint8,
+    self.ws = torch.zeros((max(self.ws_bytes, 16),), dtype=torch.uint8,
                           device=dev)
+    self.desc.flags |= _C.LSI_WS_KEEP  # zero-filled once, kept by the library
     self.fn = lib.lsi_splat_fwd
     self.dev = dev
 

@@ -47,6 +47,7 @@ extern "C" {
 #define LSI_COMPOSE 1u       /* compose_layers=True  (ldi.py:167-171)         */
 #define LSI_WANT_DISP 2u     /* compute_trg_disp=True (ldi.py:179-180)        */
 #define LSI_HAS_MASK 4u      /* mask pointer is given (else mask == 1)        */
+#define LSI_WS_KEEP 8u       /* workspace state is kept between calls (below) */
 
 /* LsiSplatDesc.path: which kernel family renders the splat.                  */
 #define LSI_PATH_AUTO 0      /* library decides from the descriptor          */
@@ -117,7 +118,18 @@ int lsi_rowband_ok(const LsiSplatDesc* desc, const float* M_host);
  */
 int lsi_stream_ok(const LsiSplatDesc* desc, const float* M_host);
 
-/* Bytes of device workspace lsi_splat_fwd needs for this descriptor. */
+/*
+ * Bytes of device workspace lsi_splat_fwd needs for this descriptor (16-byte
+ * aligned; any path).  The ATOMIC path keeps its canvases there.  The STREAM
+ * path uses it to combine the target rows shared by two neighbouring row bands:
+ * a few arrival counters at its start, then partial rows.  The counters must be
+ * zero when a call starts and every call leaves them zero; lsi_splat_fwd clears
+ * them itself (one small memset on the stream) unless LSI_WS_KEEP promises that
+ * the buffer was zero-filled once and has only been used by completed or
+ * stream-ordered lsi_splat_fwd calls WITH THE SAME L, B, Ht, Wt AND flags since
+ * (the place of the counters depends on those).  One workspace must not be used by
+ * two calls that can run concurrently.
+ */
 size_t lsi_splat_workspace_bytes(const LsiSplatDesc* desc);
 
 /*

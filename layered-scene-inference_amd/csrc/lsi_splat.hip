@@ -513,8 +513,11 @@ size_t lsi_splat_workspace_bytes(const LsiSplatDesc* d) {
   if (check_desc(d) != LSI_OK) return 0;
   // ATOMIC-path canvases (the ROWBAND path needs none; sized for the worst
   // case so that one allocation serves either path).
-  return (size_t)canvas_count(d) * d->B * d->Ht * d->Wt * canvas_channels(d) *
-         sizeof(float);
+  const size_t atomic_need = (size_t)canvas_count(d) * d->B * d->Ht * d->Wt *
+                             canvas_channels(d) * sizeof(float);
+  // STREAM-path boundary-row exchange area (worst case band height)
+  const size_t stream_need = lsi_stream_workspace_bytes(d);
+  return atomic_need > stream_need ? atomic_need : stream_need;
 }
 
 int lsi_splat_fwd(const LsiSplatDesc* d, const float* tex, const float* disp,
@@ -532,6 +535,7 @@ int lsi_splat_fwd(const LsiSplatDesc* d, const float* tex, const float* disp,
   a.tex = tex; a.disp = disp; a.mask = mask; a.M = M;
   a.out_img = out_img; a.out_wts = out_wts; a.out_disp = out_disp;
   a.canvas = (float*)workspace;
+  a.ws_bytes = workspace_bytes;
   a.nch = canvas_channels(d);
   a.ncanv = canvas_count(d);
   a.shared = (d->flags & LSI_COMPOSE) && !(d->flags & LSI_WANT_DISP);
@@ -567,7 +571,8 @@ int lsi_splat_fwd(const LsiSplatDesc* d, const float* tex, const float* disp,
   if (path == LSI_PATH_STREAM) return lsi_stream_launch(a, stream);
   if (path != LSI_PATH_ATOMIC) return LSI_EINVAL;
 
-  const size_t need = lsi_splat_workspace_bytes(d);
+  const size_t need = (size_t)canvas_count(d) * d->B * d->Ht * d->Wt *
+                      canvas_channels(d) * sizeof(float);
   if (!workspace) return LSI_ENULL;
   if (workspace_bytes < need) return LSI_EWORKSPACE;
   if (hipMemsetAsync(workspace, 0, need, stream) != hipSuccess)
@@ -592,6 +597,7 @@ int lsi_project_indices(const LsiSplatDesc* d, const float* disp,
   a.d = *d;
   a.tex = nullptr; a.disp = disp; a.mask = mask; a.M = M;
   a.out_img = a.out_wts = a.out_disp = a.canvas = nullptr;
+  a.ws_bytes = 0;
   a.nch = 4; a.ncanv = 1; a.shared = 0; a.band_rows = 0;
   const int npx = d->H * d->W;
   hipLaunchKernelGGL(project_indices_kernel,
@@ -629,6 +635,7 @@ int lsi_splat_bwd(const LsiSplatDesc* d, const float* tex, const float* disp,
   a.d = *d;
   a.tex = tex; a.disp = disp; a.mask = mask; a.M = M;
   a.out_img = a.out_wts = a.out_disp = a.canvas = nullptr;
+  a.ws_bytes = 0;
   a.nch = 4; a.ncanv = 1; a.shared = 0; a.band_rows = 0;
   const int npx = d->H * d->W;
   hipLaunchKernelGGL(splat_bwd_kernel, dim3((npx + 255) / 256, d->B, d->L),

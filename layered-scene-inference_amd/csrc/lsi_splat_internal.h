@@ -13,12 +13,14 @@ struct SplatArgs {
   float* out_img;
   float* out_wts;
   float* out_disp;
-  float* canvas;  // ATOMIC path workspace
+  float* canvas;  // caller's workspace: ATOMIC canvases / STREAM exchange area
+  size_t ws_bytes;
   int nch;        // canvas channels (4, or 5 with disparity)
   int ncanv;      // canvases per batch element (1 or L)
   int shared;     // 1: compose without disparity, all layers share a canvas
   int band_rows;  // ROWBAND: target rows per workgroup
 };
 
-// LSI_PATH_STREAM launcher (lsi_splat_stream.hip).
+// LSI_PATH_STREAM launcher and workspace need (lsi_splat_stream.hip).
+size_t lsi_stream_workspace_bytes(const LsiSplatDesc* d);
 int lsi_stream_launch(const SplatArgs& a, hipStream_t stream);

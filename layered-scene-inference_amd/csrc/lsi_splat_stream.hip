@@ -38,6 +38,8 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 #include "../../include/lsi_hip.h"
 #include "lsi_common.h"
@@ -50,8 +52,7 @@ using namespace lsi;
 namespace {
 
 constexpr int SEG = 256;   // source pixels per task (64 lanes x 4)
-constexpr int MAXU = 3;    // target-cell units (64 cells) owned per wave
-constexpr int MAXNW = 12;
+constexpr int MAXNW = 16;
 // lsi_stream_ok's return value: window cells, plus this bit when every batch
 // element has normaliser == 1 and M row 3 == (0,0,0,1) (division-free kernel)
 constexpr int LSI_STREAM_SIMPLE_BIT = 1 << 20;
@@ -77,6 +78,12 @@ struct StreamCfg {
   int nb;     // 64-cell units per target row
   int steps_per_chunk;  // cap / (nw * tpw)
   float inv_nb, inv_nwin, inv_gx;  // reciprocals for division-free indexing
+  // boundary-row exchange area in the workspace (see stream_exchange_layout)
+  int* xcount;     // [npass][B][nbands] arrival counters, zero between calls
+  float4* xpart;   // [npass][B][nbands][2][Wt] partial rows
+  long long* tstamps;  // debug flag 4
+  int exchange;  // 1: bands own source rows and exchange boundary target rows
+                 // 0: bands own target rows and re-read one halo row pair
 };
 
 #define LSI_COMPILER_FENCE() asm volatile("" ::: "memory")
@@ -104,6 +111,32 @@ __device__ __forceinline__ int div_small(int n, int d, float rcp) {
   q += (r >= d) ? 1 : 0;
   q -= (r < 0) ? 1 : 0;
   return q;
+}
+
+// Device-coherent accesses for the boundary-row exchange: agent-scope relaxed
+// atomics are write-through / cache-bypassing (sc1), so no L2 write-back or
+// invalidate (a full agent-scope fence costs tens of microseconds here).
+__device__ __forceinline__ void store_coherent(float4* p, float4 v) {
+  unsigned long long* q = reinterpret_cast<unsigned long long*>(p);
+  const unsigned long long lo =
+      (unsigned long long)__float_as_uint(v.x) |
+      ((unsigned long long)__float_as_uint(v.y) << 32);
+  const unsigned long long hi =
+      (unsigned long long)__float_as_uint(v.z) |
+      ((unsigned long long)__float_as_uint(v.w) << 32);
+  __hip_atomic_store(q, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(q + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float4 load_coherent(const float4* p) {
+  const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
+  const unsigned long long lo =
+      __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long hi =
+      __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return make_float4(__uint_as_float((unsigned)lo),
+                     __uint_as_float((unsigned)(lo >> 32)),
+                     __uint_as_float((unsigned)hi),
+                     __uint_as_float((unsigned)(hi >> 32)));
 }
 
 // accumulations are not index-critical: fused multiply-add
@@ -144,7 +177,7 @@ __device__ __forceinline__ void slow_corners(float* extras, float4 V, float x0,
 // SIMPLE: the normaliser is exactly 1 and row 3 of M is (0,0,0,1) for every
 // batch element (rectified stereo): u = q0 and D = d with no division.
 template <int LAYOUT, bool SIMPLE>  // LAYOUT 0: channels-last RGB, 1: planar
-__global__ __launch_bounds__(768) void splat_stream_kernel(SplatArgs a,
+__global__ __launch_bounds__(1024) void splat_stream_kernel(SplatArgs a,
                                                            StreamCfg cfg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const LsiSplatDesc& d = a.d;
@@ -172,18 +205,36 @@ __global__ __launch_bounds__(768) void splat_stream_kernel(SplatArgs a,
       b = id / gridDim.x;
     }
   }
+  // Two decompositions of the image into row bands (cfg.exchange):
+  //  1: band = the source rows whose top target row k = floor(Y) lies in
+  //     [row0, row0 + R) (band 0 also takes k = -1).  They add into target
+  //     rows row0 .. row0 + R: the tile.  Its first row is shared with the
+  //     band above and its last with the band below; the two partial rows of a
+  //     shared target row are combined through the workspace by whichever
+  //     band finishes second.  No source row is read twice.
+  //  0: band = target rows [row0, row0 + R); it reads every source row that
+  //     touches them (k in [row0 - 1, row0 + R - 1]) and drops the
+  //     contributions that fall outside: one extra k per band, no exchange
+  //     (cheaper when a band is only a few microseconds of work).
+  const int nbands = gridDim.x;
   const int row0 = band * R;
-  const int rows = min(R, Ht - row0);
+  const bool xchg = cfg.exchange != 0;
+  const int rows = min(xchg ? R + 1 : R, Ht - row0);  // tile rows
+  const int k_lo = xchg ? (band == 0 ? -1 : row0) : row0 - 1;
+  const int k_hi = xchg ? min(row0 + R, Ht) - 1 : row0 + rows - 1;
+  const bool top_shared = xchg && band > 0;
+  const bool bot_shared = xchg && row0 + R < Ht;  // tile row R exists, shared
   const int NB = cfg.nb;
   const int nunits = rows * NB;
 
   float4* rb_all = reinterpret_cast<float4*>(smem_raw);  // [NWIN][WMAX]
   unsigned* cnt_all = reinterpret_cast<unsigned*>(rb_all + NWIN * WMAX);
-  float* extras = reinterpret_cast<float*>(cnt_all + NW * WMAX);  // [R][Wt][4]
+  float* extras = reinterpret_cast<float*>(cnt_all + NW * WMAX);  // [R+1][Wt][4]
   const int CAP = cfg.cap;
-  TaskA* taskA = reinterpret_cast<TaskA*>(extras + R * Wt * 4);  // [CAP]
+  TaskA* taskA = reinterpret_cast<TaskA*>(
+      extras + (R + cfg.exchange) * Wt * 4);  // [CAP]
   TaskB* taskB = reinterpret_cast<TaskB*>(taskA + CAP);           // [CAP]
-  int* yrange = reinterpret_cast<int*>(taskB + CAP);  // [0..1] rows, [2] slot ticket
+  int* yrange = reinterpret_cast<int*>(taskB + CAP);  // [0..1] rows, [2] slot ticket, [4..5] exchange order
   unsigned* cnt = cnt_all + wave * WMAX;
 
   // Everything read from global / kernarg memory inside the loops is copied to
@@ -209,8 +260,7 @@ __global__ __launch_bounds__(768) void splat_stream_kernel(SplatArgs a,
   const float inv_md = div_rn(1.0f, max_disp);
 
   long long* tdbg = (a.d.reserved & 4)
-                        ? reinterpret_cast<long long*>(a.canvas) +
-                              ((size_t)b * gridDim.x + band) * 32
+                        ? cfg.tstamps + ((size_t)b * gridDim.x + band) * 32
                         : nullptr;
   int tslot = 0;
 #define LSI_TSTAMP()                                               \
@@ -235,19 +285,20 @@ __global__ __launch_bounds__(768) void splat_stream_kernel(SplatArgs a,
   // ---- one-time init ------------------------------------------------------
   // (task windows are zeroed by their owning wave when the task starts)
   for (int i = tid; i < NW * WMAX; i += T) cnt_all[i] = 0u;
-  for (int i = tid; i < R * Wt * 4; i += T) extras[i] = 0.0f;
+  for (int i = tid; i < rows * Wt; i += T)
+    reinterpret_cast<float4*>(extras)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   if (tid == 0) { yrange[0] = d.H; yrange[1] = -1; yrange[2] = 0; }
   LSI_TSTAMP();
   __syncthreads();
   LSI_TSTAMP();
-  {  // source rows whose target rows (y0, y0+1) intersect the band
+  {  // source rows of the band: floor(Y) in [k_lo, k_hi]
     int lo = d.H, hi = -1;
     for (int y = tid; y < d.H; y += T) {
       float nd;
       const float Y = row_Y(y, nd);
       if (!finite_f(Y)) continue;
       const float y0 = floorf(Y);
-      if (y0 >= (float)(row0 - 1) && y0 <= (float)(row0 + rows - 1)) {
+      if (y0 >= (float)k_lo && y0 <= (float)k_hi) {
         lo = min(lo, y); hi = max(hi, y);
       }
     }
@@ -265,9 +316,6 @@ __global__ __launch_bounds__(768) void splat_stream_kernel(SplatArgs a,
   const int npass = compose ? 1 : nlayers;
   const int Lp = compose ? nlayers : 1;
   for (int pass = 0; pass < npass; ++pass) {
-    float4 acc[MAXU];
-#pragma unroll
-    for (int u = 0; u < MAXU; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
     const int l_begin = compose ? 0 : pass;
     const int ntask = nsrc * nseg;
     const int nstep = div_small(ntask + NWIN - 1, NWIN, cfg.inv_nwin);
@@ -612,10 +660,7 @@ __global__ __launch_bounds__(768) void splat_stream_kernel(SplatArgs a,
         mine.row0 = -1000000; mine.wy0 = 0.f; mine.wy1 = 0.f; mine.win = 0;
         if (lane < NWIN) mine = taskA[sidx * NWIN + lane];
         const int mine_wlo = mine.win & 0xffff, mine_wwin = mine.win >> 16;
-#pragma unroll
-        for (int u = 0; u < MAXU; ++u) {
-          const int unit = wave + u * NW;
-          if (unit >= nunits) continue;
+        for (int unit = wave; unit < nunits; unit += NW) {
           const int r = div_small(unit, NB, cfg.inv_nb);
           const int c0 = (unit - r * NB) * 64;
           const int cell = c0 + lane;
@@ -640,6 +685,8 @@ __global__ __launch_bounds__(768) void splat_stream_kernel(SplatArgs a,
             v = rb_all[t * WMAX + (in ? rel : 0)];
             if (!in) wy = 0.0f;
           };
+          float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+          const bool any = todo != 0ull;
           while (todo) {  // two independent LDS reads in flight per iteration
             const int t0 = __builtin_ctzll(todo);
             todo &= todo - 1;
@@ -651,8 +698,14 @@ __global__ __launch_bounds__(768) void splat_stream_kernel(SplatArgs a,
               todo &= todo - 1;
               fetch(t1, vb, wb);
             }
-            acc[u] = f4_fma(acc[u], va, wa);
-            acc[u] = f4_fma(acc[u], vb, wb);
+            acc = f4_fma(acc, va, wa);
+            acc = f4_fma(acc, vb, wb);
+          }
+          if (any && cell < Wt) {  // the unit's owner adds into the tile
+            float4* tcell = reinterpret_cast<float4*>(extras) + r * Wt + cell;
+            float4 tv = *tcell;
+            tv.x += acc.x; tv.y += acc.y; tv.z += acc.z; tv.w += acc.w;
+            *tcell = tv;
           }
         }
       }
@@ -664,18 +717,12 @@ __global__ __launch_bounds__(768) void splat_stream_kernel(SplatArgs a,
     }
 
     // ================= epilogue for this pass ===============================
+    // (each wave finishes the units it merged: no barrier needed before)
     const float lbg = compose ? (float)nlayers * bg : bg;
     const int lo_ = compose ? 0 : pass;
-#pragma unroll
-    for (int u = 0; u < MAXU; ++u) {
-      const int unit = wave + u * NW;
-      if (unit >= nunits) continue;
-      const int r = div_small(unit, NB, cfg.inv_nb);
-      const int cell = (unit - r * NB) * 64 + lane;
-      if (cell >= Wt) continue;
-      float* e = extras + ((size_t)r * Wt + cell) * 4;
-      const float A0 = (acc[u].x + e[0]) + lbg, A1 = (acc[u].y + e[1]) + lbg,
-                  A2 = (acc[u].z + e[2]) + lbg, Wsum = (acc[u].w + e[3]) + lbg;
+    auto finish = [&](int r, int cell, float4 A) {  // normalise and store
+      const float A0 = A.x + lbg, A1 = A.y + lbg, A2 = A.z + lbg;
+      const float Wsum = A.w + lbg;
       const float wd = safe_den(Wsum);
       const size_t o =
           ((size_t)lo_ * d.B + b) * P + (size_t)(row0 + r) * Wt + cell;
@@ -683,7 +730,82 @@ __global__ __launch_bounds__(768) void splat_stream_kernel(SplatArgs a,
       a.out_img[3 * o + 1] = div_rn(A1, wd);
       a.out_img[3 * o + 2] = div_rn(A2, wd);
       a.out_wts[o] = Wsum;
-      if (pass + 1 < npass) { e[0] = 0.f; e[1] = 0.f; e[2] = 0.f; e[3] = 0.f; }
+    };
+    // boundary j (between bands j-1 and j): counter and two partial rows
+    const size_t xb = ((size_t)pass * d.B + b) * nbands;
+    auto xrow = [&](int j, int side) {
+      return cfg.xpart + ((xb + j) * 2 + side) * (size_t)Wt;
+    };
+    for (int unit = wave; unit < nunits; unit += NW) {
+      const int r = div_small(unit, NB, cfg.inv_nb);
+      const int cell = (unit - r * NB) * 64 + lane;
+      if (cell >= Wt) continue;
+      float4* tcell = reinterpret_cast<float4*>(extras) + r * Wt + cell;
+      const float4 A = *tcell;
+      if (r == 0 && top_shared) {
+        store_coherent(xrow(band, 1) + cell, A);      // lower band's share
+      } else if (r == R && bot_shared) {
+        store_coherent(xrow(band + 1, 0) + cell, A);  // upper band's share
+      } else {
+        finish(r, cell, A);
+        if (pass + 1 < npass) *tcell = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    LSI_TSTAMP();
+    if (top_shared || bot_shared) {
+      // the partial rows are performed (write-through stores, waited for by
+      // every thread) before one thread announces this band on each boundary
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_s_waitcnt(0);
+      __syncthreads();
+      if (tid == 0) {
+        yrange[4] = top_shared
+                        ? __hip_atomic_fetch_add(&cfg.xcount[xb + band], 1,
+                                                 __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT)
+                        : 0;
+        yrange[5] = bot_shared
+                        ? __hip_atomic_fetch_add(&cfg.xcount[xb + band + 1], 1,
+                                                 __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT)
+                        : 0;
+      }
+      __syncthreads();
+      const bool fin_top = top_shared && yrange[4] == 1;
+      const bool fin_bot = bot_shared && yrange[5] == 1;
+      if (fin_top || fin_bot) {
+        for (int unit = wave; unit < nunits; unit += NW) {
+          const int r = div_small(unit, NB, cfg.inv_nb);
+          const int cell = (unit - r * NB) * 64 + lane;
+          if (cell >= Wt) continue;
+          const bool top = (r == 0 && fin_top), bot = (r == R && fin_bot);
+          if (!top && !bot) continue;
+          const float4 mine_v =
+              *(reinterpret_cast<float4*>(extras) + r * Wt + cell);
+          const float4* other = top ? xrow(band, 0) : xrow(band + 1, 1);
+          const float4 o4 = load_coherent(other + cell);
+          finish(r, cell, make_float4(mine_v.x + o4.x, mine_v.y + o4.y,
+                                      mine_v.z + o4.z, mine_v.w + o4.w));
+        }
+        if (tid == 0) {  // leave the counters zero for the next call
+          if (fin_top)
+            __hip_atomic_store(&cfg.xcount[xb + band], 0, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+          if (fin_bot)
+            __hip_atomic_store(&cfg.xcount[xb + band + 1], 0, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      if (pass + 1 < npass) {  // shared tile rows start the next pass empty
+        __syncthreads();
+        for (int i = tid; i < Wt; i += T) {
+          if (top_shared)
+            reinterpret_cast<float4*>(extras)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (bot_shared)
+            reinterpret_cast<float4*>(extras)[R * Wt + i] =
+                make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
     }
     LSI_TSTAMP();
     if (pass + 1 < npass) __syncthreads();
@@ -696,11 +818,11 @@ int stream_cap(int nw, int tpw) {
   return nwin * (256 / nwin > 0 ? 256 / nwin : 1);
 }
 
-size_t stream_lds_bytes(const LsiSplatDesc* d, int R, int nw, int wmax,
+size_t stream_lds_bytes(const LsiSplatDesc* d, int tile_rows, int nw, int wmax,
                         int tpw) {
   return (size_t)nw * tpw * wmax * 16 + (size_t)nw * wmax * 4 +
-         (size_t)R * d->Wt * 16 +
-         (size_t)stream_cap(nw, tpw) * (sizeof(TaskA) + sizeof(TaskB)) + 16;
+         (size_t)tile_rows * d->Wt * 16 +
+         (size_t)stream_cap(nw, tpw) * (sizeof(TaskA) + sizeof(TaskB)) + 32;
 }
 
 // layout class of the texture strides: 0 channels-last, 1 planar, -1 neither
@@ -754,6 +876,88 @@ extern "C" int lsi_stream_ok(const LsiSplatDesc* d, const float* M) {
   return win | (simple ? LSI_STREAM_SIMPLE_BIT : 0);
 }
 
+// Workspace layout of the boundary-row exchange for bands of R rows: arrival
+// counters first, then the partial rows.
+struct XLayout { size_t count_bytes, part_bytes; int nbands, npass; };
+static XLayout stream_exchange_layout(const LsiSplatDesc* d, int R) {
+  XLayout x;
+  x.npass = (d->flags & LSI_COMPOSE) ? 1 : d->L;
+  x.nbands = (d->Ht + R - 1) / R;
+  x.count_bytes =
+      (((size_t)x.npass * d->B * x.nbands * sizeof(int)) + 255) / 256 * 256;
+  x.part_bytes = (size_t)x.npass * d->B * x.nbands * 2 * d->Wt * 16;
+  return x;
+}
+
+size_t lsi_stream_workspace_bytes(const LsiSplatDesc* d) {
+  const XLayout x = stream_exchange_layout(d, 1);  // worst case: 1-row bands
+  return x.count_bytes + x.part_bytes;
+}
+
+// Band height, waves and windows per workgroup.  One workgroup runs per CU at
+// a time (registers), so the cost model is: rounds of workgroups x (fixed
+// prologue/epilogue + per-step barriers and merge + the longest chain of tasks
+// on a SIMD).  Units: shader cycles, fitted to tools/phase_probe.py timelines.
+static int stream_plan(const LsiSplatDesc* d, int wmax, StreamCfg* cfg,
+                       int* nw_out) {
+  const int nseg = (d->W + SEG - 1) / SEG;
+  const int tpw_override = (d->reserved >> 12) & 0xf;  // experiments only
+  double best = -1.0;
+  int bR = 0, bnw = 0, btpw = 0, bx = 0;
+  const int layers = (d->flags & LSI_COMPOSE) ? d->L : 1;
+  const int npass = (d->flags & LSI_COMPOSE) ? 1 : d->L;
+  const int force_mode = (d->reserved >> 16) & 3;  // experiments: 1 halo, 2 exchange
+  for (int xch = 0; xch <= 1; ++xch) {
+    if (force_mode && xch != force_mode - 1) continue;
+    for (int R = 1; R <= 64; R *= 2) {
+      if (d->tune_rows > 0 && R != d->tune_rows) continue;
+      if (d->tune_rows <= 0 && R > 1 && R / 2 >= d->Ht) break;
+      const long nwg = (long)((d->Ht + R - 1) / R) * d->B;
+      const long rounds = (nwg + 255) / 256;
+      // source rows per band ~ R / s (one more target row's worth when the
+      // band re-reads its halo); one task per (row, 256-pixel segment)
+      const int ntask =
+          (int)ceilf((float)(R + 1 - xch) / d->trg_downsampling) * nseg;
+      // a task alone on a SIMD is latency-bound (~500 cycles per pixel
+      // iteration: two dependent LDS round trips); the CU's four SIMDs issue
+      // one pixel iteration per ~42 cycles when enough waves share them
+      const double t_lat = layers * 4 * 500.0, t_issue = layers * 4 * 42.5;
+      for (int c = MAXNW; c >= 4; --c) {
+        if (d->tune_threads > 0 && c != (d->tune_threads + 63) / 64) continue;
+        for (int t = 1; t <= 8 && c * t <= 64; ++t) {
+          if (tpw_override && t != tpw_override) continue;
+          if (stream_lds_bytes(d, R + xch, c, wmax, t) > 156 * 1024) break;
+          const int steps = (ntask + c * t - 1) / (c * t);
+          const double per_step = (double)ntask / steps;  // tasks in a step
+          // tickets balance the waves; the step still ends ~a third of a
+          // wave's share after the average wave (measured), then merges
+          const double step_cost = 6000.0 + 0.35 * (per_step / c) * t_lat;
+          const double xpass =
+              fmax((double)ntask / c * t_lat, ntask * t_issue) + 0.5 * t_lat;
+          const double est =
+              (double)rounds *
+              (8000.0 +
+               npass * (3000.0 + 6500.0 * xch + steps * step_cost + xpass));
+          if (best < 0.0 || est < best) {
+            best = est; bR = R; bnw = c; btpw = t; bx = xch;
+          }
+        }
+      }
+    }
+  }
+  if (bnw == 0) return LSI_EINVAL;
+  cfg->R = bR;
+  cfg->tpw = btpw;
+  cfg->exchange = bx;
+  *nw_out = bnw;
+  static const bool verbose = getenv("LSI_STREAM_VERBOSE") != nullptr;
+  if (verbose)
+    fprintf(stderr, "lsi stream plan: R=%d waves=%d windows/wave=%d %s est=%.0f "
+            "cycles lds=%zu\n", bR, bnw, btpw, bx ? "exchange" : "halo", best,
+            stream_lds_bytes(d, bR + bx, bnw, wmax, btpw));
+  return LSI_OK;
+}
+
 int lsi_stream_launch(const SplatArgs& a, hipStream_t stream) {
   const LsiSplatDesc* d = &a.d;
   const int layout = tex_layout(d);
@@ -765,53 +969,43 @@ int lsi_stream_launch(const SplatArgs& a, hipStream_t stream) {
   if ((d->tune_window & ~LSI_STREAM_SIMPLE_BIT) <= 0)
     return LSI_EINVAL;  // from lsi_stream_ok
   const int NB = (d->Wt + 63) / 64;
-  const int nseg = (d->W + SEG - 1) / SEG;
   StreamCfg cfg;
   cfg.wmax = d->tune_window & ~LSI_STREAM_SIMPLE_BIT;
-  int R = d->tune_rows;
-  if (R <= 0) {  // tallest band that still gives >= 256 workgroups
-    R = 1;
-    for (int c = 2; c <= 16; c *= 2) {
-      if ((long)((d->Ht + c - 1) / c) * d->B < 256) break;
-      R = c;
-    }
-  }
-  const int tpw_override = (d->reserved >> 8) & 0xff;  // experiments only
-  int nw = 0, tpw = 1;
-  for (;;) {
-    // source rows per band ~ (R + 1) / s; one task per (row, segment)
-    const int ntask =
-        (int)ceilf((float)(R + 1) / d->trg_downsampling) * nseg;
-    long best = -1;
-    nw = 0;
-    for (int c = MAXNW; c >= 4; --c) {
-      if (d->tune_threads > 0 && c != (d->tune_threads + 63) / 64) continue;
-      if (R * NB > MAXU * c) continue;
-      for (int t = 1; t <= 6 && c * t <= 64; ++t) {
-        if (tpw_override && t != tpw_override) continue;
-        if (stream_lds_bytes(d, R, c, cfg.wmax, t) > 150 * 1024) break;
-        const int steps = (ntask + c * t - 1) / (c * t);
-        // shortest per-wave chain of tasks, then fewest barrier rounds, then
-        // more waves (idle waves are free; busy ones hide each other's latency)
-        const long score = -(long)steps * t * 1000000 - (long)steps * 1000 + c;
-        if (nw == 0 || score > best) { best = score; nw = c; tpw = t; }
-      }
-    }
-    if (nw > 0) break;
-    if (R == 1) return LSI_EINVAL;
-    R /= 2;
-  }
+  int nw = 0;
+  if (stream_plan(d, cfg.wmax, &cfg, &nw) != LSI_OK) return LSI_EINVAL;
+  const int R = cfg.R, tpw = cfg.tpw;
   const int threads = nw * 64;
-  const size_t lds = stream_lds_bytes(d, R, nw, cfg.wmax, tpw);
+  const size_t lds = stream_lds_bytes(d, R + cfg.exchange, nw, cfg.wmax, tpw);
   if (lds > 160 * 1024) return LSI_EINVAL;
-  cfg.tpw = tpw;
-  cfg.R = R;
   cfg.cap = stream_cap(nw, tpw);
   cfg.nb = NB;
   cfg.steps_per_chunk = cfg.cap / (nw * tpw);
   cfg.inv_nb = 1.0f / (float)NB;
   cfg.inv_nwin = 1.0f / (float)(nw * tpw);
   cfg.inv_gx = 1.0f / (float)((d->Ht + R - 1) / R);
+  // boundary-row exchange area
+  const XLayout x = stream_exchange_layout(d, R);
+  if (!a.canvas) return LSI_ENULL;
+  // the counters keep the place they have with 1-row bands, whatever R is: a
+  // kept workspace (LSI_WS_KEEP) then never sees partial rows where a later
+  // call with the same dimensions looks for zeroed counters
+  const size_t part_off = stream_exchange_layout(d, 1).count_bytes;
+  if (a.ws_bytes < part_off + x.part_bytes) return LSI_EWORKSPACE;
+  if (!aligned16(a.canvas)) return LSI_EINVAL;
+  cfg.xcount = reinterpret_cast<int*>(a.canvas);
+  cfg.xpart = reinterpret_cast<float4*>(reinterpret_cast<char*>(a.canvas) +
+                                        part_off);
+  cfg.tstamps = nullptr;
+  if (d->reserved & 4) {  // phase probe: stamps after the regular workspace
+    const size_t off = (lsi_splat_workspace_bytes(d) + 255) / 256 * 256;
+    if (a.ws_bytes < off + (size_t)x.nbands * d->B * 32 * 8) return LSI_EWORKSPACE;
+    cfg.tstamps = reinterpret_cast<long long*>(
+        reinterpret_cast<char*>(a.canvas) + off);
+  }
+  if (!(d->flags & LSI_WS_KEEP)) {
+    if (hipMemsetAsync(a.canvas, 0, x.count_bytes, stream) != hipSuccess)
+      return LSI_ELAUNCH;
+  }
   dim3 grid((d->Ht + R - 1) / R, d->B);
   const bool simple = (d->tune_window & LSI_STREAM_SIMPLE_BIT) != 0;
   const void* fn;

@@ -13,7 +13,7 @@ _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SO_PATH = os.path.join(_PKG, 'liblsi_hip.so')
 
 LSI_OK = 0
-LSI_COMPOSE, LSI_WANT_DISP, LSI_HAS_MASK = 1, 2, 4
+LSI_COMPOSE, LSI_WANT_DISP, LSI_HAS_MASK, LSI_WS_KEEP = 1, 2, 4, 8
 LSI_PATH_AUTO, LSI_PATH_ATOMIC, LSI_PATH_ROWBAND, LSI_PATH_STREAM = 0, 1, 2, 3
 PATH_NAMES = {1: 'atomic', 2: 'rowband', 3: 'stream'}
 

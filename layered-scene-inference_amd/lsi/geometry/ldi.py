@@ -78,6 +78,24 @@ def select_path(desc, mat_host, path='auto'):
   return desc.path
 
 
+_WS_CACHE = {}
+
+
+def _stream_workspace(desc, dev):
+  """Zero-filled once, then kept by the library (lsi_hip.h, LSI_WS_KEEP): one
+  buffer per (device, stream, call geometry); calls on a stream are ordered."""
+  need = int(_C.lib().lsi_splat_workspace_bytes(ctypes.byref(desc)))
+  key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, desc.L, desc.B,
+         desc.Ht, desc.Wt, desc.flags & ~_C.LSI_WS_KEEP)
+  ws = _WS_CACHE.get(key)
+  if ws is None:
+    if len(_WS_CACHE) >= 16:  # a handful of shapes per process is the norm
+      _WS_CACHE.clear()
+    ws = torch.zeros((need,), dtype=torch.uint8, device=dev)
+    _WS_CACHE[key] = ws
+  return ws, ws.numel()
+
+
 class _ForwardSplat(torch.autograd.Function):
   """lsi_splat_fwd / lsi_splat_bwd (include/lsi_hip.h)."""
 
@@ -116,6 +134,9 @@ class _ForwardSplat(torch.autograd.Function):
     if desc.path == _C.LSI_PATH_ATOMIC:
       ws_bytes = int(lib.lsi_splat_workspace_bytes(ctypes.byref(desc)))
       ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+    elif desc.path == _C.LSI_PATH_STREAM:
+      ws, ws_bytes = _stream_workspace(desc, dev)
+      desc.flags |= _C.LSI_WS_KEEP
     mat = mat.contiguous()
     rc = lib.lsi_splat_fwd(ctypes.byref(desc), _C.ptr(tex), _C.ptr(disp),
                            _C.ptr(mask), _C.ptr(mat), _C.ptr(img), _C.ptr(wts),

@@ -433,3 +433,39 @@ def test_stream_path_rejects_what_it_cannot_render(dev):
     ldi.forward_splat_matrix(
         [torch.tensor(tex2, device=dev), None, torch.tensor(disp2, device=dev)],
         torch.tensor(mat2), path='stream')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('band_rows', [0, 1, 2, 4, 8, 16])
+def test_stream_band_exchange(band_rows, dev):
+  """STREAM path: target rows shared by two row bands are combined through the
+  workspace by whichever band finishes second.  Every band height must give the
+  ATOMIC path's image, and repeated calls (the arrival counters are left zero
+  by the kernel, not cleared per call) must give the same bits every time."""
+  from lsi.geometry import ldi, projection
+  gen = torch.Generator(device='cpu').manual_seed(23)
+  nl, b, h, w = 2, 3, 128, 512
+  tex = torch.rand(nl, b, h, w, 3, generator=gen).to(dev)
+  disp = (0.4 * torch.rand(nl, b, h, w, 1, generator=gen)).to(dev)
+  k = torch.tensor([[0.58 * w, 0, w / 2], [0, 0.58 * w, h / 2], [0, 0, 1.0]])
+  k = k.expand(b, 3, 3)
+  eye = torch.eye(3).expand(b, 3, 3)
+  t = torch.tensor([[-0.532], [0], [0]]).expand(b, 3, 1)
+  mat = projection.forward_projection_matrix(k, k, eye, t)
+  kw = dict(trg_downsampling=0.5, bg_layer_disp=1e-3, max_disp=0.4,
+            zbuf_scale=50)
+  for compose in (True, False):
+    ref_img, ref_wts = ldi.forward_splat_matrix(
+        [tex, None, disp], mat, compose_layers=compose, path='atomic', **kw)
+    first = None
+    for rep in range(6):
+      img, wts = ldi.forward_splat_matrix(
+          [tex, None, disp], mat, compose_layers=compose, path='stream',
+          band_rows=band_rows, **kw)
+      torch.testing.assert_close(img, ref_img, rtol=0, atol=IMG_ATOL)
+      torch.testing.assert_close(wts, ref_wts, rtol=WTS_RTOL, atol=0)
+      if first is None:
+        first = (img.clone(), wts.clone())
+      else:  # a + b == b + a: the order of arrival does not change the bits
+        diff = float((img - first[0]).abs().max())
+        assert diff <= 1e-6, (rep, diff)

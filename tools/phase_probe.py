@@ -12,13 +12,14 @@ dev = torch.device('cuda:0')
 tex, disp, mat = bench.make_inputs(nl, batch, h, w, cams, max_disp, 1000, dev)
 r = bench.Renderer(tex, disp, mat, max_disp, bg, 'stream')
 r.desc.reserved = 4 | flags
+base = (int(_C.lib().lsi_splat_workspace_bytes(ctypes.byref(r.desc))) + 255) // 256 * 256
 nwg = 4096 * 8
-r.ws = torch.zeros((nwg * 32 * 8,), dtype=torch.uint8, device=dev)
+r.ws = torch.zeros((base + nwg * 32 * 8,), dtype=torch.uint8, device=dev)
 r.ws_bytes = r.ws.numel()
 for _ in range(3):
   r.launch()
 torch.cuda.synchronize()
-t = r.ws.view(torch.int64).view(-1, 32).cpu().numpy()
+t = r.ws[base:].view(torch.int64).view(-1, 32).cpu().numpy()
 t = t[t[:, 0] != 0]
 rel = (t - t[:, :1]).astype(np.float64)
 n = int((t[0] != 0).sum())
