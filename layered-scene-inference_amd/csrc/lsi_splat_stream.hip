@@ -287,49 +287,29 @@ __global__ __launch_bounds__(1024) void splat_stream_kernel(SplatArgs a,
   for (int i = tid; i < NW * WMAX; i += T) cnt_all[i] = 0u;
   for (int i = tid; i < rows * Wt; i += T)
     reinterpret_cast<float4*>(extras)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (tid == 0) { yrange[0] = d.H; yrange[1] = -1; yrange[2] = 0; }
+  if (tid == 0) yrange[2] = 0;  // slot tickets (first read after a barrier)
   LSI_TSTAMP();
-  __syncthreads();
-  LSI_TSTAMP();
-  {  // source rows of the band: floor(Y) in [k_lo, k_hi]
-    int lo = d.H, hi = -1;
-    for (int y = tid; y < d.H; y += T) {
-      float nd;
-      const float Y = row_Y(y, nd);
-      if (!finite_f(Y)) continue;
-      const float y0 = floorf(Y);
-      if (y0 >= (float)k_lo && y0 <= (float)k_hi) {
-        lo = min(lo, y); hi = max(hi, y);
-      }
-    }
-    if (hi >= 0) { atomicMin(&yrange[0], lo); atomicMax(&yrange[1], hi); }
-  }
-  __syncthreads();
-  LSI_TSTAMP();
-  const int y_lo = yrange[0], y_hi = yrange[1];
-  const int nsrc = (y_hi >= y_lo) ? (y_hi - y_lo + 1) : 0;
   const int nseg = (W + SEG - 1) / SEG;
   const float inv_nseg = 1.0f / (float)nseg;
-  const float bg = d.bg_wt;
-  const size_t P = (size_t)Ht * Wt;
-
-  const int npass = compose ? 1 : nlayers;
-  const int Lp = compose ? nlayers : 1;
-  for (int pass = 0; pass < npass; ++pass) {
-    const int l_begin = compose ? 0 : pass;
-    const int ntask = nsrc * nseg;
-    const int nstep = div_small(ntask + NWIN - 1, NWIN, cfg.inv_nwin);
-
-    // task table for tasks [tg0, tg0 + CAP): one task per thread
-    auto fill_tasks = [&](int tg0) {
-      for (int t = tid; t < CAP; t += T) {
+  // Source rows of the band: floor(Y(y)) in [k_lo, k_hi].  Y is a Moebius
+  // function of y, monotone where the normaliser is positive, so the rows form
+  // a range whose ends are found by inverting Y and then checking the result
+  // with the exact fp32 Y.  Wave 0 does this and fills the first chunk of the
+  // task table while the other waves clear the tile: the uniform arithmetic is
+  // not repeated by (and does not contend with) the other waves.  Maps that
+  // are decreasing, too flat for fp32 to keep monotone, or not finite at the
+  // ends take the scan further below instead.
+  // task table for tasks [tg0, tg0 + CAP) of ntask, rows from ylo on: one task
+  // per participating thread (threads first, first + stride, ...)
+  auto fill_tasks = [&](int tg0, int first, int stride, int ylo, int ntask) {
+    for (int t = first; t < CAP; t += stride) {
         const int tg = tg0 + t;
         TaskA ta; ta.row0 = -1000000; ta.wy0 = 0.f; ta.wy1 = 0.f; ta.win = 0;
         TaskB tb; tb.nden = 1.0f; tb.rn = 1.0f; tb.y = 0; tb.xs = 0;
         if (tg < ntask) {
           // tg / nseg without an integer division (tg < 2^20: exact in fp32)
           const int yi = (int)(((float)tg + 0.5f) * inv_nseg);
-          const int y = y_lo + yi;
+          const int y = ylo + yi;
           const int xs = (tg - yi * nseg) * SEG;
           const float py = (float)y + 0.5f;
           float nden;
@@ -377,13 +357,95 @@ __global__ __launch_bounds__(1024) void splat_stream_kernel(SplatArgs a,
         taskB[t] = tb;
       }
     };
+  if (wave == 0) {
+    int y_lo = d.H, y_hi = -1;
+    bool ranged = false;
+    {
+      const int H = d.H;
+      float nA, nB;
+      const float YA = row_Y(0, nA), YB = row_Y(H - 1, nB);
+      const bool ok = finite_f(YA) && finite_f(YB) && fabsf(YA) < 65536.0f &&
+                      fabsf(YB) < 65536.0f && nA > 0.0f && nB > 0.0f &&
+                      (H == 1 || (YB - YA) >= 0.0625f * (float)(H - 1));
+      if (ok) {
+        // first row y in [0, H] with Y(y) >= k  (H: none)
+        auto lower = [&](float k, bool& good) {
+          // (k + 0.5)/s = (py*m11 + m12)/(py*m21 + m22)  =>  py
+          const float t = (k + 0.5f) / s;
+          const float den = m[5] - m[9] * t;
+          float py = (m[10] * t - m[6]) / den;
+          if (SIMPLE) py = (t - m[6]) / m[5];
+          int c = finite_f(py) ? (int)fminf(fmaxf(ceilf(py - 0.5f), -1.0f),
+                                            (float)H + 1.0f)
+                               : 0;
+          c = max(0, min(H, c));
+          float nd;
+  #pragma unroll 1
+          for (int it = 0; it < 4; ++it) {
+            if (c > 0 && row_Y(c - 1, nd) >= k) --c;
+            else if (c < H && !(row_Y(c, nd) >= k)) ++c;
+            else break;
+          }
+          good = good && (c == 0 || !(row_Y(c - 1, nd) >= k)) &&
+                 (c == H || row_Y(c, nd) >= k);
+          return c;
+        };
+        bool good = true;
+        const int lo = lower((float)k_lo, good);
+        const int hi = lower((float)(k_hi + 1), good) - 1;
+        if (good) { y_lo = lo; y_hi = hi; ranged = true; }
+      }
+    }
+    if (lane == 0) { yrange[0] = y_lo; yrange[1] = y_hi; yrange[3] = ranged; }
+    if (ranged)
+      fill_tasks(0, lane, 64, y_lo,
+                 ((y_hi >= y_lo) ? (y_hi - y_lo + 1) : 0) * nseg);
+  }
+  LSI_TSTAMP();
+  __syncthreads();
+  LSI_TSTAMP();
+  if (!yrange[3]) {  // general case: every thread tests its rows
+    __syncthreads();  // (everyone has read the flag)
+    if (tid == 0) { yrange[0] = d.H; yrange[1] = -1; }
+    __syncthreads();
+    int lo = d.H, hi = -1;
+    for (int y = tid; y < d.H; y += T) {
+      float nd;
+      const float Y = row_Y(y, nd);
+      if (!finite_f(Y)) continue;
+      const float y0 = floorf(Y);
+      if (y0 >= (float)k_lo && y0 <= (float)k_hi) {
+        lo = min(lo, y); hi = max(hi, y);
+      }
+    }
+    if (hi >= 0) { atomicMin(&yrange[0], lo); atomicMax(&yrange[1], hi); }
+    __syncthreads();
+    const int ylo = yrange[0], yhi = yrange[1];
+    fill_tasks(0, tid, T, ylo, ((yhi >= ylo) ? (yhi - ylo + 1) : 0) * nseg);
+    __syncthreads();
+  }
+  const int y_lo = yrange[0], y_hi = yrange[1];
+  LSI_TSTAMP();
+  const int nsrc = (y_hi >= y_lo) ? (y_hi - y_lo + 1) : 0;
+  const float bg = d.bg_wt;
+  const size_t P = (size_t)Ht * Wt;
+
+  const int npass = compose ? 1 : nlayers;
+  const int Lp = compose ? nlayers : 1;
+  for (int pass = 0; pass < npass; ++pass) {
+    const int l_begin = compose ? 0 : pass;
+    const int ntask = nsrc * nseg;
+    const int nstep = div_small(ntask + NWIN - 1, NWIN, cfg.inv_nwin);
+
     const int steps_per_chunk = cfg.steps_per_chunk;
 
     for (int step = 0, sidx = 0; step < nstep; ++step, ++sidx) {
       if (sidx == steps_per_chunk) sidx = 0;
-      if (sidx == 0) {  // (the previous step's closing barrier protects the table)
-        fill_tasks(step * NWIN);
-        LSI_TSTAMP();
+      // chunk 0 is in the table from the prologue, and still is at the start
+      // of a later pass unless this pass needed more than one chunk
+      if (sidx == 0 && (step > 0 || (pass > 0 && nstep > steps_per_chunk))) {
+        // (the previous step's closing barrier protects the table)
+        fill_tasks(step * NWIN, tid, T, y_lo, ntask);
         __syncthreads();
       }
       LSI_TSTAMP();
@@ -902,6 +964,8 @@ static int stream_plan(const LsiSplatDesc* d, int wmax, StreamCfg* cfg,
                        int* nw_out) {
   const int nseg = (d->W + SEG - 1) / SEG;
   const int tpw_override = (d->reserved >> 12) & 0xf;  // experiments only
+  static const char* cap_env = getenv("LSI_STREAM_LDS_CAP");  // experiments
+  const size_t lds_cap = cap_env ? (size_t)atol(cap_env) : 156 * 1024;
   double best = -1.0;
   int bR = 0, bnw = 0, btpw = 0, bx = 0;
   const int layers = (d->flags & LSI_COMPOSE) ? d->L : 1;
@@ -926,7 +990,7 @@ static int stream_plan(const LsiSplatDesc* d, int wmax, StreamCfg* cfg,
         if (d->tune_threads > 0 && c != (d->tune_threads + 63) / 64) continue;
         for (int t = 1; t <= 8 && c * t <= 64; ++t) {
           if (tpw_override && t != tpw_override) continue;
-          if (stream_lds_bytes(d, R + xch, c, wmax, t) > 156 * 1024) break;
+          if (stream_lds_bytes(d, R + xch, c, wmax, t) > lds_cap) break;
           const int steps = (ntask + c * t - 1) / (c * t);
           const double per_step = (double)ntask / steps;  // tasks in a step
           // tickets balance the waves; the step still ends ~a third of a

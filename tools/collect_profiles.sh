@@ -20,7 +20,7 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o w
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch3 -o f -- python $R/bench.py --workload cfg3 --no-cpu-baseline --steps 20 --warmup 5 --launch eager > /dev/null 2>> $OUT/fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write3 -o w -- python $R/bench.py --workload cfg3 --no-cpu-baseline --steps 20 --warmup 5 --launch eager > /dev/null 2>> $OUT/write.err
 python3 - <<PY
-import csv, glob, json, collections
+import csv, glob, json, collections, re
 out = {}
 def kstats(path):
     rows = list(csv.DictReader(open(path)))
@@ -32,7 +32,8 @@ def pmc(dirname, counter):
     for f in glob.glob("$OUT/%s/*counter_collection.csv" % dirname):
         for row in csv.DictReader(open(f)):
             if 'splat' in row['Kernel_Name'] and row['Counter_Name'] == counter:
-                res[row['Kernel_Name'].split('(')[0][-40:]].append(float(row['Counter_Value']))
+                name = re.search(r'splat_\w+(<[^>]*>)?', row['Kernel_Name']).group(0)
+                res[name].append(float(row['Counter_Value']))
     return {k: {'n': len(v), 'mean': sum(v)/len(v), 'min': min(v), 'max': max(v)} for k, v in res.items()}
 out['FETCH_SIZE_cfg2'] = pmc('fetch', 'FETCH_SIZE'); out['WRITE_SIZE_cfg2'] = pmc('write', 'WRITE_SIZE')
 out['FETCH_SIZE_cfg3'] = pmc('fetch3', 'FETCH_SIZE'); out['WRITE_SIZE_cfg3'] = pmc('write3', 'WRITE_SIZE')

@@ -26,8 +26,10 @@ n = int((t[0] != 0).sum())
 print('workgroups', len(t), 'stamps', n)
 print('median phase stamps (cycles since WG start):', np.median(rel[:, :n], axis=0).astype(int).tolist())
 print('max:', rel[:, :n].max(axis=0).astype(int).tolist())
-print('WG start spread (cycles):', int(t[:, 0].max() - t[:, 0].min()), ' kernel span:', int(t[:, :n].max() - t[:, 0].min()))
-
+st = t[:, 0].astype(np.float64)
+en = t[:, :n].max(axis=1).astype(np.float64)
+print('WG start: p0/p50/p100 since first start:', int(st.min() - st.min()), int(np.median(st) - st.min()), int(st.max() - st.min()),
+      ' WG end p50/p100:', int(np.median(en) - st.min()), int(en.max() - st.min()))
 pw = t[:, 16:32]
 pw = np.where(pw != 0, pw - t[:, :1], 0)
 print('per-wave x-pass end (median over WGs):', np.median(pw, axis=0).astype(int).tolist())
