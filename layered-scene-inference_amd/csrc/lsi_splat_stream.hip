@@ -1049,16 +1049,20 @@ int lsi_stream_launch(const SplatArgs& a, hipStream_t stream) {
   cfg.inv_gx = 1.0f / (float)((d->Ht + R - 1) / R);
   // boundary-row exchange area
   const XLayout x = stream_exchange_layout(d, R);
-  if (!a.canvas) return LSI_ENULL;
+  if (!a.canvas && (cfg.exchange || (d->reserved & 4))) return LSI_ENULL;
   // the counters keep the place they have with 1-row bands, whatever R is: a
   // kept workspace (LSI_WS_KEEP) then never sees partial rows where a later
   // call with the same dimensions looks for zeroed counters
   const size_t part_off = stream_exchange_layout(d, 1).count_bytes;
-  if (a.ws_bytes < part_off + x.part_bytes) return LSI_EWORKSPACE;
-  if (!aligned16(a.canvas)) return LSI_EINVAL;
-  cfg.xcount = reinterpret_cast<int*>(a.canvas);
-  cfg.xpart = reinterpret_cast<float4*>(reinterpret_cast<char*>(a.canvas) +
-                                        part_off);
+  cfg.xcount = nullptr;
+  cfg.xpart = nullptr;
+  if (cfg.exchange) {
+    if (a.ws_bytes < part_off + x.part_bytes) return LSI_EWORKSPACE;
+    if (!aligned16(a.canvas)) return LSI_EINVAL;
+    cfg.xcount = reinterpret_cast<int*>(a.canvas);
+    cfg.xpart = reinterpret_cast<float4*>(reinterpret_cast<char*>(a.canvas) +
+                                          part_off);
+  }
   cfg.tstamps = nullptr;
   if (d->reserved & 4) {  // phase probe: stamps after the regular workspace
     const size_t off = (lsi_splat_workspace_bytes(d) + 255) / 256 * 256;
@@ -1066,7 +1070,7 @@ int lsi_stream_launch(const SplatArgs& a, hipStream_t stream) {
     cfg.tstamps = reinterpret_cast<long long*>(
         reinterpret_cast<char*>(a.canvas) + off);
   }
-  if (!(d->flags & LSI_WS_KEEP)) {
+  if (cfg.exchange && !(d->flags & LSI_WS_KEEP)) {
     if (hipMemsetAsync(a.canvas, 0, x.count_bytes, stream) != hipSuccess)
       return LSI_ELAUNCH;
   }

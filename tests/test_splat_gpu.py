@@ -469,3 +469,64 @@ def test_stream_band_exchange(band_rows, dev):
       else:  # a + b == b + a: the order of arrival does not change the bits
         diff = float((img - first[0]).abs().max())
         assert diff <= 1e-6, (rep, diff)
+
+
+@pytest.mark.gpu
+def test_stream_workspace_contract_through_the_c_abi(dev):
+  """lsi_hip.h: without LSI_WS_KEEP the library clears the arrival counters
+  itself, so a dirty workspace is fine; with it, a workspace zero-filled once is
+  reused by every later call; a too-small workspace is refused."""
+  import ctypes
+  from lsi import _C
+  from lsi.geometry import ldi, projection
+  gen = torch.Generator(device='cpu').manual_seed(5)
+  nl, b, h, w = 2, 2, 64, 256
+  tex = torch.rand(nl, b, h, w, 3, generator=gen).to(dev)
+  disp = (0.4 * torch.rand(nl, b, h, w, 1, generator=gen)).to(dev)
+  k = torch.tensor([[0.58 * w, 0, w / 2], [0, 0.58 * w, h / 2], [0, 0, 1.0]])
+  k = k.expand(b, 3, 3)
+  mat_host = projection.forward_projection_matrix(
+      k, k, torch.eye(3).expand(b, 3, 3),
+      torch.tensor([[-0.532], [0], [0]]).expand(b, 3, 1)).contiguous()
+  mat = mat_host.to(dev)
+  ref_img, ref_wts = ldi.forward_splat_matrix(
+      [tex, None, disp], mat, trg_downsampling=0.5, bg_layer_disp=1e-3,
+      max_disp=0.4, zbuf_scale=50, path='atomic')
+  lib = _C.lib()
+  ht, wt = h // 2, w // 2
+  bg = _C.bg_weight(1e-3, 0.4, 50)
+
+  def run(flags_extra, ws):
+    d = ldi._desc(tex, None, disp, ht, wt, 0.5, 0.4, 50.0, bg,
+                  _C.LSI_COMPOSE | flags_extra, 0, 4)
+    ldi.select_path(d, mat_host, 'stream')
+    d.reserved = 2 << 16            # experiments field: force the exchange bands
+    img = torch.full((1, b, ht, wt, 3), -7.0, device=dev)
+    wts = torch.full((1, b, ht, wt, 1), -7.0, device=dev)
+    rc = lib.lsi_splat_fwd(ctypes.byref(d), _C.ptr(tex), _C.ptr(disp), None,
+                           _C.ptr(mat), _C.ptr(img), _C.ptr(wts), None,
+                           _C.ptr(ws), ws.numel() if ws is not None else 0,
+                           _C.stream_ptr(dev))
+    return rc, img, wts, d
+
+  d0 = ldi._desc(tex, None, disp, ht, wt, 0.5, 0.4, 50.0, bg, _C.LSI_COMPOSE, 0)
+  need = int(lib.lsi_splat_workspace_bytes(ctypes.byref(d0)))
+  dirty = torch.full((need,), 0x5A, dtype=torch.uint8, device=dev)
+  for _ in range(3):                 # library clears the counters per call
+    rc, img, wts, _d = run(0, dirty)
+    assert rc == 0
+    torch.testing.assert_close(img, ref_img, rtol=0, atol=IMG_ATOL)
+    torch.testing.assert_close(wts, ref_wts, rtol=WTS_RTOL, atol=0)
+  kept = torch.zeros((need,), dtype=torch.uint8, device=dev)
+  for _ in range(3):                 # caller keeps a zero-filled workspace
+    rc, img, wts, _d = run(_C.LSI_WS_KEEP, kept)
+    assert rc == 0
+    torch.testing.assert_close(img, ref_img, rtol=0, atol=IMG_ATOL)
+  torch.cuda.synchronize()
+  # the counters are back to zero after every call
+  ncount = 1 * b * ht * 4
+  assert int(kept[:ncount].to(torch.int64).sum()) == 0
+  rc, _, _, _ = run(0, torch.zeros((64,), dtype=torch.uint8, device=dev))
+  assert rc == -3                    # LSI_EWORKSPACE
+  rc, _, _, _ = run(0, None)
+  assert rc == -2                    # LSI_ENULL
