@@ -25,6 +25,7 @@ if _HERE not in sys.path:
   sys.path.insert(0, _HERE)
 
 from lsi.geometry import ldi as ldi_utils  # noqa: E402
+from lsi.geometry import projection  # noqa: E402
 from lsi.loss import loss  # noqa: E402
 from lsi.nnutils import helpers as nn_helpers  # noqa: E402
 from lsi.nnutils import nets  # noqa: E402
@@ -62,6 +63,8 @@ def build_parser():
   a('--bf16', type=_bool, default=False, help='bf16 autocast for the convs')
   a('--channels_last', type=_bool, default=True)
   a('--cpu', type=_bool, default=False, help='CPU run (no splat losses)')
+  a('--hip_graph', type=_bool, default=False,
+    help='capture the training step in a HIP graph (single process)')
   return p
 
 
@@ -116,12 +119,15 @@ class SyntheticPairs(object):
 
   def __init__(self, opts, device, seed):
     self.opts, self.device = opts, device
-    self.gen = torch.Generator(device='cpu').manual_seed(seed)
+    # images are generated where they are consumed (the CPU version of this
+    # generator cost 12-20 ms per batch, a third of a training step)
+    self.gen = torch.Generator(device=device).manual_seed(seed)
 
   def forward(self, bs):
     o = self.opts
     h, w = o.img_height, o.img_width
-    lo = torch.rand((bs, 3, h // 16 + 2, w // 16 + 2), generator=self.gen)
+    lo = torch.rand((bs, 3, h // 16 + 2, w // 16 + 2), generator=self.gen,
+                    device=self.device)
     img = torch.nn.functional.interpolate(lo, size=(h, w + 64), mode='bicubic',
                                           align_corners=False).clamp(0, 1)
     shift = 16  # pixels of parallax of the (single, fronto-parallel) plane
@@ -138,7 +144,7 @@ class SyntheticPairs(object):
     k = k.expand(bs, 3, 3).contiguous()
     rot = torch.eye(3).expand(bs, 3, 3).contiguous()
     t = t.expand(bs, 3, 1).contiguous()
-    return (src.to(self.device), trg.to(self.device), k, k.clone(), rot, t)
+    return (src, trg, k, k.clone(), rot, t)
 
 
 class Trainer(train_utils.Trainer):
@@ -156,11 +162,35 @@ class Trainer(train_utils.Trainer):
   def feed(self):
     return self.data_loader.forward(self.opts.batch_size)
 
-  def compute_losses(self, batch):
-    opts = self.opts
+  def stage(self, batch):
+    """Images to the device; the two src->trg projection matrices are built on
+    the host (tiny), kept there for the kernel-family choice and copied to the
+    device.  plan = what the renderer would choose for these cameras."""
     imgs_src, imgs_trg, k_s, k_t, rot_mat, trans_mat = batch
+    f32 = lambda t: t.detach().to('cpu', torch.float32)
+    k_s, k_t, rot_mat, trans_mat = f32(k_s), f32(k_t), f32(rot_mat), f32(trans_mat)
     inv_rot_mat = nn_helpers.transpose(rot_mat)
     inv_trans_mat = -torch.matmul(inv_rot_mat, trans_mat)
+    mat_trg = projection.forward_projection_matrix(k_s, k_t, rot_mat, trans_mat)
+    mat_src = projection.forward_projection_matrix(k_t, k_s, inv_rot_mat,
+                                                   inv_trans_mat)
+    self.host_mats = {'trg': mat_trg.contiguous(), 'src': mat_src.contiguous()}
+    plan = None
+    if self.device.type == 'cuda':
+      o = self.opts
+      plan = tuple(
+          ldi_utils.plan_key((o.n_layers, imgs_src.shape[0], o.img_height,
+                              o.img_width), o.trg_splat_downsampling,
+                             o.max_disp, self.host_mats[w])
+          for w in ('trg', 'src'))
+    dev = self.device
+    return [imgs_src.to(dev), imgs_trg.to(dev), mat_trg.to(dev),
+            mat_src.to(dev)], plan
+
+  def compute_losses(self, staged):
+    opts = self.opts
+    imgs_src, imgs_trg, mat_trg, mat_src = staged
+    mats = {'trg': mat_trg, 'src': mat_src}
     amp = (torch.autocast('cuda', dtype=torch.bfloat16) if
            (opts.bf16 and self.device.type == 'cuda') else _NullCtx())
     with amp:
@@ -193,15 +223,14 @@ class Trainer(train_utils.Trainer):
         continue
       for which in ('trg', 'src'):
         if which == 'trg':
-          target, l, cams = imgs_trg, ldi_src, (k_s, k_t, rot_mat, trans_mat)
+          target, l = imgs_trg, ldi_src
         else:
-          target, l, cams = imgs_src, ldi_trg, (k_t, k_s, inv_rot_mat,
-                                                inv_trans_mat)
-        recons_splat, _ = ldi_utils.forward_splat(
-            l, self.pixel_coords, *cams, compose_layers=use_compose,
+          target, l = imgs_src, ldi_trg
+        recons_splat, _ = ldi_utils.forward_splat_matrix(
+            l, mats[which], compose_layers=use_compose,
             trg_downsampling=opts.trg_splat_downsampling,
             zbuf_scale=opts.zbuf_scale, bg_layer_disp=opts.bg_layer_disp,
-            max_disp=opts.max_disp)
+            max_disp=opts.max_disp, mat_host=self.host_mats[which])
         term = loss.view_synthesis_loss(recons_splat, target,
                                         opts.splat_bdry_ignore)
         if use_compose:

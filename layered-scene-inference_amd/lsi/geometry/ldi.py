@@ -78,6 +78,20 @@ def select_path(desc, mat_host, path='auto'):
   return desc.path
 
 
+def plan_key(shape, trg_downsampling, max_disp, mat_host):
+  """(kernel family, STREAM window) the renderer would choose for an
+  L x B x H x W LDI and these host matrices: what a captured HIP graph of a
+  training step bakes in (a different key needs a re-capture)."""
+  nl, b, h, w = shape
+  tex = torch.empty((nl, b, h, w, 3), device='meta')
+  disp = torch.empty((nl, b, h, w, 1), device='meta')
+  ht, wt = int(h * trg_downsampling), int(w * trg_downsampling)
+  desc = _desc(tex, None, disp, ht, wt, float(trg_downsampling),
+               float(max_disp), 1.0, 0.0, 0, 0)
+  select_path(desc, mat_host.to(torch.float32), 'auto')
+  return int(desc.path), int(desc.tune_window)
+
+
 _WS_CACHE = {}
 
 

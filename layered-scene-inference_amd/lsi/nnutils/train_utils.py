@@ -63,6 +63,13 @@ class Trainer(object):
   def feed(self):
     raise NotImplementedError
 
+  def stage(self, batch):
+    """Moves one batch to the device.  Returns (staged, plan): `staged` is the
+    list of device tensors compute_losses reads; `plan` is any hashable
+    host-side decision derived from the batch (e.g. which kernel family renders
+    it) that a captured HIP graph bakes in -- a change forces a re-capture."""
+    return [t.to(self.device) for t in batch], None
+
   # ---- harness ---------------------------------------------------------------
   def setup(self, backend=None):
     opts = self.opts
@@ -86,9 +93,19 @@ class Trainer(object):
       self.train_model = DDP(
           self.model, device_ids=[self.local_rank] if use_gpu else None,
           bucket_cap_mb=25, gradient_as_bucket_view=True)
+    # --hip_graph: the whole step (forward, losses, backward, Adam) is captured
+    # once into a HIP graph and replayed; the eager step is launch-bound (about
+    # 1500 kernels).  Single process only: with DDP the step stays eager.
+    self.use_graph = bool(getattr(opts, 'hip_graph', False)) and use_gpu and \
+        self.world == 1
+    self._graph, self._graph_plan, self._static = None, None, None
+    self._graph_warm = 0
     self.optim = torch.optim.Adam(self.model.parameters(),
                                   lr=opts.learning_rate,
-                                  betas=(opts.beta1, 0.999), eps=1e-8)
+                                  betas=(opts.beta1, 0.999), eps=1e-8,
+                                  capturable=self.use_graph)
+    if self.use_graph:
+      self._stream = torch.cuda.Stream(self.device)
     self.resume()
 
   def resume(self):
@@ -114,14 +131,54 @@ class Trainer(object):
     for old in numbered[:-10]:  # max_to_keep=10
       os.remove(old)
 
-  def train_step(self):
-    batch = self.feed()
+  def _eager_step(self, staged):
     self.optim.zero_grad(set_to_none=True)
-    total, scalars = self.compute_losses(batch)
+    total, scalars = self.compute_losses(staged)
     total.backward()
     self.optim.step()
-    self.global_step += 1
     return total, scalars
+
+  def train_step(self):
+    batch = self.feed()
+    staged, plan = self.stage(batch)
+    if not self.use_graph:
+      out = self._eager_step(staged)
+    else:
+      out = self._graph_step(staged, plan)
+    self.global_step += 1
+    return out
+
+  GRAPH_WARMUP = 3  # eager steps (MIOpen find, allocator) before capturing
+
+  def _graph_step(self, staged, plan):
+    """Eager for the first steps, then one captured HIP graph per plan."""
+    cur = torch.cuda.current_stream(self.device)
+    if self._graph is not None and plan == self._graph_plan:
+      for dst, src in zip(self._static, staged):
+        dst.copy_(src)
+      self._graph.replay()
+      return self._graph_out
+    self._stream.wait_stream(cur)
+    with torch.cuda.stream(self._stream):
+      if self._graph_warm < self.GRAPH_WARMUP:
+        out = self._eager_step(staged)
+        self._graph_warm += 1
+      else:
+        # capture: records the step, nothing runs until the replay below
+        self._graph = None
+        self._static = [t.clone() for t in staged]
+        self._graph_plan = plan
+        self.optim.zero_grad(set_to_none=True)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=self._stream):
+          self._graph_out = self._eager_step(self._static)
+        self._graph = graph
+        out = None
+    cur.wait_stream(self._stream)
+    if out is not None:
+      return out
+    self._graph.replay()
+    return self._graph_out
 
   def train(self, log_file=None):
     opts = self.opts
