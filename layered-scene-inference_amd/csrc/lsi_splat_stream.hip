@@ -245,10 +245,14 @@ __global__ __launch_bounds__(1024) void splat_stream_kernel(SplatArgs a,
   for (int k = 0; k < 16; ++k) m[k] = a.M[16 * b + k];
   const float s = d.trg_downsampling;
   const float max_disp = d.max_disp, zscale = d.zbuf_scale;
-  const long tex_sl = d.tex_sl, tex_sb = d.tex_sb, tex_sy = d.tex_sy,
-             tex_sc = d.tex_sc;
-  const long disp_sl = d.disp_sl, disp_sb = d.disp_sb, disp_sy = d.disp_sy;
-  const long mask_sl = d.mask_sl, mask_sb = d.mask_sb, mask_sy = d.mask_sy;
+  // element strides fit in 32 bits (checked by lsi_stream_ok): half the scalar
+  // registers of the 64-bit descriptor fields
+  const int tex_sl = (int)d.tex_sl, tex_sb = (int)d.tex_sb,
+            tex_sy = (int)d.tex_sy, tex_sc = (int)d.tex_sc;
+  const int disp_sl = (int)d.disp_sl, disp_sb = (int)d.disp_sb,
+            disp_sy = (int)d.disp_sy;
+  const int mask_sl = (int)d.mask_sl, mask_sb = (int)d.mask_sb,
+            mask_sy = (int)d.mask_sy;
   const float* __restrict__ g_tex = a.tex;
   const float* __restrict__ g_disp = a.disp;
   const float* __restrict__ g_mask = a.mask;
@@ -488,12 +492,13 @@ __global__ __launch_bounds__(1024) void splat_stream_kernel(SplatArgs a,
 
         struct PxData { float4 d4, t0, t1, t2, m4; };
         // per-lane source pointers, advanced by one layer stride per load
-        const float* p_disp = g_disp + l_begin * disp_sl + b * disp_sb +
-                              y * disp_sy + x;
-        const float* p_tex = g_tex + l_begin * tex_sl + b * tex_sb + y * tex_sy +
-                             (LAYOUT == 0 ? 3 * x : x);
-        const float* p_mask = has_mask ? g_mask + l_begin * mask_sl +
-                                             b * mask_sb + y * mask_sy + x
+        const float* p_disp = g_disp + (long)l_begin * disp_sl +
+                              (long)b * disp_sb + (long)y * disp_sy + x;
+        const float* p_tex = g_tex + (long)l_begin * tex_sl + (long)b * tex_sb +
+                             (long)y * tex_sy + (LAYOUT == 0 ? 3 * x : x);
+        const float* p_mask = has_mask ? g_mask + (long)l_begin * mask_sl +
+                                             (long)b * mask_sb +
+                                             (long)y * mask_sy + x
                                        : nullptr;
         auto load_layer = [&](PxData& o) {
           if (inrange) {
@@ -637,6 +642,18 @@ __global__ __launch_bounds__(1024) void splat_stream_kernel(SplatArgs a,
             // left-cell offset in the window (+-Inf saturates; NaN gives
             // offset 0 but both its side weights are then clamped to 0 below)
             const int cl = (int)(x0 - wlo_f);
+#ifdef LSI_EXPERIMENT_NOCHECK  // timing experiment only: results are wrong
+            {
+              float4* cellx = rb + (cl & 127);
+              if (inrange) {
+                cellx[0] = f4_fma(cellx[0], V, w0);
+                LSI_COMPILER_FENCE();
+                cellx[1] = f4_fma(cellx[1], V, w1);
+              }
+              LSI_COMPILER_FENCE();
+              continue;
+            }
+#endif
             // in-window lanes: both cells inside the (in-image) window.  Each
             // ballot is taken straight from one compare; the masks are
             // combined with scalar ops.
@@ -907,6 +924,13 @@ extern "C" int lsi_stream_ok(const LsiSplatDesc* d, const float* M) {
   if (d->flags & LSI_WANT_DISP) return 0;
   if (d->W % 4 != 0) return 0;
   if (d->Wt > 32767) return 0;  // window origin is kept in 16 bits
+  {  // the kernel keeps element strides in 32 bits
+    const int64_t st[] = {d->tex_sl, d->tex_sb, d->tex_sy, d->tex_sc, d->disp_sl,
+                          d->disp_sb, d->disp_sy, d->mask_sl, d->mask_sb,
+                          d->mask_sy};
+    for (int64_t v : st)
+      if (v < 0 || v > 0x7fffffffLL) return 0;
+  }
   if (tex_layout(d) < 0) return 0;
   if (d->disp_sx != 1 || d->disp_sy % 4 || d->disp_sb % 4 || d->disp_sl % 4)
     return 0;
