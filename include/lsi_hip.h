@@ -59,8 +59,8 @@ extern "C" {
 #define LSI_PATH_STREAM 3    /* row-uniform projections (additionally         */
                              /* M[b][1][0] == M[b][2][0] == 0: rectified      */
                              /* stereo): wave-private LDS row windows updated */
-                             /* by plain read-modify-write, merged into       */
-                             /* register accumulators -- lsi_stream_ok.       */
+                             /* by plain read-modify-write, merged into an    */
+                             /* LDS tile of the band -- lsi_stream_ok.        */
 
 typedef void* lsi_stream_t; /* hipStream_t */
 
@@ -85,6 +85,8 @@ typedef struct LsiSplatDesc {
   int32_t path;
   /* Tuning knobs, 0 = library default: target rows per workgroup, threads   */
   /* per workgroup, and (STREAM) LDS window cells per wave = lsi_stream_ok(). */
+  /* reserved: 0.  (tools/ set timing-experiment bits in it; results may then */
+  /* be wrong -- see the `dbg` uses in csrc/lsi_splat_stream.hip.)            */
   int32_t tune_rows, tune_threads, tune_window, reserved;
 } LsiSplatDesc;
 

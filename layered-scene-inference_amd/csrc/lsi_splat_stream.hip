@@ -14,27 +14,31 @@
 // 1e-3 clamp on the product (sampling.py:218-222), which is honoured exactly by
 // routing the rare affected corners through an exact slow path.
 //
-// Structure.  Workgroup = (band of R target rows, batch element b), NW waves.
-//   task  = (source row y, 256-pixel segment j), all layers of the pass; every
-//           step each wave runs one task:
-//     x-pass  lanes load 4 consecutive pixels (dwordx4), project them, and add
-//             V*wx0 / V*wx1 (V = (r,g,b,1)*pixel weight) into the wave's
-//             PRIVATE window of float4 cells in LDS by plain RMW.  Lanes are 4
-//             pixels apart, so their cells are distinct whenever floor(X) is
-//             strictly increasing across the wave (checked); otherwise the
-//             lanes are ranked per cell with an integer LDS atomic and the RMW
-//             is issued rank by rank.
+// Structure.  Workgroup = (band of target rows, batch element b), NW <= 16 waves.
+//   task  = (source row y, 256-pixel segment j), all layers of the pass.
+//     prologue wave 0 finds the band's source rows (analytic inverse of Y(y),
+//             verified with the exact fp32 Y) and fills the task table while
+//             the other waves clear the band's tile.
+//     x-pass  waves draw tasks from a ticket counter.  Lanes load 4 consecutive
+//             pixels (dwordx4), project them, and add V*wx0 / V*wx1
+//             (V = (r,g,b,1)*pixel weight) into the task's PRIVATE window of
+//             float4 cells in LDS by plain RMW.  Lanes are 4 pixels apart, so
+//             their cells are distinct whenever floor(X) is strictly
+//             increasing across the wave (checked); otherwise the lanes are
+//             ranked per cell with an integer LDS atomic and the RMW is issued
+//             rank by rank.
 //     barrier
-//     merge   every target cell of the band is owned by one lane, which keeps
-//             its accumulator in REGISTERS and adds window[cell] * wy of each
-//             task that touches its row.  No shared accumulation tile, no
-//             locks, deterministic summation order.
-//     barrier
+//     merge   every 64-cell unit of the band's LDS tile is owned by one wave,
+//             which adds window[cell] * wy of each task that touches its row
+//             (deterministic summation order).
+//     barrier (only if another step follows)
 //   Corners that the factorisation cannot represent exactly (clamped products,
 //   cells outside the window because the disparity leaves [0, max_disp]) are
-//   added with fp32 LDS atomics into a small `extras` tile -- exact for any
-//   input, slow only when such corners are common.
-//   epilogue: (acc + extras + background) normalised, each output written once.
+//   added to the tile with fp32 LDS atomics -- exact for any input, slow only
+//   when such corners are common.
+//   epilogue: (tile + background) normalised, each output written once.  With
+//   source-row bands (cfg.exchange) the first and last tile rows are shared
+//   with the neighbouring bands and combined through the workspace.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
