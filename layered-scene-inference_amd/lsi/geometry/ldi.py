@@ -137,6 +137,7 @@ class _ForwardSplat(torch.autograd.Function):
     desc = _desc(tex, mask, disp, ht, wt, float(s), float(cfg['max_disp']),
                  float(cfg['zbuf_scale']), bg_wt, flags, 0,
                  cfg.get('band_rows', 0), cfg.get('threads', 0))
+    desc.reserved = int(cfg.get('experiment', 0))
     select_path(desc, mat_host, cfg.get('path', 'auto'))
     nlo = 1 if cfg['compose_layers'] else nl
     img = torch.empty((nlo, b, ht, wt, 3), dtype=torch.float32, device=dev)
@@ -194,12 +195,14 @@ class _ForwardSplat(torch.autograd.Function):
 def forward_splat_matrix(ldi_src, src2trg_mat, compose_layers=True,
                          compute_trg_disp=False, trg_downsampling=1,
                          bg_layer_disp=0, max_disp=1, zbuf_scale=10,
-                         mat_host=None, path='auto', band_rows=0, threads=0):
+                         mat_host=None, path='auto', band_rows=0, threads=0,
+                         experiment=0):
   """forward_splat with the B x 4 x 4 src->trg projection matrix given as data.
 
   `mat_host` (optional CPU copy of the matrices) lets the row-band LDS path be
   selected without a device->host copy; when omitted and `src2trg_mat` is on the
-  GPU it is fetched once (one small synchronising copy).
+  GPU it is fetched once (one small synchronising copy).  `band_rows`,
+  `threads` and `experiment` (LsiSplatDesc.reserved) are tuning/test knobs.
   """
   tex, mask, disp = ldi_src
   if mat_host is None and path != 'atomic':
@@ -209,7 +212,7 @@ def forward_splat_matrix(ldi_src, src2trg_mat, compose_layers=True,
              compute_trg_disp=bool(compute_trg_disp),
              trg_downsampling=trg_downsampling, bg_layer_disp=bg_layer_disp,
              max_disp=max_disp, zbuf_scale=zbuf_scale, path=path,
-             band_rows=band_rows, threads=threads)
+             band_rows=band_rows, threads=threads, experiment=experiment)
   img, wts, dsp = _ForwardSplat.apply(tex, mask, disp, mat, mat_host, cfg)
   if compute_trg_disp:
     return img, wts, dsp

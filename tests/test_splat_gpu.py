@@ -436,6 +436,35 @@ def test_stream_path_rejects_what_it_cannot_render(dev):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('mode', [1, 2])          # 1: halo bands, 2: exchange
+@pytest.mark.parametrize('band_rows', [1, 4, 16])
+def test_stream_bands_that_do_not_divide_the_image(band_rows, mode, dev):
+  """66 target rows in bands of 4 or 16: the last band is partial, in both band
+  decompositions (forced through the experiments field)."""
+  from lsi.geometry import ldi, projection
+  gen = torch.Generator(device='cpu').manual_seed(29)
+  nl, b, h, w = 2, 2, 132, 260
+  tex = torch.rand(nl, b, h, w, 3, generator=gen).to(dev)
+  disp = (0.4 * torch.rand(nl, b, h, w, 1, generator=gen)).to(dev)
+  k = torch.tensor([[0.58 * w, 0, w / 2], [0, 0.58 * w, h / 2], [0, 0, 1.0]])
+  k = k.expand(b, 3, 3)
+  mat = projection.forward_projection_matrix(
+      k, k, torch.eye(3).expand(b, 3, 3),
+      torch.tensor([[-0.532], [0], [0]]).expand(b, 3, 1))
+  kw = dict(trg_downsampling=0.5, bg_layer_disp=1e-3, max_disp=0.4,
+            zbuf_scale=50)
+  for compose in (True, False):
+    ref_img, ref_wts = ldi.forward_splat_matrix(
+        [tex, None, disp], mat, compose_layers=compose, path='atomic', **kw)
+    for _ in range(2):
+      img, wts = ldi.forward_splat_matrix(
+          [tex, None, disp], mat, compose_layers=compose, path='stream',
+          band_rows=band_rows, experiment=mode << 16, **kw)
+      torch.testing.assert_close(img, ref_img, rtol=0, atol=IMG_ATOL)
+      torch.testing.assert_close(wts, ref_wts, rtol=WTS_RTOL, atol=0)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('band_rows', [0, 1, 2, 4, 8, 16])
 def test_stream_band_exchange(band_rows, dev):
   """STREAM path: target rows shared by two row bands are combined through the
@@ -461,7 +490,7 @@ def test_stream_band_exchange(band_rows, dev):
     for rep in range(6):
       img, wts = ldi.forward_splat_matrix(
           [tex, None, disp], mat, compose_layers=compose, path='stream',
-          band_rows=band_rows, **kw)
+          band_rows=band_rows, experiment=2 << 16, **kw)  # exchange bands
       torch.testing.assert_close(img, ref_img, rtol=0, atol=IMG_ATOL)
       torch.testing.assert_close(wts, ref_wts, rtol=WTS_RTOL, atol=0)
       if first is None:
