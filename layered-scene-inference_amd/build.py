@@ -43,25 +43,35 @@ def _stale(target, deps):
   return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
+SO_HOOKS = os.path.join(PKG, 'liblsi_hip_hooks.so')
+
+
+def build(force=False, verbose=False, hooks=False):
+  """hooks=True builds liblsi_hip_hooks.so: the same library with the stream
+  kernel's timing-experiment hooks compiled in (tools/phase_probe.py,
+  bench.py --debug-flags; select it with LSI_HIP_LIB=hooks)."""
   srcs = [os.path.join(CSRC, s) for s in SOURCES
           if os.path.exists(os.path.join(CSRC, s))]
+  so = SO_HOOKS if hooks else SO
+  ext = '.hooks.o' if hooks else '.o'
+  flags = HIPCC_FLAGS + (['-DLSI_STREAM_HOOKS=1'] if hooks else [])
   objs = []
   for src in srcs:
-    obj = src[:-4] + '.o'
+    obj = src[:-4] + ext
     if force or _stale(obj, [src] + HEADERS):
-      cmd = [hipcc()] + HIPCC_FLAGS + ['-c', src, '-o', obj]
+      cmd = [hipcc()] + flags + ['-c', src, '-o', obj]
       if verbose:
         print(' '.join(cmd))
       subprocess.check_call(cmd)
     objs.append(obj)
-  if force or _stale(SO, objs):
-    cmd = [hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', SO] + objs
+  if force or _stale(so, objs):
+    cmd = [hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', so] + objs
     if verbose:
       print(' '.join(cmd))
     subprocess.check_call(cmd)
-  return SO
+  return so
 
 
 if __name__ == '__main__':
-  print(build(force='--force' in sys.argv, verbose=True))
+  print(build(force='--force' in sys.argv, verbose=True,
+              hooks='--hooks' in sys.argv))

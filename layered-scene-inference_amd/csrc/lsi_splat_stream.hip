@@ -51,6 +51,10 @@
 
 #pragma clang fp contract(off)
 
+#ifndef LSI_STREAM_HOOKS
+#define LSI_STREAM_HOOKS 0
+#endif
+
 using namespace lsi;
 
 namespace {
@@ -74,7 +78,7 @@ struct __attribute__((aligned(16))) TaskB {
   int y, xs;       // source row, first source pixel of the segment
 };
 
-struct StreamCfg {
+struct alignas(16) StreamCfg {  // (kernarg offset: see epilogue_args)
   int R;      // target rows per workgroup
   int wmax;   // window cells per task
   int tpw;    // tasks (windows) per wave per step
@@ -178,6 +182,30 @@ __device__ __forceinline__ void slow_corners(float* extras, float4 V, float x0,
   }
 }
 
+// Kernel arguments that only the epilogue needs, fetched from the kernarg
+// segment where they are used (scalar loads, ~200 cycles once per pass) instead
+// of living in scalar registers through the whole kernel: the kernel needs more
+// uniform values than there are SGPRs, and every spilled one costs v_readlane /
+// v_writelane instructions in code all waves execute.
+typedef const __attribute__((address_space(4))) char* KernargPtr;
+struct EpilogueArgs {
+  float* out_img; float* out_wts; int* xcount; float4* xpart; float bg; int B;
+};
+__device__ __forceinline__ EpilogueArgs epilogue_args() {
+  KernargPtr ka = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(ka));  // opaque here: the loads below are not hoisted
+  typedef const __attribute__((address_space(4))) SplatArgs* AP;
+  typedef const __attribute__((address_space(4))) StreamCfg* CP;
+  AP ap = (AP)ka;
+  CP cp = (CP)(ka + ((sizeof(SplatArgs) + alignof(StreamCfg) - 1) &
+                     ~(alignof(StreamCfg) - 1)));
+  EpilogueArgs e;
+  e.out_img = ap->out_img; e.out_wts = ap->out_wts;
+  e.bg = ap->d.bg_wt; e.B = ap->d.B;
+  e.xcount = cp->xcount; e.xpart = cp->xpart;
+  return e;
+}
+
 // SIMPLE: the normaliser is exactly 1 and row 3 of M is (0,0,0,1) for every
 // batch element (rectified stereo): u = q0 and D = d with no division.
 template <int LAYOUT, bool SIMPLE>  // LAYOUT 0: channels-last RGB, 1: planar
@@ -260,14 +288,21 @@ __global__ __launch_bounds__(1024) void splat_stream_kernel(SplatArgs a,
   const float* __restrict__ g_tex = a.tex;
   const float* __restrict__ g_disp = a.disp;
   const float* __restrict__ g_mask = a.mask;
+  // Timing-experiment hooks (tools/phase_probe.py, bench.py --debug-flags) are
+  // compiled only into the instrumented build (-DLSI_STREAM_HOOKS=1): they cost
+  // a dozen scalar registers the production kernel cannot spare.
+#if LSI_STREAM_HOOKS
   const int dbg = d.reserved;
+#else
+  constexpr int dbg = 0;
+#endif
   const int nlayers = d.L;
   const float xmax = (float)Wt - 1.0f, ymax = (float)Ht - 1.0f;
   const bool has_mask = d.flags & LSI_HAS_MASK;
   const bool compose = d.flags & LSI_COMPOSE;
   const float inv_md = div_rn(1.0f, max_disp);
 
-  long long* tdbg = (a.d.reserved & 4)
+  long long* tdbg = (dbg & 4)
                         ? cfg.tstamps + ((size_t)b * gridDim.x + band) * 32
                         : nullptr;
   int tslot = 0;
@@ -435,7 +470,6 @@ __global__ __launch_bounds__(1024) void splat_stream_kernel(SplatArgs a,
   const int y_lo = yrange[0], y_hi = yrange[1];
   LSI_TSTAMP();
   const int nsrc = (y_hi >= y_lo) ? (y_hi - y_lo + 1) : 0;
-  const float bg = d.bg_wt;
   const size_t P = (size_t)Ht * Wt;
 
   const int npass = compose ? 1 : nlayers;
@@ -801,23 +835,24 @@ __global__ __launch_bounds__(1024) void splat_stream_kernel(SplatArgs a,
 
     // ================= epilogue for this pass ===============================
     // (each wave finishes the units it merged: no barrier needed before)
-    const float lbg = compose ? (float)nlayers * bg : bg;
+    const EpilogueArgs ea = epilogue_args();
+    const float lbg = compose ? (float)nlayers * ea.bg : ea.bg;
     const int lo_ = compose ? 0 : pass;
     auto finish = [&](int r, int cell, float4 A) {  // normalise and store
       const float A0 = A.x + lbg, A1 = A.y + lbg, A2 = A.z + lbg;
       const float Wsum = A.w + lbg;
       const float wd = safe_den(Wsum);
       const size_t o =
-          ((size_t)lo_ * d.B + b) * P + (size_t)(row0 + r) * Wt + cell;
-      a.out_img[3 * o + 0] = div_rn(A0, wd);
-      a.out_img[3 * o + 1] = div_rn(A1, wd);
-      a.out_img[3 * o + 2] = div_rn(A2, wd);
-      a.out_wts[o] = Wsum;
+          ((size_t)lo_ * ea.B + b) * P + (size_t)(row0 + r) * Wt + cell;
+      ea.out_img[3 * o + 0] = div_rn(A0, wd);
+      ea.out_img[3 * o + 1] = div_rn(A1, wd);
+      ea.out_img[3 * o + 2] = div_rn(A2, wd);
+      ea.out_wts[o] = Wsum;
     };
     // boundary j (between bands j-1 and j): counter and two partial rows
-    const size_t xb = ((size_t)pass * d.B + b) * nbands;
+    const size_t xb = ((size_t)pass * ea.B + b) * nbands;
     auto xrow = [&](int j, int side) {
-      return cfg.xpart + ((xb + j) * 2 + side) * (size_t)Wt;
+      return ea.xpart + ((xb + j) * 2 + side) * (size_t)Wt;
     };
     for (int unit = wave; unit < nunits; unit += NW) {
       const int r = div_small(unit, NB, cfg.inv_nb);
@@ -843,12 +878,12 @@ __global__ __launch_bounds__(1024) void splat_stream_kernel(SplatArgs a,
       __syncthreads();
       if (tid == 0) {
         yrange[4] = top_shared
-                        ? __hip_atomic_fetch_add(&cfg.xcount[xb + band], 1,
+                        ? __hip_atomic_fetch_add(&ea.xcount[xb + band], 1,
                                                  __ATOMIC_RELAXED,
                                                  __HIP_MEMORY_SCOPE_AGENT)
                         : 0;
         yrange[5] = bot_shared
-                        ? __hip_atomic_fetch_add(&cfg.xcount[xb + band + 1], 1,
+                        ? __hip_atomic_fetch_add(&ea.xcount[xb + band + 1], 1,
                                                  __ATOMIC_RELAXED,
                                                  __HIP_MEMORY_SCOPE_AGENT)
                         : 0;
@@ -872,10 +907,10 @@ __global__ __launch_bounds__(1024) void splat_stream_kernel(SplatArgs a,
         }
         if (tid == 0) {  // leave the counters zero for the next call
           if (fin_top)
-            __hip_atomic_store(&cfg.xcount[xb + band], 0, __ATOMIC_RELAXED,
+            __hip_atomic_store(&ea.xcount[xb + band], 0, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
           if (fin_bot)
-            __hip_atomic_store(&cfg.xcount[xb + band + 1], 0, __ATOMIC_RELAXED,
+            __hip_atomic_store(&ea.xcount[xb + band + 1], 0, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
         }
       }

@@ -10,7 +10,11 @@ import os
 import torch
 
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SO_PATH = os.path.join(_PKG, 'liblsi_hip.so')
+# LSI_HIP_LIB=hooks selects the instrumented build (build.py --hooks) whose
+# stream kernel honours the timing-experiment bits of LsiSplatDesc.reserved
+SO_PATH = os.path.join(_PKG, 'liblsi_hip_hooks.so' if
+                       os.environ.get('LSI_HIP_LIB') == 'hooks' else
+                       'liblsi_hip.so')
 
 LSI_OK = 0
 LSI_COMPOSE, LSI_WANT_DISP, LSI_HAS_MASK, LSI_WS_KEEP = 1, 2, 4, 8

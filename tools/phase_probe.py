@@ -1,5 +1,7 @@
-"""Per-workgroup phase timestamps of the stream kernel (debug flag 4)."""
+"""Per-workgroup phase timestamps of the stream kernel (debug flag 4).
+Needs the instrumented library: python layered-scene-inference_amd/build.py --hooks"""
 import ctypes, os, sys
+os.environ['LSI_HIP_LIB'] = 'hooks'
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'layered-scene-inference_amd'))
