@@ -241,7 +241,10 @@ def main():
   ap.add_argument('--band-rows', type=int, default=0)
   ap.add_argument('--threads', type=int, default=0)
   ap.add_argument('--no-cpu-baseline', action='store_true')
-  ap.add_argument('--debug-flags', type=int, default=0)
+  ap.add_argument('--debug-flags', type=int, default=0,
+                  help='LsiSplatDesc.reserved: planner experiments (bits 12+) work '
+                  'with any build; the kernel timing hooks (bits 0-9) need '
+                  'LSI_HIP_LIB=hooks (build.py --hooks)')
   ap.add_argument('--disp', default='smooth',
                   choices=['smooth', 'rough', 'stress'])
   args = ap.parse_args()
