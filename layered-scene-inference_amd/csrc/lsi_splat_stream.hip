@@ -206,6 +206,19 @@ __device__ __forceinline__ EpilogueArgs epilogue_args() {
   return e;
 }
 
+// Same for what only the merge and the epilogue need of the launch plan.
+struct UnitArgs { int nb; float inv_nb; };
+__device__ __forceinline__ UnitArgs unit_args() {
+  KernargPtr ka = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(ka));
+  typedef const __attribute__((address_space(4))) StreamCfg* CP;
+  CP cp = (CP)(ka + ((sizeof(SplatArgs) + alignof(StreamCfg) - 1) &
+                     ~(alignof(StreamCfg) - 1)));
+  UnitArgs u;
+  u.nb = cp->nb; u.inv_nb = cp->inv_nb;
+  return u;
+}
+
 // SIMPLE: the normaliser is exactly 1 and row 3 of M is (0,0,0,1) for every
 // batch element (rectified stereo): u = q0 and D = d with no division.
 template <int LAYOUT, bool SIMPLE>  // LAYOUT 0: channels-last RGB, 1: planar
@@ -250,14 +263,12 @@ __global__ __launch_bounds__(1024) void splat_stream_kernel(SplatArgs a,
   //     (cheaper when a band is only a few microseconds of work).
   const int nbands = gridDim.x;
   const int row0 = band * R;
-  const bool xchg = cfg.exchange != 0;
+  const int xchg = cfg.exchange;  // (uniform flags are ints: one SGPR, not a lane mask)
   const int rows = min(xchg ? R + 1 : R, Ht - row0);  // tile rows
   const int k_lo = xchg ? (band == 0 ? -1 : row0) : row0 - 1;
   const int k_hi = xchg ? min(row0 + R, Ht) - 1 : row0 + rows - 1;
-  const bool top_shared = xchg && band > 0;
-  const bool bot_shared = xchg && row0 + R < Ht;  // tile row R exists, shared
-  const int NB = cfg.nb;
-  const int nunits = rows * NB;
+  const int top_shared = (xchg && band > 0) ? 1 : 0;
+  const int bot_shared = (xchg && row0 + R < Ht) ? 1 : 0;  // tile row R exists
 
   float4* rb_all = reinterpret_cast<float4*>(smem_raw);  // [NWIN][WMAX]
   unsigned* cnt_all = reinterpret_cast<unsigned*>(rb_all + NWIN * WMAX);
@@ -771,6 +782,8 @@ __global__ __launch_bounds__(1024) void splat_stream_kernel(SplatArgs a,
       // ================= merge: cell owners gather the windows =============
       if (tid == 0) yrange[2] = 0;  // next step's tickets (no draws until then)
       {
+        const UnitArgs ua = unit_args();
+        const int NB = ua.nb, nunits = rows * NB;
         // lane t holds task slot t's table entry; the slots that touch a unit
         // are found with one ballot and their entries broadcast by readlane
         TaskA mine;
@@ -778,7 +791,7 @@ __global__ __launch_bounds__(1024) void splat_stream_kernel(SplatArgs a,
         if (lane < NWIN) mine = taskA[sidx * NWIN + lane];
         const int mine_wlo = mine.win & 0xffff, mine_wwin = mine.win >> 16;
         for (int unit = wave; unit < nunits; unit += NW) {
-          const int r = div_small(unit, NB, cfg.inv_nb);
+          const int r = div_small(unit, NB, ua.inv_nb);
           const int c0 = (unit - r * NB) * 64;
           const int cell = c0 + lane;
           const bool hit =
@@ -836,6 +849,8 @@ __global__ __launch_bounds__(1024) void splat_stream_kernel(SplatArgs a,
     // ================= epilogue for this pass ===============================
     // (each wave finishes the units it merged: no barrier needed before)
     const EpilogueArgs ea = epilogue_args();
+    const UnitArgs ua = unit_args();
+    const int NB = ua.nb, nunits = rows * NB;
     const float lbg = compose ? (float)nlayers * ea.bg : ea.bg;
     const int lo_ = compose ? 0 : pass;
     auto finish = [&](int r, int cell, float4 A) {  // normalise and store
@@ -855,7 +870,7 @@ __global__ __launch_bounds__(1024) void splat_stream_kernel(SplatArgs a,
       return ea.xpart + ((xb + j) * 2 + side) * (size_t)Wt;
     };
     for (int unit = wave; unit < nunits; unit += NW) {
-      const int r = div_small(unit, NB, cfg.inv_nb);
+      const int r = div_small(unit, NB, ua.inv_nb);
       const int cell = (unit - r * NB) * 64 + lane;
       if (cell >= Wt) continue;
       float4* tcell = reinterpret_cast<float4*>(extras) + r * Wt + cell;
@@ -893,7 +908,7 @@ __global__ __launch_bounds__(1024) void splat_stream_kernel(SplatArgs a,
       const bool fin_bot = bot_shared && yrange[5] == 1;
       if (fin_top || fin_bot) {
         for (int unit = wave; unit < nunits; unit += NW) {
-          const int r = div_small(unit, NB, cfg.inv_nb);
+          const int r = div_small(unit, NB, ua.inv_nb);
           const int cell = (unit - r * NB) * 64 + lane;
           if (cell >= Wt) continue;
           const bool top = (r == 0 && fin_top), bot = (r == R && fin_bot);
