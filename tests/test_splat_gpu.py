@@ -228,6 +228,30 @@ def test_ragged_and_tiny_shapes(shape, path, dev):
                              atol=1e-7)
 
 
+@pytest.mark.parametrize('shape,s', [((1, 1, 2, 4), 0.5), ((1, 1, 1, 4), 1),
+                                     ((2, 1, 6, 12), 0.5), ((1, 2, 34, 260), 0.5),
+                                     ((3, 1, 8, 2048), 0.5), ((1, 1, 8, 1028), 1),
+                                     ((2, 1, 516, 8), 0.5)])
+@pytest.mark.parametrize('compose', [True, False])
+def test_stream_path_at_the_extremes_of_its_planner(shape, s, compose, dev):
+  """One-row images, one-segment rows, eight segments per row, target tiles
+  that only fit the LDS with one-row bands, more bands than CUs: the planner
+  must find a launch for each and the result must be the oracle's."""
+  from lsi.geometry import ldi
+  nl, b, h, w = shape
+  rs = np.random.RandomState(h * w + nl)
+  tex, disp, mat = _synth(rs, nl, b, h, w)
+  want = O.forward_splat(tex, np.ones_like(disp), disp, mat, s, 1e-3, 0.4, 50,
+                         compose)
+  ldi_src = [torch.tensor(tex, device=dev), None, torch.tensor(disp, device=dev)]
+  img, wts = ldi.forward_splat_matrix(
+      ldi_src, torch.tensor(mat), compose_layers=compose, trg_downsampling=s,
+      bg_layer_disp=1e-3, max_disp=0.4, zbuf_scale=50, path='stream')
+  np.testing.assert_allclose(img.cpu().numpy(), want['img'], rtol=0,
+                             atol=IMG_ATOL)
+  np.testing.assert_allclose(wts.cpu().numpy(), want['wts'], rtol=WTS_RTOL)
+
+
 def test_non_integral_target_size_is_rejected(dev):
   from lsi.geometry import ldi
   tex = torch.rand(1, 1, 5, 7, 3, device=dev)
