@@ -236,7 +236,7 @@ def main():
   ap.add_argument('--steps', type=int, default=200)
   ap.add_argument('--warmup', type=int, default=20)
   ap.add_argument('--workload', default='cfg2', choices=sorted(WORKLOADS))
-  ap.add_argument('--path', default='auto', choices=['auto', 'atomic', 'rowband', 'stream'])
+  ap.add_argument('--path', default='auto', choices=['auto', 'atomic', 'rowband', 'stream', 'tile'])
   ap.add_argument('--launch', default='graph', choices=['graph', 'eager'])
   ap.add_argument('--band-rows', type=int, default=0)
   ap.add_argument('--threads', type=int, default=0)

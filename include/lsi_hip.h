@@ -62,6 +62,11 @@ extern "C" {
                              /* by plain read-modify-write, merged into an    */
                              /* LDS tile of the band -- lsi_stream_ok.        */
 
+#define LSI_PATH_TILE 4      /* any M: source pixels binned per target tile   */
+                             /* with integer LDS exchanges, every target cell */
+                             /* summed by its owner thread; no fp32 atomics.  */
+                             /* What AUTO resolves to inside lsi_splat_fwd.   */
+
 typedef void* lsi_stream_t; /* hipStream_t */
 
 /*

@@ -542,8 +542,10 @@ int lsi_splat_fwd(const LsiSplatDesc* d, const float* tex, const float* disp,
   a.band_rows = 0;
 
   int path = d->path;
-  if (path == LSI_PATH_AUTO) path = LSI_PATH_ATOMIC;  // AUTO needs host M:
-                                                      // callers use rowband_ok
+  // AUTO without a host copy of M: the any-pose tile path (callers that have
+  // one ask lsi_stream_ok first)
+  if (path == LSI_PATH_AUTO) path = LSI_PATH_TILE;
+  if (path == LSI_PATH_TILE) return lsi_tile_launch(a, stream);
   if (path == LSI_PATH_ROWBAND) {
     const int R = d->tune_rows > 0 ? d->tune_rows : pick_band_rows(d);
     const size_t lds = rowband_lds_bytes(d, R);

@@ -24,3 +24,7 @@ struct SplatArgs {
 // LSI_PATH_STREAM launcher and workspace need (lsi_splat_stream.hip).
 size_t lsi_stream_workspace_bytes(const LsiSplatDesc* d);
 int lsi_stream_launch(const SplatArgs& a, hipStream_t stream);
+
+// LSI_PATH_TILE launcher and workspace need (lsi_splat_tile.hip).
+size_t lsi_tile_workspace_bytes(const LsiSplatDesc* d);
+int lsi_tile_launch(const SplatArgs& a, hipStream_t stream);

@@ -1,0 +1,305 @@
+// LSI_PATH_TILE: forward splat for ANY projection matrix (general 3-D poses,
+// BASELINE config 4) without floating-point atomics.
+//
+// Why: fp32 atomics -- global or LDS -- retire ~100-300 G/s on gfx950
+// (tools/microbench*.hip); a splat issues 16 per source pixel, which makes the
+// ATOMIC path ~2 ms at config 4.  Integer LDS atomics are ~20x faster, so the
+// scatter is turned into a gather: source pixels are BINNED by their top-left
+// target cell with one integer exchange each, and every target cell is then
+// summed by the one thread that owns it.
+//
+// Workgroup = (tile of TH x TW target cells, batch element), one thread per
+// cell (1024).  Per layer, the source rows that can reach the tile (a bound
+// from the four (x, disparity) corners of each row, with the batch element's
+// actual disparity range from a small reduction kernel) are swept in chunks of
+// 2048 pixels:
+//   A  every thread projects two pixels exactly (same arithmetic as the other
+//      paths: indices are bit-exact); a pixel whose top-left cell (x0, y0) lies
+//      in the tile or its one-cell upper/left halo loads its colour, writes a
+//      32-byte record {wx0, wx1, wy0, wy1, r*w, g*w, b*w, w} to LDS and links
+//      it into the list of bin (y0, x0):  next[i] = exchange(head[bin], i).
+//   B  the owner of cell (Y, X) walks the lists of bins (Y, X), (Y, X-1),
+//      (Y-1, X), (Y-1, X-1) and adds V * clamp(wx * wy) with the corner's own
+//      weights (border masks are in wx / wy; sampling.py:193-222).
+// Epilogue per cell: background, per-layer disparity, compose, normalisation
+// (ldi.py:122-125, 157-182), each output written once.  Summation order within
+// a cell follows list order (not run-to-run deterministic, like ATOMIC).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/lsi_hip.h"
+#include "lsi_common.h"
+#include "lsi_splat_internal.h"
+
+#pragma clang fp contract(off)
+
+using namespace lsi;
+
+namespace {
+
+constexpr int TT = 1024;  // threads per workgroup = cells per tile
+constexpr int CH = 2048;  // source pixels per chunk (two per thread)
+
+struct TileCfg {
+  int tw_log2;   // tile width  TW = 1 << tw_log2 (32, 64 or 128)
+  int th;        // tile height TH = 1024 / TW
+  int tiles_x;   // tiles per row of tiles
+};
+
+// Per batch element: min and max of the finite-or-infinite disparities (NaNs
+// are skipped: such pixels are dropped by every path).  grid (B), block 1024.
+__global__ __launch_bounds__(1024) void disp_range_kernel(SplatArgs a,
+                                                          float2* range) {
+  const LsiSplatDesc& d = a.d;
+  const int b = blockIdx.x;
+  float lo = __builtin_inff(), hi = -__builtin_inff();
+  const int n = d.H * d.W;
+  for (int l = 0; l < d.L; ++l) {
+    const float* base = a.disp + (long)l * d.disp_sl + (long)b * d.disp_sb;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+      const int y = i / d.W, x = i - y * d.W;
+      const float v = base[(long)y * d.disp_sy + (long)x * d.disp_sx];
+      lo = fminf(lo, v);  // fminf / fmaxf return the non-NaN operand
+      hi = fmaxf(hi, v);
+    }
+  }
+  __shared__ float slo[16], shi[16];
+  for (int o = 32; o > 0; o >>= 1) {
+    lo = fminf(lo, __shfl_xor(lo, o));
+    hi = fmaxf(hi, __shfl_xor(hi, o));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    slo[threadIdx.x >> 6] = lo;
+    shi[threadIdx.x >> 6] = hi;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 16; ++w) { lo = fminf(lo, slo[w]); hi = fmaxf(hi, shi[w]); }
+    range[b] = make_float2(lo, hi);
+  }
+}
+
+template <bool WANT_DISP>
+__global__ __launch_bounds__(1024) void splat_tile_kernel(
+    SplatArgs a, TileCfg c, const float2* __restrict__ range) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const LsiSplatDesc& d = a.d;
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y;
+  const int TW = 1 << c.tw_log2, TH = c.th;
+  const int tile_y = blockIdx.x / c.tiles_x, tile_x = blockIdx.x - tile_y * c.tiles_x;
+  const int ty0 = tile_y * TH, tx0 = tile_x * TW;
+  const int Ht = d.Ht, Wt = d.Wt, H = d.H, W = d.W;
+  const int nbins = (TH + 1) * (TW + 1);
+
+  float4* recA = reinterpret_cast<float4*>(smem);          // wx0 wx1 wy0 wy1
+  float4* recB = recA + CH;                                // r*w g*w b*w w
+  float* recD = reinterpret_cast<float*>(recB + CH);       // dd*w (WANT_DISP)
+  int* next = reinterpret_cast<int*>(recD + (WANT_DISP ? CH : 0));
+  int* head = next + CH;
+  int* rowr = head + nbins;  // [0] first candidate row, [1] last
+
+  float m[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) m[k] = a.M[16 * b + k];
+  const float s = d.trg_downsampling, max_disp = d.max_disp,
+              zscale = d.zbuf_scale;
+  const bool has_mask = d.flags & LSI_HAS_MASK;
+  const bool compose = d.flags & LSI_COMPOSE;
+  const float xmax = (float)Wt - 1.0f, ymax = (float)Ht - 1.0f;
+  // acceptance window of the top-left cell (x0, y0), as floats
+  const float ay_lo = (float)(ty0 - 1), ay_hi = (float)(ty0 + TH - 1);
+  const float ax_lo = (float)(tx0 - 1), ax_hi = (float)(tx0 + TW - 1);
+
+  for (int i = tid; i < nbins; i += TT) head[i] = -1;
+  if (tid == 0) { rowr[0] = H; rowr[1] = -1; }
+  __syncthreads();
+
+  // ---- source rows that can reach the tile -------------------------------
+  {
+    const float2 dr = range[b];
+    int lo = H, hi = -1;
+    for (int y = tid; y < H; y += TT) {
+      const float py = (float)y + 0.5f;
+      float vmin = __builtin_inff(), vmax = -__builtin_inff();
+      bool wild = !(dr.x <= dr.y);  // no finite disparity seen: nothing to bound
+      float nsign = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float px = (k & 1) ? (float)W - 0.5f : 0.5f;
+        const float dv = (k & 2) ? dr.y : dr.x;
+        const float q1 = mrow(m, 1, px, py, dv);
+        const float n = mrow(m, 2, px, py, dv);
+        const float v = div_rn(q1, safe_den(n)) * s - 0.5f;
+        // Y is linear-fractional in x and in d: monotone along both as long as
+        // the denominator keeps its sign on the row; else no bound holds
+        if (!finite_f(v) || !finite_f(n) || n == 0.0f) wild = true;
+        if (k == 0) nsign = n;
+        else if ((n > 0.0f) != (nsign > 0.0f)) wild = true;
+        vmin = fminf(vmin, v);
+        vmax = fmaxf(vmax, v);
+      }
+      // one cell of slack on either side for the rounding of the corner values
+      const bool cand = wild || (floorf(vmax) + 1.0f >= ay_lo &&
+                                 floorf(vmin) - 1.0f <= ay_hi);
+      if (cand) { lo = min(lo, y); hi = max(hi, y); }
+    }
+    if (hi >= 0) { atomicMin(&rowr[0], lo); atomicMax(&rowr[1], hi); }
+  }
+  __syncthreads();
+  const int ys0 = rowr[0], ys1 = rowr[1];
+  const long px_begin = (long)ys0 * W;
+  const long px_end = (ys1 >= ys0) ? (long)(ys1 + 1) * W : px_begin;
+
+  // the cell this thread owns
+  const int cy = tid >> c.tw_log2, cx = tid & (TW - 1);
+  const int gy = ty0 + cy, gx = tx0 + cx;
+  const bool owner = gy < Ht && gx < Wt;
+  const int bin00 = (cy + 1) * (TW + 1) + (cx + 1);
+
+  const float bg = d.bg_wt;
+  const size_t P = (size_t)Ht * Wt;
+  const size_t op = (size_t)gy * Wt + gx;
+  const bool shared_canvas = compose && !WANT_DISP;  // as the ATOMIC epilogue
+  float T0 = 0.f, T1 = 0.f, T2 = 0.f, TWs = 0.f, Tdmax = 0.f;  // compose totals
+
+  for (int l = 0; l < d.L; ++l) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, aw = 0.f, ad = 0.f;  // this layer
+    const float* dbase = a.disp + (long)l * d.disp_sl + (long)b * d.disp_sb;
+    const float* tbase = a.tex + (long)l * d.tex_sl + (long)b * d.tex_sb;
+    const float* mbase =
+        has_mask ? a.mask + (long)l * d.mask_sl + (long)b * d.mask_sb : nullptr;
+    for (long base = px_begin; base < px_end; base += CH) {
+      // ---- A: project, bin ------------------------------------------------
+#pragma unroll
+      for (int h = 0; h < CH / TT; ++h) {
+        const int ri = tid + h * TT;
+        const long i = base + ri;
+        if (i >= px_end) continue;
+        const int y = (int)(i / W), x = (int)(i - (long)y * W);
+        const float dv = dbase[(long)y * d.disp_sy + (long)x * d.disp_sx];
+        const float px = (float)x + 0.5f, py = (float)y + 0.5f;
+        const float q0 = mrow(m, 0, px, py, dv);
+        const float q1 = mrow(m, 1, px, py, dv);
+        const float nden = safe_den(mrow(m, 2, px, py, dv));
+        const float X = div_rn(q0, nden) * s - 0.5f;
+        const float Y = div_rn(q1, nden) * s - 0.5f;
+        const float x0 = floorf(X), y0 = floorf(Y);
+        // (non-finite X / Y fail the comparisons: dropped, like every path)
+        if (!(y0 >= ay_lo && y0 <= ay_hi && x0 >= ax_lo && x0 <= ax_hi)) continue;
+        const float q3 = mrow(m, 3, px, py, dv);
+        const float dd = div_rn(q3, nden);
+        const float mk = has_mask
+                             ? mbase[(long)y * d.mask_sy + (long)x * d.mask_sx]
+                             : 1.0f;
+        const float pw = zbuffer_weight(div_rn(dd, max_disp), zscale) * mk;
+        if (pw == 0.0f) continue;  // contributes exactly +0 everywhere
+        const Axis ax = splat_axis(X, xmax);
+        const Axis ay = splat_axis(Y, ymax);
+        const float* tp = tbase + (long)y * d.tex_sy + (long)x * d.tex_sx;
+        recA[ri] = make_float4(ax.w0, ax.w1, ay.w0, ay.w1);
+        recB[ri] = make_float4(tp[0] * pw, tp[d.tex_sc] * pw,
+                               tp[2 * d.tex_sc] * pw, pw);
+        if (WANT_DISP) recD[ri] = dd * pw;
+        const int bin = (int)(y0 - ay_lo) * (TW + 1) + (int)(x0 - ax_lo);
+        next[ri] = atomicExch(&head[bin], ri);
+      }
+      __syncthreads();
+      // ---- B: every cell gathers its four bins ----------------------------
+      if (owner) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int dy = k >> 1, dx = k & 1;
+          for (int j = head[bin00 - dy * (TW + 1) - dx]; j >= 0; j = next[j]) {
+            const float4 w4 = recA[j];
+            const float cw = clamp_small((dx ? w4.y : w4.x) * (dy ? w4.w : w4.z));
+            if (cw == 0.0f) continue;
+            const float4 v4 = recB[j];
+            a0 += v4.x * cw; a1 += v4.y * cw; a2 += v4.z * cw; aw += v4.w * cw;
+            if (WANT_DISP) ad += recD[j] * cw;
+          }
+        }
+      }
+      __syncthreads();
+      for (int i = tid; i < nbins; i += TT) head[i] = -1;
+      __syncthreads();
+    }
+    // ---- layer done: per-layer outputs / compose -----------------------------
+    if (owner) {
+      if (shared_canvas) {
+        T0 += a0; T1 += a1; T2 += a2; TWs += aw;
+      } else {
+        const float l0 = bg + a0, l1 = bg + a1, l2 = bg + a2, lw = bg + aw;
+        const float dl = WANT_DISP ? div_rn(ad, safe_den(lw)) : 0.0f;
+        if (compose) {
+          if (l == 0) { T0 = l0; T1 = l1; T2 = l2; TWs = lw; Tdmax = dl; }
+          else { T0 += l0; T1 += l1; T2 += l2; TWs += lw; Tdmax = fmaxf(Tdmax, dl); }
+        } else {
+          const size_t o = ((size_t)l * d.B + b) * P + op;
+          const float wd = safe_den(lw);
+          a.out_img[3 * o + 0] = div_rn(l0, wd);
+          a.out_img[3 * o + 1] = div_rn(l1, wd);
+          a.out_img[3 * o + 2] = div_rn(l2, wd);
+          a.out_wts[o] = lw;
+          if (WANT_DISP) a.out_disp[o] = dl;
+        }
+      }
+    }
+  }
+  if (owner && compose) {
+    const size_t o = (size_t)b * P + op;
+    if (shared_canvas) {
+      const float lbg = (float)d.L * bg;
+      const float w = TWs + lbg;
+      const float wd = safe_den(w);
+      a.out_img[3 * o + 0] = div_rn(T0 + lbg, wd);
+      a.out_img[3 * o + 1] = div_rn(T1 + lbg, wd);
+      a.out_img[3 * o + 2] = div_rn(T2 + lbg, wd);
+      a.out_wts[o] = w;
+    } else {
+      const float wd = safe_den(TWs);
+      a.out_img[3 * o + 0] = div_rn(T0, wd);
+      a.out_img[3 * o + 1] = div_rn(T1, wd);
+      a.out_img[3 * o + 2] = div_rn(T2, wd);
+      a.out_wts[o] = TWs;
+      if (WANT_DISP) a.out_disp[o] = Tdmax;
+    }
+  }
+}
+
+}  // namespace
+
+size_t lsi_tile_workspace_bytes(const LsiSplatDesc* d) {
+  return (size_t)d->B * sizeof(float2);
+}
+
+int lsi_tile_launch(const SplatArgs& a, hipStream_t stream) {
+  const LsiSplatDesc* d = &a.d;
+  if (!a.canvas) return LSI_ENULL;
+  if (a.ws_bytes < lsi_tile_workspace_bytes(d)) return LSI_EWORKSPACE;
+  if ((reinterpret_cast<uintptr_t>(a.canvas) & 7) != 0) return LSI_EINVAL;
+  float2* range = reinterpret_cast<float2*>(a.canvas);
+  hipLaunchKernelGGL(disp_range_kernel, dim3(d->B), dim3(1024), 0, stream, a,
+                     range);
+  TileCfg c;
+  c.tw_log2 = d->Wt <= 32 ? 5 : (d->Wt <= 64 ? 6 : 7);
+  const int TW = 1 << c.tw_log2;
+  c.th = TT / TW;
+  c.tiles_x = (d->Wt + TW - 1) / TW;
+  const int tiles_y = (d->Ht + c.th - 1) / c.th;
+  const bool want_disp = (d->flags & LSI_WANT_DISP) != 0;
+  const size_t lds = (size_t)CH * 32 + (want_disp ? (size_t)CH * 4 : 0) +
+                     (size_t)CH * 4 + (size_t)(c.th + 1) * (TW + 1) * 4 + 16;
+  const void* fn = want_disp ? (const void*)splat_tile_kernel<true>
+                             : (const void*)splat_tile_kernel<false>;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)lds) != hipSuccess)
+    return LSI_ELAUNCH;
+  const float2* crange = range;
+  void* kargs[3] = {const_cast<SplatArgs*>(&a), &c, &crange};
+  if (hipLaunchKernel(fn, dim3(c.tiles_x * tiles_y, d->B), dim3(TT), kargs, lds,
+                      stream) != hipSuccess)
+    return LSI_ELAUNCH;
+  return hipGetLastError() == hipSuccess ? LSI_OK : LSI_ELAUNCH;
+}

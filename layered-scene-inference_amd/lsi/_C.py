@@ -19,7 +19,8 @@ SO_PATH = os.path.join(_PKG, 'liblsi_hip_hooks.so' if
 LSI_OK = 0
 LSI_COMPOSE, LSI_WANT_DISP, LSI_HAS_MASK, LSI_WS_KEEP = 1, 2, 4, 8
 LSI_PATH_AUTO, LSI_PATH_ATOMIC, LSI_PATH_ROWBAND, LSI_PATH_STREAM = 0, 1, 2, 3
-PATH_NAMES = {1: 'atomic', 2: 'rowband', 3: 'stream'}
+LSI_PATH_TILE = 4
+PATH_NAMES = {1: 'atomic', 2: 'rowband', 3: 'stream', 4: 'tile'}
 
 _c_f = ctypes.POINTER(ctypes.c_float)
 _c_i = ctypes.POINTER(ctypes.c_int32)

@@ -51,12 +51,14 @@ def _desc(tex, mask, disp, ht, wt, s, max_disp, zbuf_scale, bg_wt, flags, path,
 def select_path(desc, mat_host, path='auto'):
   """Chooses the kernel family and stores it (plus the STREAM window size) in
   `desc`.  `mat_host` is a CPU copy of the B x 4 x 4 projection matrices (None
-  => the general atomic path).  path: 'auto' | 'atomic' | 'rowband' | 'stream'."""
+  => the any-pose tile path).  path: 'auto' | 'atomic' | 'rowband' | 'stream' |
+  'tile'.  auto = stream when its precondition holds (rectified pairs), else
+  tile (any projection, no fp32 atomics)."""
   lib = _C.lib()
-  if path == 'atomic' or mat_host is None:
+  if path in ('atomic', 'tile') or mat_host is None:
     if path in ('rowband', 'stream'):
       raise RuntimeError('%s path needs a host copy of the matrices' % path)
-    desc.path = _C.LSI_PATH_ATOMIC
+    desc.path = _C.LSI_PATH_ATOMIC if path == 'atomic' else _C.LSI_PATH_TILE
     return desc.path
   m = mat_host.contiguous()
   mp = ctypes.c_void_p(m.data_ptr())
@@ -71,10 +73,10 @@ def select_path(desc, mat_host, path='auto'):
                        'do not satisfy its precondition (lsi_rowband_ok)')
   if win:
     desc.path, desc.tune_window = _C.LSI_PATH_STREAM, win
-  elif band:
+  elif path == 'rowband':
     desc.path = _C.LSI_PATH_ROWBAND
   else:
-    desc.path = _C.LSI_PATH_ATOMIC
+    desc.path = _C.LSI_PATH_TILE
   return desc.path
 
 
@@ -146,7 +148,7 @@ class _ForwardSplat(torch.autograd.Function):
            if cfg['compute_trg_disp'] else None)
     lib = _C.lib()
     ws, ws_bytes = None, 0
-    if desc.path == _C.LSI_PATH_ATOMIC:
+    if desc.path in (_C.LSI_PATH_ATOMIC, _C.LSI_PATH_TILE):
       ws_bytes = int(lib.lsi_splat_workspace_bytes(ctypes.byref(desc)))
       ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
     elif desc.path == _C.LSI_PATH_STREAM:
@@ -205,7 +207,7 @@ def forward_splat_matrix(ldi_src, src2trg_mat, compose_layers=True,
   `threads` and `experiment` (LsiSplatDesc.reserved) are tuning/test knobs.
   """
   tex, mask, disp = ldi_src
-  if mat_host is None and path != 'atomic':
+  if mat_host is None and path not in ('atomic', 'tile'):
     mat_host = src2trg_mat.detach().to('cpu', torch.float32)
   mat = src2trg_mat.detach().to(tex.device, torch.float32)
   cfg = dict(compose_layers=bool(compose_layers),

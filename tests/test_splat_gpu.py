@@ -54,7 +54,7 @@ def _stream_ok(g):
 
 @pytest.mark.parametrize('case', FS_CASES)
 @pytest.mark.parametrize('compose', [True, False])
-@pytest.mark.parametrize('path', ['atomic', 'rowband', 'stream'])
+@pytest.mark.parametrize('path', ['atomic', 'rowband', 'stream', 'tile'])
 def test_forward_splat_matches_reference_goldens(case, compose, path, dev):
   from lsi.geometry import ldi
   g = golden(case)
@@ -141,7 +141,7 @@ def _rot(ax, ay, az):
   return rz @ ry @ rx
 
 
-@pytest.mark.parametrize('path', ['atomic', 'rowband', 'stream'])
+@pytest.mark.parametrize('path', ['atomic', 'rowband', 'stream', 'tile'])
 @pytest.mark.parametrize('compose', [True, False])
 def test_config2_size_against_c_oracle(path, compose, dev, ref_cpu):
   """BASELINE config 2 shape (2-layer 256x768, s=0.5), batch 2, vs the C oracle."""
@@ -186,7 +186,7 @@ def test_general_pose_against_c_oracle(dev, ref_cpu):
     ldi.forward_splat_matrix(ldi_src, torch.tensor(mat), path='rowband')
 
 
-@pytest.mark.parametrize('path', ['atomic', 'rowband', 'stream'])
+@pytest.mark.parametrize('path', ['atomic', 'rowband', 'stream', 'tile'])
 def test_planar_nchw_inputs_need_no_copy(path, dev, ref_cpu):
   """A permuted NCHW conv output (planar RGB+disparity) renders identically."""
   from lsi.geometry import ldi
@@ -208,7 +208,7 @@ def test_planar_nchw_inputs_need_no_copy(path, dev, ref_cpu):
 
 @pytest.mark.parametrize('shape', [(1, 1, 1, 1), (1, 1, 2, 3), (2, 1, 7, 13),
                                    (1, 3, 33, 65)])
-@pytest.mark.parametrize('path', ['atomic', 'rowband'])
+@pytest.mark.parametrize('path', ['atomic', 'rowband', 'tile'])
 def test_ragged_and_tiny_shapes(shape, path, dev):
   from lsi.geometry import ldi
   nl, b, h, w = shape
@@ -267,7 +267,7 @@ def test_nonfinite_disparity_is_dropped_not_propagated(dev):
   tex, disp, mat = _synth(rs, 1, 1, 16, 24)
   disp[0, 0, 3, 4, 0] = np.nan
   disp[0, 0, 5, 6, 0] = np.inf
-  for path in ('atomic', 'rowband', 'stream'):
+  for path in ('atomic', 'rowband', 'stream', 'tile'):
     img, wts = ldi.forward_splat_matrix(
         [torch.tensor(tex, device=dev), None, torch.tensor(disp, device=dev)],
         torch.tensor(mat), trg_downsampling=0.5, bg_layer_disp=1e-3,
@@ -275,7 +275,7 @@ def test_nonfinite_disparity_is_dropped_not_propagated(dev):
     assert bool(torch.isfinite(img).all()) and bool(torch.isfinite(wts).all())
 
 
-@pytest.mark.parametrize('path', ['atomic', 'rowband', 'stream'])
+@pytest.mark.parametrize('path', ['atomic', 'rowband', 'stream', 'tile'])
 def test_full_size_properties(path, dev):
   """BASELINE config 3's per-GPU shard (4-layer 256x768, batch 4, s=0.5):
   size-independent properties instead of a CPU oracle."""
