@@ -41,10 +41,13 @@ namespace {
 constexpr int TT = 1024;  // threads per workgroup = cells per tile
 constexpr int CH = 2048;  // source pixels per chunk (two per thread)
 
+constexpr int MAXCPT = 4;  // target cells per thread
+
 struct TileCfg {
   int tw_log2;   // tile width  TW = 1 << tw_log2 (32, 64 or 128)
-  int th;        // tile height TH = 1024 / TW
+  int th;        // tile height TH = cpt * 1024 / TW
   int tiles_x;   // tiles per row of tiles
+  int cpt;       // cells per thread (1, 2 or 4): thread t owns cells t + k*1024
 };
 
 // Per batch element: min and max of the finite-or-infinite disparities (NaNs
@@ -97,8 +100,8 @@ __global__ __launch_bounds__(1024) void splat_tile_kernel(
   float4* recB = recA + CH;                                // r*w g*w b*w w
   float* recD = reinterpret_cast<float*>(recB + CH);       // dd*w (WANT_DISP)
   int* next = reinterpret_cast<int*>(recD + (WANT_DISP ? CH : 0));
-  int* head = next + CH;
-  int* rowr = head + nbins;  // [0] first candidate row, [1] last
+  int* head_all = next + CH;          // two bin tables, used alternately
+  int* rowr = head_all + 2 * nbins;   // [0] first candidate row, [1] last
 
   float m[16];
 #pragma unroll
@@ -112,7 +115,7 @@ __global__ __launch_bounds__(1024) void splat_tile_kernel(
   const float ay_lo = (float)(ty0 - 1), ay_hi = (float)(ty0 + TH - 1);
   const float ax_lo = (float)(tx0 - 1), ax_hi = (float)(tx0 + TW - 1);
 
-  for (int i = tid; i < nbins; i += TT) head[i] = -1;
+  for (int i = tid; i < 2 * nbins; i += TT) head_all[i] = -1;
   if (tid == 0) { rowr[0] = H; rowr[1] = -1; }
   __syncthreads();
 
@@ -149,36 +152,68 @@ __global__ __launch_bounds__(1024) void splat_tile_kernel(
   }
   __syncthreads();
   const int ys0 = rowr[0], ys1 = rowr[1];
-  const long px_begin = (long)ys0 * W;
-  const long px_end = (ys1 >= ys0) ? (long)(ys1 + 1) * W : px_begin;
+  // pixel indices fit in 31 bits (H*W < 2^24); row = index / W by reciprocal
+  const int px_begin = ys0 * W;
+  const int px_end = (ys1 >= ys0) ? (ys1 + 1) * W : px_begin;
+  const float rcp_w = 1.0f / (float)W;
+  auto row_of = [&](int i) {  // i / W for 0 <= i < 2^24
+    int q = (int)((float)i * rcp_w);
+    const int r = i - q * W;
+    q += (r >= W) ? 1 : 0;
+    q -= (r < 0) ? 1 : 0;
+    return q;
+  };
 
-  // the cell this thread owns
-  const int cy = tid >> c.tw_log2, cx = tid & (TW - 1);
-  const int gy = ty0 + cy, gx = tx0 + cx;
-  const bool owner = gy < Ht && gx < Wt;
-  const int bin00 = (cy + 1) * (TW + 1) + (cx + 1);
-
+  const int CPT = c.cpt;  // thread t owns cells t + k * 1024 (row-major in tile)
   const float bg = d.bg_wt;
   const size_t P = (size_t)Ht * Wt;
-  const size_t op = (size_t)gy * Wt + gx;
   const bool shared_canvas = compose && !WANT_DISP;  // as the ATOMIC epilogue
-  float T0 = 0.f, T1 = 0.f, T2 = 0.f, TWs = 0.f, Tdmax = 0.f;  // compose totals
+  // compose totals per owned cell
+  float T0[MAXCPT], T1[MAXCPT], T2[MAXCPT], TWs[MAXCPT], Tdmax[MAXCPT];
+#pragma unroll
+  for (int k = 0; k < MAXCPT; ++k) {
+    T0[k] = 0.f; T1[k] = 0.f; T2[k] = 0.f; TWs[k] = 0.f; Tdmax[k] = 0.f;
+  }
+  int parity = 0;  // which bin table the current chunk fills
 
   for (int l = 0; l < d.L; ++l) {
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, aw = 0.f, ad = 0.f;  // this layer
+    float a0[MAXCPT], a1[MAXCPT], a2[MAXCPT], aw[MAXCPT], ad[MAXCPT];  // layer
+#pragma unroll
+    for (int k = 0; k < MAXCPT; ++k) {
+      a0[k] = 0.f; a1[k] = 0.f; a2[k] = 0.f; aw[k] = 0.f; ad[k] = 0.f;
+    }
     const float* dbase = a.disp + (long)l * d.disp_sl + (long)b * d.disp_sb;
     const float* tbase = a.tex + (long)l * d.tex_sl + (long)b * d.tex_sb;
     const float* mbase =
         has_mask ? a.mask + (long)l * d.mask_sl + (long)b * d.mask_sb : nullptr;
-    for (long base = px_begin; base < px_end; base += CH) {
+    // disparities of the next chunk are in flight while this one is processed
+    auto load_disp = [&](int base, float (&dv)[CH / TT]) {
+#pragma unroll
+      for (int h = 0; h < CH / TT; ++h) {
+        const int i = base + tid + h * TT;
+        dv[h] = 0.0f;
+        if (i < px_end) {
+          const int y = row_of(i), x = i - y * W;
+          dv[h] = dbase[(long)y * d.disp_sy + (long)x * d.disp_sx];
+        }
+      }
+    };
+    float dv_next[CH / TT];
+    load_disp(px_begin, dv_next);
+    for (int base = px_begin; base < px_end; base += CH) {
+      float dv_cur[CH / TT];
+#pragma unroll
+      for (int h = 0; h < CH / TT; ++h) dv_cur[h] = dv_next[h];
+      if (base + CH < px_end) load_disp(base + CH, dv_next);
+      int* head = head_all + parity * nbins;
       // ---- A: project, bin ------------------------------------------------
 #pragma unroll
       for (int h = 0; h < CH / TT; ++h) {
         const int ri = tid + h * TT;
-        const long i = base + ri;
+        const int i = base + ri;
         if (i >= px_end) continue;
-        const int y = (int)(i / W), x = (int)(i - (long)y * W);
-        const float dv = dbase[(long)y * d.disp_sy + (long)x * d.disp_sx];
+        const int y = row_of(i), x = i - y * W;
+        const float dv = dv_cur[h];
         const float px = (float)x + 0.5f, py = (float)y + 0.5f;
         const float q0 = mrow(m, 0, px, py, dv);
         const float q1 = mrow(m, 1, px, py, dv);
@@ -206,35 +241,75 @@ __global__ __launch_bounds__(1024) void splat_tile_kernel(
         next[ri] = atomicExch(&head[bin], ri);
       }
       __syncthreads();
-      // ---- B: every cell gathers its four bins ----------------------------
-      if (owner) {
+      // ---- B: every cell gathers its four bins; the other bin table (read in
+      // the previous chunk) is cleared for the next one meanwhile
+      {
+        int* other = head_all + (parity ^ 1) * nbins;
+        for (int i = tid; i < nbins; i += TT) other[i] = -1;
+      }
+      // The up-to-16 lists of a thread's cells are walked together: one
+      // pointer-chasing step of each per round, so their LDS latencies overlap.
+      {
+        int jl[4 * MAXCPT];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int dy = k >> 1, dx = k & 1;
-          for (int j = head[bin00 - dy * (TW + 1) - dx]; j >= 0; j = next[j]) {
-            const float4 w4 = recA[j];
-            const float cw = clamp_small((dx ? w4.y : w4.x) * (dy ? w4.w : w4.z));
-            if (cw == 0.0f) continue;
-            const float4 v4 = recB[j];
-            a0 += v4.x * cw; a1 += v4.y * cw; a2 += v4.z * cw; aw += v4.w * cw;
-            if (WANT_DISP) ad += recD[j] * cw;
+        for (int q = 0; q < MAXCPT; ++q) {
+          const int cell = tid + q * TT;
+          const int cy = cell >> c.tw_log2, cx = cell & (TW - 1);
+          const bool own = q < CPT && ty0 + cy < Ht && tx0 + cx < Wt;
+          const int bin00 = (cy + 1) * (TW + 1) + (cx + 1);
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            jl[4 * q + k] =
+                own ? head[bin00 - (k >> 1) * (TW + 1) - (k & 1)] : -1;
+        }
+        // a chunk reaches only a few rows of the tile: most of a wave's cell
+        // groups have nothing to gather (wave-uniform skip)
+#pragma unroll
+        for (int q = 0; q < MAXCPT; ++q) {
+          while (__ballot((jl[4 * q] & jl[4 * q + 1] & jl[4 * q + 2] &
+                           jl[4 * q + 3]) >= 0) != 0ull) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const int j = jl[4 * q + k];
+              if (j < 0) continue;
+              const int dy = k >> 1, dx = k & 1;
+              const float4 w4 = recA[j];
+              const float4 v4 = recB[j];
+              jl[4 * q + k] = next[j];
+              const float cw =
+                  clamp_small((dx ? w4.y : w4.x) * (dy ? w4.w : w4.z));
+              a0[q] += v4.x * cw; a1[q] += v4.y * cw; a2[q] += v4.z * cw;
+              aw[q] += v4.w * cw;
+              if (WANT_DISP) ad[q] += recD[j] * cw;
+            }
           }
         }
       }
-      __syncthreads();
-      for (int i = tid; i < nbins; i += TT) head[i] = -1;
-      __syncthreads();
+      __syncthreads();  // records and `next` are rewritten by the next chunk
+      parity ^= 1;
     }
     // ---- layer done: per-layer outputs / compose -----------------------------
-    if (owner) {
+#pragma unroll
+    for (int q = 0; q < MAXCPT; ++q) {
+      if (q >= CPT) break;
+      const int cell = tid + q * TT;
+      const int cy = cell >> c.tw_log2, cx = cell & (TW - 1);
+      const int gy = ty0 + cy, gx = tx0 + cx;
+      if (gy >= Ht || gx >= Wt) continue;
+      const size_t op = (size_t)gy * Wt + gx;
       if (shared_canvas) {
-        T0 += a0; T1 += a1; T2 += a2; TWs += aw;
+        T0[q] += a0[q]; T1[q] += a1[q]; T2[q] += a2[q]; TWs[q] += aw[q];
       } else {
-        const float l0 = bg + a0, l1 = bg + a1, l2 = bg + a2, lw = bg + aw;
-        const float dl = WANT_DISP ? div_rn(ad, safe_den(lw)) : 0.0f;
+        const float l0 = bg + a0[q], l1 = bg + a1[q], l2 = bg + a2[q],
+                    lw = bg + aw[q];
+        const float dl = WANT_DISP ? div_rn(ad[q], safe_den(lw)) : 0.0f;
         if (compose) {
-          if (l == 0) { T0 = l0; T1 = l1; T2 = l2; TWs = lw; Tdmax = dl; }
-          else { T0 += l0; T1 += l1; T2 += l2; TWs += lw; Tdmax = fmaxf(Tdmax, dl); }
+          if (l == 0) {
+            T0[q] = l0; T1[q] = l1; T2[q] = l2; TWs[q] = lw; Tdmax[q] = dl;
+          } else {
+            T0[q] += l0; T1[q] += l1; T2[q] += l2; TWs[q] += lw;
+            Tdmax[q] = fmaxf(Tdmax[q], dl);
+          }
         } else {
           const size_t o = ((size_t)l * d.B + b) * P + op;
           const float wd = safe_den(lw);
@@ -247,23 +322,31 @@ __global__ __launch_bounds__(1024) void splat_tile_kernel(
       }
     }
   }
-  if (owner && compose) {
-    const size_t o = (size_t)b * P + op;
-    if (shared_canvas) {
-      const float lbg = (float)d.L * bg;
-      const float w = TWs + lbg;
-      const float wd = safe_den(w);
-      a.out_img[3 * o + 0] = div_rn(T0 + lbg, wd);
-      a.out_img[3 * o + 1] = div_rn(T1 + lbg, wd);
-      a.out_img[3 * o + 2] = div_rn(T2 + lbg, wd);
-      a.out_wts[o] = w;
-    } else {
-      const float wd = safe_den(TWs);
-      a.out_img[3 * o + 0] = div_rn(T0, wd);
-      a.out_img[3 * o + 1] = div_rn(T1, wd);
-      a.out_img[3 * o + 2] = div_rn(T2, wd);
-      a.out_wts[o] = TWs;
-      if (WANT_DISP) a.out_disp[o] = Tdmax;
+  if (compose) {
+#pragma unroll
+    for (int q = 0; q < MAXCPT; ++q) {
+      if (q >= CPT) break;
+      const int cell = tid + q * TT;
+      const int cy = cell >> c.tw_log2, cx = cell & (TW - 1);
+      const int gy = ty0 + cy, gx = tx0 + cx;
+      if (gy >= Ht || gx >= Wt) continue;
+      const size_t o = (size_t)b * P + (size_t)gy * Wt + gx;
+      if (shared_canvas) {
+        const float lbg = (float)d.L * bg;
+        const float w = TWs[q] + lbg;
+        const float wd = safe_den(w);
+        a.out_img[3 * o + 0] = div_rn(T0[q] + lbg, wd);
+        a.out_img[3 * o + 1] = div_rn(T1[q] + lbg, wd);
+        a.out_img[3 * o + 2] = div_rn(T2[q] + lbg, wd);
+        a.out_wts[o] = w;
+      } else {
+        const float wd = safe_den(TWs[q]);
+        a.out_img[3 * o + 0] = div_rn(T0[q], wd);
+        a.out_img[3 * o + 1] = div_rn(T1[q], wd);
+        a.out_img[3 * o + 2] = div_rn(T2[q], wd);
+        a.out_wts[o] = TWs[q];
+        if (WANT_DISP) a.out_disp[o] = Tdmax[q];
+      }
     }
   }
 }
@@ -285,12 +368,30 @@ int lsi_tile_launch(const SplatArgs& a, hipStream_t stream) {
   TileCfg c;
   c.tw_log2 = d->Wt <= 32 ? 5 : (d->Wt <= 64 ? 6 : 7);
   const int TW = 1 << c.tw_log2;
-  c.th = TT / TW;
+  // Taller tiles re-project fewer source rows per output row ((TH + reach) / TH)
+  // but leave fewer workgroups: the tallest tile that still gives every CU a
+  // workgroup (tune_rows overrides: tile height in cells).
+  c.cpt = 1;
+  if (d->tune_rows > 0) {
+    c.cpt = d->tune_rows * TW / TT;
+    if (c.cpt < 1) c.cpt = 1;
+    if (c.cpt > MAXCPT) c.cpt = MAXCPT;
+    if (c.cpt == 3) c.cpt = 2;
+  } else {
+    for (int k = 2; k <= MAXCPT; k *= 2) {
+      const int th = k * TT / TW;
+      const long nwg =
+          (long)((d->Ht + th - 1) / th) * ((d->Wt + TW - 1) / TW) * d->B;
+      if (nwg < 256 || th > 2 * d->Ht) break;
+      c.cpt = k;
+    }
+  }
+  c.th = c.cpt * TT / TW;
   c.tiles_x = (d->Wt + TW - 1) / TW;
   const int tiles_y = (d->Ht + c.th - 1) / c.th;
   const bool want_disp = (d->flags & LSI_WANT_DISP) != 0;
   const size_t lds = (size_t)CH * 32 + (want_disp ? (size_t)CH * 4 : 0) +
-                     (size_t)CH * 4 + (size_t)(c.th + 1) * (TW + 1) * 4 + 16;
+                     (size_t)CH * 4 + (size_t)2 * (c.th + 1) * (TW + 1) * 4 + 16;
   const void* fn = want_disp ? (const void*)splat_tile_kernel<true>
                              : (const void*)splat_tile_kernel<false>;
   if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
