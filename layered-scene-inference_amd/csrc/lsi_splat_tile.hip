@@ -186,25 +186,32 @@ __global__ __launch_bounds__(1024) void splat_tile_kernel(
     const float* tbase = a.tex + (long)l * d.tex_sl + (long)b * d.tex_sb;
     const float* mbase =
         has_mask ? a.mask + (long)l * d.mask_sl + (long)b * d.mask_sb : nullptr;
-    // disparities of the next chunk are in flight while this one is processed
-    auto load_disp = [&](int base, float (&dv)[CH / TT]) {
+    // the next chunk's pixels (disparity, colour, mask) are in flight while
+    // this one is processed: no dependent global load on the critical path
+    struct PxIn { float dv, t0, t1, t2, mk; };
+    auto load_px = [&](int base, PxIn (&in)[CH / TT]) {
 #pragma unroll
       for (int h = 0; h < CH / TT; ++h) {
         const int i = base + tid + h * TT;
-        dv[h] = 0.0f;
+        in[h].dv = 0.0f; in[h].t0 = 0.0f; in[h].t1 = 0.0f; in[h].t2 = 0.0f;
+        in[h].mk = 1.0f;
         if (i < px_end) {
           const int y = row_of(i), x = i - y * W;
-          dv[h] = dbase[(long)y * d.disp_sy + (long)x * d.disp_sx];
+          in[h].dv = dbase[(long)y * d.disp_sy + (long)x * d.disp_sx];
+          const float* tp = tbase + (long)y * d.tex_sy + (long)x * d.tex_sx;
+          in[h].t0 = tp[0]; in[h].t1 = tp[d.tex_sc]; in[h].t2 = tp[2 * d.tex_sc];
+          if (has_mask)
+            in[h].mk = mbase[(long)y * d.mask_sy + (long)x * d.mask_sx];
         }
       }
     };
-    float dv_next[CH / TT];
-    load_disp(px_begin, dv_next);
+    PxIn in_next[CH / TT];
+    load_px(px_begin, in_next);
     for (int base = px_begin; base < px_end; base += CH) {
-      float dv_cur[CH / TT];
+      PxIn in_cur[CH / TT];
 #pragma unroll
-      for (int h = 0; h < CH / TT; ++h) dv_cur[h] = dv_next[h];
-      if (base + CH < px_end) load_disp(base + CH, dv_next);
+      for (int h = 0; h < CH / TT; ++h) in_cur[h] = in_next[h];
+      if (base + CH < px_end) load_px(base + CH, in_next);
       int* head = head_all + parity * nbins;
       // ---- A: project, bin ------------------------------------------------
 #pragma unroll
@@ -213,7 +220,7 @@ __global__ __launch_bounds__(1024) void splat_tile_kernel(
         const int i = base + ri;
         if (i >= px_end) continue;
         const int y = row_of(i), x = i - y * W;
-        const float dv = dv_cur[h];
+        const float dv = in_cur[h].dv;
         const float px = (float)x + 0.5f, py = (float)y + 0.5f;
         const float q0 = mrow(m, 0, px, py, dv);
         const float q1 = mrow(m, 1, px, py, dv);
@@ -223,19 +230,19 @@ __global__ __launch_bounds__(1024) void splat_tile_kernel(
         const float x0 = floorf(X), y0 = floorf(Y);
         // (non-finite X / Y fail the comparisons: dropped, like every path)
         if (!(y0 >= ay_lo && y0 <= ay_hi && x0 >= ax_lo && x0 <= ax_hi)) continue;
+#ifdef LSI_TILE_EXPERIMENT_REJECT_ALL
+        if (y0 > -1.0e30f) continue;
+#endif
         const float q3 = mrow(m, 3, px, py, dv);
         const float dd = div_rn(q3, nden);
-        const float mk = has_mask
-                             ? mbase[(long)y * d.mask_sy + (long)x * d.mask_sx]
-                             : 1.0f;
-        const float pw = zbuffer_weight(div_rn(dd, max_disp), zscale) * mk;
+        const float pw =
+            zbuffer_weight(div_rn(dd, max_disp), zscale) * in_cur[h].mk;
         if (pw == 0.0f) continue;  // contributes exactly +0 everywhere
         const Axis ax = splat_axis(X, xmax);
         const Axis ay = splat_axis(Y, ymax);
-        const float* tp = tbase + (long)y * d.tex_sy + (long)x * d.tex_sx;
         recA[ri] = make_float4(ax.w0, ax.w1, ay.w0, ay.w1);
-        recB[ri] = make_float4(tp[0] * pw, tp[d.tex_sc] * pw,
-                               tp[2 * d.tex_sc] * pw, pw);
+        recB[ri] = make_float4(in_cur[h].t0 * pw, in_cur[h].t1 * pw,
+                               in_cur[h].t2 * pw, pw);
         if (WANT_DISP) recD[ri] = dd * pw;
         const int bin = (int)(y0 - ay_lo) * (TW + 1) + (int)(x0 - ax_lo);
         next[ri] = atomicExch(&head[bin], ri);
@@ -264,6 +271,7 @@ __global__ __launch_bounds__(1024) void splat_tile_kernel(
         }
         // a chunk reaches only a few rows of the tile: most of a wave's cell
         // groups have nothing to gather (wave-uniform skip)
+#ifndef LSI_TILE_EXPERIMENT_SKIP_GATHER
 #pragma unroll
         for (int q = 0; q < MAXCPT; ++q) {
           while (__ballot((jl[4 * q] & jl[4 * q + 1] & jl[4 * q + 2] &
@@ -284,6 +292,7 @@ __global__ __launch_bounds__(1024) void splat_tile_kernel(
             }
           }
         }
+#endif
       }
       __syncthreads();  // records and `next` are rewritten by the next chunk
       parity ^= 1;
