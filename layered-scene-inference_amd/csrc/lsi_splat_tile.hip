@@ -16,11 +16,12 @@
 //   A  every thread projects two pixels exactly (same arithmetic as the other
 //      paths: indices are bit-exact); a pixel whose top-left cell (x0, y0) lies
 //      in the tile or its one-cell upper/left halo loads its colour, writes a
-//      32-byte record {wx0, wx1, wy0, wy1, r*w, g*w, b*w, w} to LDS and links
+//      32-byte record {c_tl, c_tr, c_bl, c_br, r*w, g*w, b*w, w} to LDS (c = the
+//      clamped, border-masked corner weights; sampling.py:193-222) and links
 //      it into the list of bin (y0, x0):  next[i] = exchange(head[bin], i).
 //   B  the owner of cell (Y, X) walks the lists of bins (Y, X), (Y, X-1),
-//      (Y-1, X), (Y-1, X-1) and adds V * clamp(wx * wy) with the corner's own
-//      weights (border masks are in wx / wy; sampling.py:193-222).
+//      (Y-1, X), (Y-1, X-1) and adds V * c with the weight of the corner that
+//      lands on it.
 // Epilogue per cell: background, per-layer disparity, compose, normalisation
 // (ldi.py:122-125, 157-182), each output written once.  Summation order within
 // a cell follows list order (not run-to-run deterministic, like ATOMIC).
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(1024) void splat_tile_kernel(
   const int Ht = d.Ht, Wt = d.Wt, H = d.H, W = d.W;
   const int nbins = (TH + 1) * (TW + 1);
 
-  float4* recA = reinterpret_cast<float4*>(smem);          // wx0 wx1 wy0 wy1
+  float4* recA = reinterpret_cast<float4*>(smem);          // corner weights
   float4* recB = recA + CH;                                // r*w g*w b*w w
   float* recD = reinterpret_cast<float*>(recB + CH);       // dd*w (WANT_DISP)
   int* next = reinterpret_cast<int*>(recD + (WANT_DISP ? CH : 0));
@@ -222,14 +223,17 @@ __global__ __launch_bounds__(1024) void splat_tile_kernel(
         const int y = row_of(i), x = i - y * W;
         const float dv = in_cur[h].dv;
         const float px = (float)x + 0.5f, py = (float)y + 0.5f;
-        const float q0 = mrow(m, 0, px, py, dv);
+        // rows first: most rejected pixels miss the tile's rows
+        // (non-finite X / Y fail the comparisons: dropped, like every path)
         const float q1 = mrow(m, 1, px, py, dv);
         const float nden = safe_den(mrow(m, 2, px, py, dv));
-        const float X = div_rn(q0, nden) * s - 0.5f;
         const float Y = div_rn(q1, nden) * s - 0.5f;
-        const float x0 = floorf(X), y0 = floorf(Y);
-        // (non-finite X / Y fail the comparisons: dropped, like every path)
-        if (!(y0 >= ay_lo && y0 <= ay_hi && x0 >= ax_lo && x0 <= ax_hi)) continue;
+        const float y0 = floorf(Y);
+        if (!(y0 >= ay_lo && y0 <= ay_hi)) continue;
+        const float q0 = mrow(m, 0, px, py, dv);
+        const float X = div_rn(q0, nden) * s - 0.5f;
+        const float x0 = floorf(X);
+        if (!(x0 >= ax_lo && x0 <= ax_hi)) continue;
 #ifdef LSI_TILE_EXPERIMENT_REJECT_ALL
         if (y0 > -1.0e30f) continue;
 #endif
@@ -240,7 +244,10 @@ __global__ __launch_bounds__(1024) void splat_tile_kernel(
         if (pw == 0.0f) continue;  // contributes exactly +0 everywhere
         const Axis ax = splat_axis(X, xmax);
         const Axis ay = splat_axis(Y, ymax);
-        recA[ri] = make_float4(ax.w0, ax.w1, ay.w0, ay.w1);
+        // the four corner weights, border masks and 1e-3 clamp applied
+        // (sampling.py:193-222): tl, tr, bl, br
+        recA[ri] = make_float4(clamp_small(ax.w0 * ay.w0), clamp_small(ax.w1 * ay.w0),
+                               clamp_small(ax.w0 * ay.w1), clamp_small(ax.w1 * ay.w1));
         recB[ri] = make_float4(in_cur[h].t0 * pw, in_cur[h].t1 * pw,
                                in_cur[h].t2 * pw, pw);
         if (WANT_DISP) recD[ri] = dd * pw;
@@ -280,12 +287,12 @@ __global__ __launch_bounds__(1024) void splat_tile_kernel(
             for (int k = 0; k < 4; ++k) {
               const int j = jl[4 * q + k];
               if (j < 0) continue;
-              const int dy = k >> 1, dx = k & 1;
+              // bin (Y - dy, X - dx) holds pixels whose corner (dy, dx) is
+              // this cell: weight component k = 2 dy + dx of the record
               const float4 w4 = recA[j];
               const float4 v4 = recB[j];
               jl[4 * q + k] = next[j];
-              const float cw =
-                  clamp_small((dx ? w4.y : w4.x) * (dy ? w4.w : w4.z));
+              const float cw = k == 0 ? w4.x : (k == 1 ? w4.y : (k == 2 ? w4.z : w4.w));
               a0[q] += v4.x * cw; a1[q] += v4.y * cw; a2[q] += v4.z * cw;
               aw[q] += v4.w * cw;
               if (WANT_DISP) ad[q] += recD[j] * cw;
