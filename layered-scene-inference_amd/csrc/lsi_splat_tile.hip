@@ -35,6 +35,10 @@
 
 #pragma clang fp contract(off)
 
+#ifndef LSI_STREAM_HOOKS
+#define LSI_STREAM_HOOKS 0
+#endif
+
 using namespace lsi;
 
 namespace {
@@ -176,6 +180,12 @@ __global__ __launch_bounds__(1024) void splat_tile_kernel(
     T0[k] = 0.f; T1[k] = 0.f; T2[k] = 0.f; TWs[k] = 0.f; Tdmax[k] = 0.f;
   }
   int parity = 0;  // which bin table the current chunk fills
+#if LSI_STREAM_HOOKS
+  long long tacc[4] = {0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
+#define TILE_STAMP(i) do { const long long tn = __builtin_readcyclecounter(); tacc[i] += tn - tprev; tprev = tn; } while (0)
+#else
+#define TILE_STAMP(i)
+#endif
 
   for (int l = 0; l < d.L; ++l) {
     float a0[MAXCPT], a1[MAXCPT], a2[MAXCPT], aw[MAXCPT], ad[MAXCPT];  // layer
@@ -254,7 +264,9 @@ __global__ __launch_bounds__(1024) void splat_tile_kernel(
         const int bin = (int)(y0 - ay_lo) * (TW + 1) + (int)(x0 - ax_lo);
         next[ri] = atomicExch(&head[bin], ri);
       }
+      TILE_STAMP(0);
       __syncthreads();
+      TILE_STAMP(1);
       // ---- B: every cell gathers its four bins; the other bin table (read in
       // the previous chunk) is cleared for the next one meanwhile
       {
@@ -301,7 +313,9 @@ __global__ __launch_bounds__(1024) void splat_tile_kernel(
         }
 #endif
       }
+      TILE_STAMP(2);
       __syncthreads();  // records and `next` are rewritten by the next chunk
+      TILE_STAMP(3);
       parity ^= 1;
     }
     // ---- layer done: per-layer outputs / compose -----------------------------
@@ -338,6 +352,14 @@ __global__ __launch_bounds__(1024) void splat_tile_kernel(
       }
     }
   }
+#if LSI_STREAM_HOOKS
+  if ((d.reserved & 4) && tid == 0) {
+    long long* o = reinterpret_cast<long long*>(
+                       const_cast<float2*>(range) + d.B) +
+                   ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4;
+    o[0] = tacc[0]; o[1] = tacc[1]; o[2] = tacc[2]; o[3] = tacc[3];
+  }
+#endif
   if (compose) {
 #pragma unroll
     for (int q = 0; q < MAXCPT; ++q) {
