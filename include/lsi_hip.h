@@ -127,14 +127,16 @@ int lsi_stream_ok(const LsiSplatDesc* desc, const float* M_host);
 
 /*
  * Bytes of device workspace lsi_splat_fwd needs for this descriptor (16-byte
- * aligned; any path).  The ATOMIC path keeps its canvases there.  The STREAM
+ * aligned; any path).  The ATOMIC path keeps its canvases there, the TILE path a
+ * per-view disparity range.  The STREAM
  * path uses it to combine the target rows shared by two neighbouring row bands:
  * a few arrival counters at its start, then partial rows.  The counters must be
  * zero when a call starts and every call leaves them zero; lsi_splat_fwd clears
  * them itself (one small memset on the stream) unless LSI_WS_KEEP promises that
  * the buffer was zero-filled once and has only been used by completed or
- * stream-ordered lsi_splat_fwd calls WITH THE SAME L, B, Ht, Wt AND flags since
- * (the place of the counters depends on those).  One workspace must not be used by
+ * stream-ordered STREAM-path lsi_splat_fwd calls WITH THE SAME L, B, Ht, Wt AND
+ * flags since (the place of the counters depends on those; the other paths
+ * write over them).  One workspace must not be used by
  * two calls that can run concurrently.
  */
 size_t lsi_splat_workspace_bytes(const LsiSplatDesc* desc);
