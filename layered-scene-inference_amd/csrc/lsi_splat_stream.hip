@@ -65,8 +65,9 @@ constexpr int MAXNW = 16;
 // element has normaliser == 1 and M row 3 == (0,0,0,1) (division-free kernel)
 constexpr int LSI_STREAM_SIMPLE_BIT = 1 << 20;
 
-// Per-task table entries, filled for a whole chunk of tasks at once by all
-// threads (one task per thread) so that no wave recomputes row geometry.
+// Per-task table entries, filled for a whole chunk of tasks at once (one task
+// per lane: by wave 0 in the prologue, by all threads for later chunks) so that
+// no wave recomputes row geometry when it draws a task.
 struct __attribute__((aligned(16))) TaskA {  // what the merge needs
   int row0;        // target row of the task's top contribution, band-relative
   float wy0, wy1;  // row weights incl. border masks (sampling.py:210-211);
@@ -81,7 +82,7 @@ struct __attribute__((aligned(16))) TaskB {
 struct alignas(16) StreamCfg {  // (kernarg offset: see epilogue_args)
   int R;      // target rows per workgroup
   int wmax;   // window cells per task
-  int tpw;    // tasks (windows) per wave per step
+  int tpw;    // windows per wave: nw * tpw tasks are in flight per step
   int cap;    // task-table entries, a multiple of nw * tpw
   int nb;     // 64-cell units per target row
   int steps_per_chunk;  // cap / (nw * tpw)
@@ -89,7 +90,7 @@ struct alignas(16) StreamCfg {  // (kernarg offset: see epilogue_args)
   // boundary-row exchange area in the workspace (see stream_exchange_layout)
   int* xcount;     // [npass][B][nbands] arrival counters, zero between calls
   float4* xpart;   // [npass][B][nbands][2][Wt] partial rows
-  long long* tstamps;  // debug flag 4
+  long long* tstamps;  // instrumented build, flag 4 (tools/phase_probe.py)
   int exchange;  // 1: bands own source rows and exchange boundary target rows
                  // 0: bands own target rows and re-read one halo row pair
 };
