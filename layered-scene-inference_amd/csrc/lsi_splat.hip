@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void splat_atomic_kernel(SplatArgs a) {
   const float pw = active ? p.pw : 0.0f;
   float ch[5];
   ch[0] = tp[0] * pw; ch[1] = tp[d.tex_sc] * pw; ch[2] = tp[2 * d.tex_sc] * pw;
-  ch[3] = pw; ch[4] = p.dd * pw;
+  ch[3] = pw; ch[4] = active ? p.dd * pw : 0.0f;  // (dd may be NaN when dropped)
   const int nch = a.nch;
   // partner = the other lane of the pair (2m, 2m+1): quad_perm [1,0,3,2]
   const int key = active ? (p.idx[0] ^ (p.idx[3] << 12)) : -1 - (int)threadIdx.x;

@@ -366,7 +366,13 @@ def forward_splat(tex, mask, disp, mat, trg_downsampling=1, bg_layer_disp=0,
     dsp0 = np.zeros((b, ht, wt, 1), np.float32) * bg_wt
     cimg[l] = splat(tex[l] * pw[..., None], coords, img0)  # :148-155
     cwts[l] = splat(pw[..., None], coords, wts0)
-    cdsp[l] = splat((dd * pw)[..., None], coords, dsp0)
+    # build definition (NaN / Inf inputs, where TF's behaviour is implementation
+    # defined): a pixel with zero weight adds nothing to the disparity canvas
+    # either, although dd * 0 would be NaN for a non-finite dd
+    with np.errstate(all='ignore'):
+      keep = (pw != 0) & np.isfinite(u) & np.isfinite(v)
+      dterm = np.where(keep, dd * pw, F(0)).astype(np.float32)
+    cdsp[l] = splat(dterm[..., None], coords, dsp0)
     if debug:
       idx4, w4 = splat_corners(u, v, ht, wt)
       idx_all.append(idx4.reshape(b, h * w, 4))

@@ -583,3 +583,48 @@ def test_stream_workspace_contract_through_the_c_abi(dev):
   assert rc == -3                    # LSI_EWORKSPACE
   rc, _, _, _ = run(0, None)
   assert rc == -2                    # LSI_ENULL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('path', ['tile', 'atomic'])
+@pytest.mark.parametrize('seed', range(8))
+def test_any_pose_paths_under_hostile_projections(seed, path, dev, ref_cpu):
+  """Random projective matrices, far outside anything a camera pair produces:
+  strong rotation and shear, the normaliser changing sign inside the image
+  (points behind the camera), disparities outside [0, max_disp], NaN / Inf
+  pixels.  The tile path bounds which source rows can reach a tile; that bound
+  must stay a superset whatever M is.  Checked against the C oracle."""
+  from lsi.geometry import ldi
+  rs = np.random.RandomState(100 + seed)
+  nl, b, h, w = 2, 2, 40, 72
+  tex = rs.rand(nl, b, h, w, 3).astype(np.float32)
+  disp = rs.uniform(-0.2, 1.3, (nl, b, h, w, 1)).astype(np.float32)
+  mask = rs.rand(nl, b, h, w, 1).astype(np.float32)
+  if seed % 2:
+    bad = rs.rand(nl, b, h, w, 1) < 0.01
+    disp[bad] = np.nan
+    disp[rs.rand(nl, b, h, w, 1) < 0.005] = np.inf
+  mat = np.zeros((b, 4, 4), np.float32)
+  for i in range(b):
+    m = np.eye(4) + rs.normal(0, 0.35, (4, 4))
+    m[0, 2] += rs.uniform(-20, 20); m[1, 2] += rs.uniform(-10, 10)
+    m[0, 3] = rs.uniform(-30, 30); m[1, 3] = rs.uniform(-30, 30)
+    # normaliser n = m20 x + m21 y + m22 + m23 d: sign change inside the image
+    m[2] = [rs.normal(0, 0.02), rs.normal(0, 0.03), rs.uniform(-0.5, 1.0),
+            rs.normal(0, 0.8)]
+    m[3] = [0, 0, 0, 1] if seed < 4 else m[3]
+    mat[i] = m.astype(np.float32)
+  s = 0.5
+  for compose in (True, False):
+    want = ref_cpu.forward_splat(tex, mask, disp, mat, s, 0.2, 1.0, 50, compose)
+    ldi_src = [torch.tensor(x, device=dev) for x in (tex, mask, disp)]
+    img, wts, dsp = ldi.forward_splat_matrix(
+        ldi_src, torch.tensor(mat), compose_layers=compose,
+        compute_trg_disp=True, trg_downsampling=s, bg_layer_disp=0.2,
+        max_disp=1.0, zbuf_scale=50, path=path)
+    np.testing.assert_allclose(wts.cpu().numpy(), want['wts'], rtol=WTS_RTOL,
+                               atol=1e-30)
+    np.testing.assert_allclose(img.cpu().numpy(), want['img'], rtol=0,
+                               atol=IMG_ATOL)
+    np.testing.assert_allclose(dsp.cpu().numpy(), want['disp'], rtol=DSP_RTOL,
+                               atol=1e-6)
