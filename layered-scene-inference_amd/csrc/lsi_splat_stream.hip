@@ -580,7 +580,11 @@ __global__ __launch_bounds__(1024) void splat_stream_kernel(SplatArgs a,
             ((wymax != wymin) && rmax >= 0 && rmax < rows && !(dbg & 1)) ? 1
                                                                          : 0);
         float* const emax = extras + ((long)rmax * Wt + t_wlo) * 4;
-        const unsigned wspan = (unsigned)(t_wwin - 2);  // last left-cell offset
+        // last admissible left-cell offset; a window of fewer than two cells
+        // (the whole segment maps outside the image) admits no lane at all
+        const unsigned wspan = (unsigned)max(t_wwin - 2, 0);
+        const int win_ok = t_wwin >= 2 ? 1 : 0;
+        const unsigned long long win_mask = win_ok ? ~0ull : 0ull;
         // lanes exempt from the "strictly increasing" test: lane 0, and the
         // tail lanes beyond the image (no in-window lane follows them)
         const unsigned long long inr_mask = __ballot(inrange);
@@ -708,8 +712,8 @@ __global__ __launch_bounds__(1024) void splat_stream_kernel(SplatArgs a,
             // ballot is taken straight from one compare; the masks are
             // combined with scalar ops.
             const bool in_b = (unsigned)cl <= wspan;
-            const bool inw = in_b && inrange;
-            const unsigned long long inw_mask = __ballot(in_b) & inr_mask;
+            const bool inw = in_b && inrange && win_ok;
+            const unsigned long long inw_mask = __ballot(in_b) & inr_mask & win_mask;
             // lane l-1's floor(X) by DPP wave_shr:1 (VALU, no LDS round trip)
             const float prev = __int_as_float(__builtin_amdgcn_mov_dpp(
                 __float_as_int(x0), 0x138, 0xf, 0xf, true));
@@ -741,7 +745,7 @@ __global__ __launch_bounds__(1024) void splat_stream_kernel(SplatArgs a,
             // lanes outside the window: exact slow path (cells outside the
             // image and non-finite X fail its range tests and add nothing)
             if ((inr_mask & ~inw_mask) != 0ull && !(dbg & 1)) {
-              if (inrange && !in_b && V.w != 0.0f)
+              if (inrange && !inw && V.w != 0.0f)
                 slow_corners(extras, V, x0, w0, w1, xmax, wy0, wy1, t_row0,
                              rows, Wt);
             }

@@ -628,3 +628,56 @@ def test_any_pose_paths_under_hostile_projections(seed, path, dev, ref_cpu):
                                atol=IMG_ATOL)
     np.testing.assert_allclose(dsp.cpu().numpy(), want['disp'], rtol=DSP_RTOL,
                                atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('seed', range(10))
+def test_stream_path_under_hostile_row_uniform_projections(seed, dev, ref_cpu):
+  """Random matrices that satisfy the stream precondition but nothing else a
+  stereo rig would: mirrored or sheared x, target rows decreasing with the
+  source row (the analytic row range must fall back to the scan), a normaliser
+  that varies with the row, huge disparity shifts (windows overflow into the
+  exact slow path), disparities outside [0, max_disp], NaN / Inf pixels."""
+  from lsi import _C
+  from lsi.geometry import ldi
+  import ctypes
+  rs = np.random.RandomState(500 + seed)
+  nl, b, h, w = 3, 2, 48, 256
+  tex = rs.rand(nl, b, h, w, 3).astype(np.float32)
+  disp = rs.uniform(-0.1, 0.6, (nl, b, h, w, 1)).astype(np.float32)
+  mask = rs.rand(nl, b, h, w, 1).astype(np.float32)
+  if seed % 3 == 0:
+    disp[rs.rand(nl, b, h, w, 1) < 0.01] = np.nan
+    disp[rs.rand(nl, b, h, w, 1) < 0.005] = np.inf
+    disp[rs.rand(nl, b, h, w, 1) < 0.005] = -np.inf
+  mat = np.zeros((b, 4, 4), np.float32)
+  for i in range(b):
+    sx = rs.choice([-1.0, 1.0]) if seed % 2 else 1.0
+    sy = -1.0 if seed % 5 == 4 else 1.0
+    m = np.zeros((4, 4))
+    m[0] = [sx * rs.uniform(0.4, 1.8), rs.normal(0, 0.3), rs.uniform(-30, 30),
+            rs.choice([-1, 1]) * rs.uniform(0, 150)]
+    m[1] = [0, sy * rs.uniform(0.5, 1.6), rs.uniform(-8, 8) + (h if sy < 0 else 0), 0]
+    m[2] = [0, rs.normal(0, 0.004), rs.uniform(0.7, 1.4), 0]
+    m[3] = [0, 0, 0, 1] if seed < 5 else [rs.normal(0, 0.01), rs.normal(0, 0.01),
+                                          rs.normal(0, 0.1), rs.uniform(0.5, 1.5)]
+    mat[i] = m.astype(np.float32)
+  s = 0.5
+  probe = ldi._desc(torch.empty((nl, b, h, w, 3), device='meta'), None,
+                    torch.empty((nl, b, h, w, 1), device='meta'), h // 2, w // 2,
+                    s, 0.4, 50.0, 0.0, 0, 0)
+  ok = _C.lib().lsi_stream_ok(ctypes.byref(probe),
+                              ctypes.c_void_p(torch.tensor(mat).data_ptr()))
+  assert ok, 'the generator must produce matrices the stream path accepts'
+  for compose in (True, False):
+    want = ref_cpu.forward_splat(tex, mask, disp, mat, s, 1e-3, 0.4, 50, compose)
+    ldi_src = [torch.tensor(x, device=dev) for x in (tex, mask, disp)]
+    for mode in (1, 2):   # halo bands, exchange bands
+      img, wts = ldi.forward_splat_matrix(
+          ldi_src, torch.tensor(mat), compose_layers=compose, trg_downsampling=s,
+          bg_layer_disp=1e-3, max_disp=0.4, zbuf_scale=50, path='stream',
+          experiment=mode << 16)
+      np.testing.assert_allclose(wts.cpu().numpy(), want['wts'], rtol=WTS_RTOL,
+                                 atol=1e-30)
+      np.testing.assert_allclose(img.cpu().numpy(), want['img'], rtol=0,
+                                 atol=IMG_ATOL)
