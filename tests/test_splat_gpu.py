@@ -370,6 +370,61 @@ def test_backward_matches_autograd_of_the_op_graph(case, compose, dev):
     assert bad.mean() < 0.005, (name, bad.mean(), np.abs(got - want).max() / scale)
 
 
+@pytest.mark.parametrize('compose', [True, False])
+@pytest.mark.parametrize('seed', range(4))
+def test_backward_under_general_projections(seed, compose, dev):
+  """lsi_splat_bwd vs fp64 autograd for random projective matrices (rotation,
+  shear, a normaliser that varies over the image, part of the image leaving the
+  target), a mask input, disparities below 0 (zero weight) -- and, for the odd
+  seeds, NaN / Inf disparities, whose pixels are dropped: their gradients must
+  be exactly 0 and nothing else may turn non-finite."""
+  import lsi_torch_ref as TR
+  from lsi.geometry import ldi
+  rs = np.random.RandomState(900 + seed)
+  nl, b, h, w = 2, 1, 20, 28
+  tex = rs.rand(nl, b, h, w, 3).astype(np.float32)
+  disp = rs.uniform(-0.05, 0.45, (nl, b, h, w, 1)).astype(np.float32)
+  mask = rs.uniform(0.3, 1.0, (nl, b, h, w, 1)).astype(np.float32)
+  m = np.eye(4) + rs.normal(0, 0.12, (4, 4))
+  m[0, 2] += rs.uniform(-3, 3); m[1, 2] += rs.uniform(-3, 3)
+  m[0, 3] = rs.uniform(-12, 12); m[1, 3] = rs.uniform(-8, 8)
+  m[2] = [rs.normal(0, 0.004), rs.normal(0, 0.004), rs.uniform(0.8, 1.2),
+          rs.normal(0, 0.2)]
+  m[3] = [0, 0, 0, 1]
+  mat = m.astype(np.float32)[None]
+  dropped = np.zeros(disp.shape, bool)
+  if seed % 2:
+    dropped = rs.rand(*disp.shape) < 0.03
+    disp[dropped] = np.where(rs.rand(int(dropped.sum())) < 0.5, np.nan, np.inf)
+  s, bg, md, zb = 0.5, 1e-3, 0.4, 50.0
+  clean = np.where(dropped, 0.0, disp)        # fp64 graph: dropped = masked out
+  kill = np.where(dropped, 0.0, 1.0)
+  t64 = [torch.tensor(x, dtype=torch.float64, requires_grad=True)
+         for x in (tex, mask, clean)]
+  img, wts, _ = TR.forward_splat(t64[0], t64[1] * torch.tensor(kill), t64[2],
+                                 torch.tensor(mat, dtype=torch.float64), s, bg,
+                                 md, zb, compose)
+  gen = torch.Generator().manual_seed(seed)
+  cimg = torch.rand(img.shape, generator=gen, dtype=torch.float64)
+  cwts = torch.rand(wts.shape, generator=gen, dtype=torch.float64) * 1e-3
+  ((img * cimg).sum() + (torch.log(wts) * cwts).sum()).backward()
+  t32 = [torch.tensor(x, device=dev, requires_grad=True)
+         for x in (tex, mask, disp)]
+  img_g, wts_g = ldi.forward_splat_matrix(
+      t32, torch.tensor(mat), compose_layers=compose, trg_downsampling=s,
+      bg_layer_disp=bg, max_disp=md, zbuf_scale=zb)
+  ((img_g * cimg.float().to(dev)).sum() +
+   (torch.log(wts_g) * cwts.float().to(dev)).sum()).backward()
+  for a, b_, name in zip(t32, t64, ('tex', 'mask', 'disp')):
+    got = a.grad.cpu().double().numpy()
+    assert np.isfinite(got).all(), name
+    assert not got[np.broadcast_to(dropped, got.shape)].any(), name
+    want = np.where(np.broadcast_to(dropped, got.shape), 0.0, b_.grad.numpy())
+    scale = np.abs(want).max() + 1e-30
+    bad = np.abs(got - want) > 2e-4 * scale + 1e-3 * np.abs(want)
+    assert bad.mean() < 0.01, (name, bad.mean(), np.abs(got - want).max() / scale)
+
+
 # ---------------------------------------------------------------------------
 # LSI_PATH_STREAM specifics: every internal route (monotone RMW, ranked RMW,
 # exact slow path, window overflow) against the C oracle.
