@@ -226,3 +226,40 @@ def test_scene_generator_views_are_geometrically_consistent(dev):
   err = ((img[0] - trg).abs().mean(dim=3) * covered).sum() / covered.sum()
   assert float(covered.mean()) > 0.5
   assert float(err) < 0.06, float(err)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('seed', range(4))
+def test_sampling_ops_under_hostile_coordinates(seed, dev):
+  """bilinear and splat with coordinates on cell borders and centres, far
+  outside the image, huge, NaN and Inf: same values as the oracle, and finite
+  gradients (a non-finite coordinate samples / adds nothing)."""
+  from lsi.geometry import sampling
+  rs = np.random.RandomState(40 + seed)
+  b, hs, ws, c, ht, wt = 2, 9, 13, 3, 7, 11
+  imgs = rs.rand(b, hs, ws, c).astype(np.float32)
+  coords = np.stack([rs.uniform(-4, ws + 4, (b, ht, wt)),
+                     rs.uniform(-4, hs + 4, (b, ht, wt))], -1).astype(np.float32)
+  special = np.array([0.0, 0.5, 1.0, -0.5, ws - 0.5, ws, ws + 0.5, 1e9, -1e9,
+                      np.nan, np.inf, -np.inf, 3.5, 2.999999], np.float32)
+  pick = rs.rand(b, ht, wt, 2) < 0.35
+  coords[pick] = special[rs.randint(0, len(special), int(pick.sum()))]
+  want = O.bilinear(imgs, coords)
+  ti = T(imgs, dev).requires_grad_(True)
+  tc = T(coords, dev).requires_grad_(True)
+  got = sampling.bilinear(ti, tc)
+  np.testing.assert_allclose(got.detach().cpu().numpy(), want, rtol=1e-6,
+                             atol=1e-7)
+  got.sum().backward()
+  assert bool(torch.isfinite(ti.grad).all() and torch.isfinite(tc.grad).all())
+  # splat: source image to hostile target coordinates
+  src = rs.rand(b, ht, wt, c).astype(np.float32)
+  init = rs.rand(b, hs, ws, c).astype(np.float32)
+  want_s = O.splat(src, coords, init)
+  tsrc = T(src, dev).requires_grad_(True)
+  tc2 = T(coords, dev).requires_grad_(True)
+  got_s = sampling.splat(tsrc, tc2, T(init, dev))
+  np.testing.assert_allclose(got_s.detach().cpu().numpy(), want_s, rtol=1e-5,
+                             atol=1e-6)
+  got_s.sum().backward()
+  assert bool(torch.isfinite(tsrc.grad).all() and torch.isfinite(tc2.grad).all())
