@@ -736,3 +736,27 @@ def test_stream_path_under_hostile_row_uniform_projections(seed, dev, ref_cpu):
                                  atol=1e-30)
       np.testing.assert_allclose(img.cpu().numpy(), want['img'], rtol=0,
                                  atol=IMG_ATOL)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mode', [1, 2])
+@pytest.mark.parametrize('compose', [True, False])
+def test_stream_task_table_is_refilled_in_chunks(compose, mode, dev, ref_cpu):
+  """8-row bands at trg_downsampling 0.25 over 2304-pixel rows: 32 source rows
+  x 9 segments = 288 tasks per band, more than the 256-entry task table -- the
+  table is refilled mid-band, and again at the start of every later pass."""
+  from lsi.geometry import ldi
+  rs = np.random.RandomState(77)
+  nl, b, h, w = 2, 1, 96, 2304
+  tex, disp, mat = _synth(rs, nl, b, h, w)
+  s = 0.25
+  want = ref_cpu.forward_splat(tex, np.ones_like(disp), disp, mat, s, 1e-3, 0.4,
+                               50, compose)
+  ldi_src = [torch.tensor(tex, device=dev), None, torch.tensor(disp, device=dev)]
+  img, wts = ldi.forward_splat_matrix(
+      ldi_src, torch.tensor(mat), compose_layers=compose, trg_downsampling=s,
+      bg_layer_disp=1e-3, max_disp=0.4, zbuf_scale=50, path='stream',
+      band_rows=8, experiment=mode << 16)
+  np.testing.assert_allclose(wts.cpu().numpy(), want['wts'], rtol=WTS_RTOL)
+  np.testing.assert_allclose(img.cpu().numpy(), want['img'], rtol=0,
+                             atol=IMG_ATOL)
