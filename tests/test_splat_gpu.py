@@ -760,3 +760,26 @@ def test_stream_task_table_is_refilled_in_chunks(compose, mode, dev, ref_cpu):
   np.testing.assert_allclose(wts.cpu().numpy(), want['wts'], rtol=WTS_RTOL)
   np.testing.assert_allclose(img.cpu().numpy(), want['img'], rtol=0,
                              atol=IMG_ATOL)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(1, 37, 36, 64), (2, 5, 52, 128), (1, 201, 8, 64)])
+def test_stream_workgroup_placement_covers_every_band_once(shape, dev, ref_cpu):
+  """Workgroup -> (band, batch element) goes through an XCD-aware bijective
+  remap with reciprocal divisions: grids whose size is not a multiple of 8, one
+  band per image, hundreds of batch elements -- every output must be written."""
+  from lsi.geometry import ldi
+  nl, b, h, w = shape
+  rs = np.random.RandomState(b)
+  tex, disp, mat = _synth(rs, nl, b, h, w)
+  want = ref_cpu.forward_splat(tex, np.ones_like(disp), disp, mat, 0.5, 1e-3, 0.4,
+                               50, True)
+  ldi_src = [torch.tensor(tex, device=dev), None, torch.tensor(disp, device=dev)]
+  for rows in (0, 1, 2):
+    img = torch.full((1, b, h // 2, w // 2, 3), float('nan'), device=dev)
+    img, wts = ldi.forward_splat_matrix(
+        ldi_src, torch.tensor(mat), trg_downsampling=0.5, bg_layer_disp=1e-3,
+        max_disp=0.4, zbuf_scale=50, path='stream', band_rows=rows)
+    np.testing.assert_allclose(wts.cpu().numpy(), want['wts'], rtol=WTS_RTOL)
+    np.testing.assert_allclose(img.cpu().numpy(), want['img'], rtol=0,
+                               atol=IMG_ATOL)
