@@ -727,11 +727,11 @@ def test_stream_path_under_hostile_row_uniform_projections(seed, dev, ref_cpu):
   for compose in (True, False):
     want = ref_cpu.forward_splat(tex, mask, disp, mat, s, 1e-3, 0.4, 50, compose)
     ldi_src = [torch.tensor(x, device=dev) for x in (tex, mask, disp)]
-    for mode in (1, 2):   # halo bands, exchange bands
+    for mode in (1, 2, 0):   # stream: halo bands, exchange bands; 0: rowband
       img, wts = ldi.forward_splat_matrix(
           ldi_src, torch.tensor(mat), compose_layers=compose, trg_downsampling=s,
-          bg_layer_disp=1e-3, max_disp=0.4, zbuf_scale=50, path='stream',
-          experiment=mode << 16)
+          bg_layer_disp=1e-3, max_disp=0.4, zbuf_scale=50,
+          path='stream' if mode else 'rowband', experiment=mode << 16)
       np.testing.assert_allclose(wts.cpu().numpy(), want['wts'], rtol=WTS_RTOL,
                                  atol=1e-30)
       np.testing.assert_allclose(img.cpu().numpy(), want['img'], rtol=0,
