@@ -222,7 +222,9 @@ __device__ __forceinline__ UnitArgs unit_args() {
 
 // SIMPLE: the normaliser is exactly 1 and row 3 of M is (0,0,0,1) for every
 // batch element (rectified stereo): u = q0 and D = d with no division.
-template <int LAYOUT, bool SIMPLE>  // LAYOUT 0: channels-last RGB, 1: planar
+// LEAN: compose mode, no mask input, halo bands (the training / benchmark
+// configuration): the code and scalar registers of the other modes are gone.
+template <int LAYOUT, bool SIMPLE, bool LEAN>  // LAYOUT 0: channels-last, 1: planar
 __global__ __launch_bounds__(1024) void splat_stream_kernel(SplatArgs a,
                                                            StreamCfg cfg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -264,7 +266,7 @@ __global__ __launch_bounds__(1024) void splat_stream_kernel(SplatArgs a,
   //     (cheaper when a band is only a few microseconds of work).
   const int nbands = gridDim.x;
   const int row0 = band * R;
-  const int xchg = cfg.exchange;  // (uniform flags are ints: one SGPR, not a lane mask)
+  const int xchg = LEAN ? 0 : cfg.exchange;  // (uniform flags are ints: one SGPR)
   const int rows = min(xchg ? R + 1 : R, Ht - row0);  // tile rows
   const int k_lo = xchg ? (band == 0 ? -1 : row0) : row0 - 1;
   const int k_hi = xchg ? min(row0 + R, Ht) - 1 : row0 + rows - 1;
@@ -310,8 +312,8 @@ __global__ __launch_bounds__(1024) void splat_stream_kernel(SplatArgs a,
 #endif
   const int nlayers = d.L;
   const float xmax = (float)Wt - 1.0f, ymax = (float)Ht - 1.0f;
-  const bool has_mask = d.flags & LSI_HAS_MASK;
-  const bool compose = d.flags & LSI_COMPOSE;
+  const bool has_mask = LEAN ? false : (d.flags & LSI_HAS_MASK) != 0;
+  const bool compose = LEAN ? true : (d.flags & LSI_COMPOSE) != 0;
   const float inv_md = div_rn(1.0f, max_disp);
 
   long long* tdbg = (dbg & 4)
@@ -1159,13 +1161,17 @@ int lsi_stream_launch(const SplatArgs& a, hipStream_t stream) {
   }
   dim3 grid((d->Ht + R - 1) / R, d->B);
   const bool simple = (d->tune_window & LSI_STREAM_SIMPLE_BIT) != 0;
+  const bool lean = (d->flags & LSI_COMPOSE) && !(d->flags & LSI_HAS_MASK) &&
+                    !cfg.exchange;
   const void* fn;
+#define LSI_PICK(L_, S_) \
+  (lean ? (const void*)splat_stream_kernel<L_, S_, true> \
+        : (const void*)splat_stream_kernel<L_, S_, false>)
   if (layout == 0)
-    fn = simple ? (const void*)splat_stream_kernel<0, true>
-                : (const void*)splat_stream_kernel<0, false>;
+    fn = simple ? LSI_PICK(0, true) : LSI_PICK(0, false);
   else
-    fn = simple ? (const void*)splat_stream_kernel<1, true>
-                : (const void*)splat_stream_kernel<1, false>;
+    fn = simple ? LSI_PICK(1, true) : LSI_PICK(1, false);
+#undef LSI_PICK
   if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)lds) != hipSuccess)
     return LSI_ELAUNCH;
