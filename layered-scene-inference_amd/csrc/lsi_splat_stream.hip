@@ -222,9 +222,10 @@ __device__ __forceinline__ UnitArgs unit_args() {
 
 // SIMPLE: the normaliser is exactly 1 and row 3 of M is (0,0,0,1) for every
 // batch element (rectified stereo): u = q0 and D = d with no division.
-// LEAN: compose mode, no mask input, halo bands (the training / benchmark
-// configuration): the code and scalar registers of the other modes are gone.
-template <int LAYOUT, bool SIMPLE, bool LEAN>  // LAYOUT 0: channels-last, 1: planar
+// MODE 1 / 2: compose mode without a mask input (the training / benchmark
+// configuration) with halo / exchange bands: the code and scalar registers of
+// the other modes are gone.  MODE 0: everything, decided at run time.
+template <int LAYOUT, bool SIMPLE, int MODE>  // LAYOUT 0: channels-last, 1: planar
 __global__ __launch_bounds__(1024) void splat_stream_kernel(SplatArgs a,
                                                            StreamCfg cfg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -266,7 +267,8 @@ __global__ __launch_bounds__(1024) void splat_stream_kernel(SplatArgs a,
   //     (cheaper when a band is only a few microseconds of work).
   const int nbands = gridDim.x;
   const int row0 = band * R;
-  const int xchg = LEAN ? 0 : cfg.exchange;  // (uniform flags are ints: one SGPR)
+  constexpr bool LEAN = MODE != 0;
+  const int xchg = MODE == 1 ? 0 : (MODE == 2 ? 1 : cfg.exchange);
   const int rows = min(xchg ? R + 1 : R, Ht - row0);  // tile rows
   const int k_lo = xchg ? (band == 0 ? -1 : row0) : row0 - 1;
   const int k_hi = xchg ? min(row0 + R, Ht) - 1 : row0 + rows - 1;
@@ -1161,12 +1163,13 @@ int lsi_stream_launch(const SplatArgs& a, hipStream_t stream) {
   }
   dim3 grid((d->Ht + R - 1) / R, d->B);
   const bool simple = (d->tune_window & LSI_STREAM_SIMPLE_BIT) != 0;
-  const bool lean = (d->flags & LSI_COMPOSE) && !(d->flags & LSI_HAS_MASK) &&
-                    !cfg.exchange;
+  const bool lean = (d->flags & LSI_COMPOSE) && !(d->flags & LSI_HAS_MASK);
+  const int mode = lean ? (cfg.exchange ? 2 : 1) : 0;
   const void* fn;
-#define LSI_PICK(L_, S_) \
-  (lean ? (const void*)splat_stream_kernel<L_, S_, true> \
-        : (const void*)splat_stream_kernel<L_, S_, false>)
+#define LSI_PICK(L_, S_)                                                   \
+  (mode == 1 ? (const void*)splat_stream_kernel<L_, S_, 1>                  \
+             : mode == 2 ? (const void*)splat_stream_kernel<L_, S_, 2>      \
+                         : (const void*)splat_stream_kernel<L_, S_, 0>)
   if (layout == 0)
     fn = simple ? LSI_PICK(0, true) : LSI_PICK(0, false);
   else
