@@ -427,27 +427,30 @@ __global__ __launch_bounds__(1024) void splat_stream_kernel(SplatArgs a,
                       fabsf(YB) < 65536.0f && nA > 0.0f && nB > 0.0f &&
                       (H == 1 || (YB - YA) >= 0.0625f * (float)(H - 1));
       if (ok) {
-        // first row y in [0, H] with Y(y) >= k  (H: none)
+        // first row y in [0, H] with Y(y) >= k  (H: none).  The 64 lanes test
+        // 64 consecutive rows around the estimate with the exact fp32 Y: the
+        // answer is the first lane that passes, provided the lanes before it
+        // (and, by monotonicity, every earlier row) fail.
+        const float inv_s = __builtin_amdgcn_rcpf(s);  // estimates only
         auto lower = [&](float k, bool& good) {
           // (k + 0.5)/s = (py*m11 + m12)/(py*m21 + m22)  =>  py
-          const float t = (k + 0.5f) / s;
-          const float den = m[5] - m[9] * t;
-          float py = (m[10] * t - m[6]) / den;
-          if (SIMPLE) py = (t - m[6]) / m[5];
-          int c = finite_f(py) ? (int)fminf(fmaxf(ceilf(py - 0.5f), -1.0f),
-                                            (float)H + 1.0f)
-                               : 0;
-          c = max(0, min(H, c));
+          const float t = (k + 0.5f) * inv_s;
+          const float py = SIMPLE ? (t - m[6]) * __builtin_amdgcn_rcpf(m[5])
+                                  : (m[10] * t - m[6]) *
+                                        __builtin_amdgcn_rcpf(m[5] - m[9] * t);
+          const int c = finite_f(py) ? (int)fminf(fmaxf(ceilf(py - 0.5f), 0.0f),
+                                                  (float)H)
+                                     : 0;
+          const int base = max(0, min(c - 32, H - 64));
+          const int y = base + lane;
           float nd;
-  #pragma unroll 1
-          for (int it = 0; it < 4; ++it) {
-            if (c > 0 && row_Y(c - 1, nd) >= k) --c;
-            else if (c < H && !(row_Y(c, nd) >= k)) ++c;
-            else break;
-          }
-          good = good && (c == 0 || !(row_Y(c - 1, nd) >= k)) &&
-                 (c == H || row_Y(c, nd) >= k);
-          return c;
+          // rows past the image count as passing: the result is then H
+          const bool pass_ = y >= H || row_Y(y, nd) >= k;
+          const unsigned long long mask = __ballot(pass_);
+          const int p = mask ? __builtin_ctzll(mask) : 64;
+          good = good && mask == (p < 64 ? (~0ull << p) : 0ull) &&
+                 (p > 0 || base == 0) && (p < 64 || base + 64 >= H);
+          return min(base + p, H);
         };
         bool good = true;
         const int lo = lower((float)k_lo, good);
@@ -456,6 +459,7 @@ __global__ __launch_bounds__(1024) void splat_stream_kernel(SplatArgs a,
       }
     }
     if (lane == 0) { yrange[0] = y_lo; yrange[1] = y_hi; yrange[3] = ranged; }
+    LSI_TSTAMP();
     if (ranged)
       fill_tasks(0, lane, 64, y_lo,
                  ((y_hi >= y_lo) ? (y_hi - y_lo + 1) : 0) * nseg);
