@@ -225,7 +225,8 @@ __device__ __forceinline__ UnitArgs unit_args() {
 // MODE 1 / 2: compose mode without a mask input (the training / benchmark
 // configuration) with halo / exchange bands: the code and scalar registers of
 // the other modes are gone.  MODE 0: everything, decided at run time.
-template <int LAYOUT, bool SIMPLE, int MODE>  // LAYOUT 0: channels-last, 1: planar
+// FULL: W is a multiple of the 256-pixel segment: every lane always has pixels.
+template <int LAYOUT, bool SIMPLE, int MODE, bool FULL>  // LAYOUT 0: channels-last, 1: planar
 __global__ __launch_bounds__(1024) void splat_stream_kernel(SplatArgs a,
                                                            StreamCfg cfg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -535,7 +536,7 @@ __global__ __launch_bounds__(1024) void splat_stream_kernel(SplatArgs a,
 
         float4* rb = rb_all + slot * WMAX;
         const int x = xs + 4 * lane;
-        const bool inrange = x < W;
+        const bool inrange = FULL ? true : x < W;
         const float py = (float)y + 0.5f;
         // row-uniform pieces of q = M p, in the contract's rounding order
         const float pym01 = py * m[1];
@@ -595,7 +596,7 @@ __global__ __launch_bounds__(1024) void splat_stream_kernel(SplatArgs a,
         const unsigned long long win_mask = win_ok ? ~0ull : 0ull;
         // lanes exempt from the "strictly increasing" test: lane 0, and the
         // tail lanes beyond the image (no in-window lane follows them)
-        const unsigned long long inr_mask = __ballot(inrange);
+        const unsigned long long inr_mask = FULL ? ~0ull : __ballot(inrange);
         const unsigned long long edge_mask = ~inr_mask | 1ull;
         const int l_end = l_begin + Lp;
 
@@ -1170,14 +1171,17 @@ int lsi_stream_launch(const SplatArgs& a, hipStream_t stream) {
   const bool lean = (d->flags & LSI_COMPOSE) && !(d->flags & LSI_HAS_MASK);
   const int mode = lean ? (cfg.exchange ? 2 : 1) : 0;
   const void* fn;
-#define LSI_PICK(L_, S_)                                                   \
-  (mode == 1 ? (const void*)splat_stream_kernel<L_, S_, 1>                  \
-             : mode == 2 ? (const void*)splat_stream_kernel<L_, S_, 2>      \
-                         : (const void*)splat_stream_kernel<L_, S_, 0>)
+#define LSI_PICK2(L_, S_, M_)                                              \
+  (full ? (const void*)splat_stream_kernel<L_, S_, M_, true>                \
+        : (const void*)splat_stream_kernel<L_, S_, M_, false>)
+#define LSI_PICK(L_, S_) \
+  (mode == 1 ? LSI_PICK2(L_, S_, 1) : mode == 2 ? LSI_PICK2(L_, S_, 2) : LSI_PICK2(L_, S_, 0))
+  const bool full = d->W % SEG == 0;
   if (layout == 0)
     fn = simple ? LSI_PICK(0, true) : LSI_PICK(0, false);
   else
     fn = simple ? LSI_PICK(1, true) : LSI_PICK(1, false);
+#undef LSI_PICK2
 #undef LSI_PICK
   if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)lds) != hipSuccess)
