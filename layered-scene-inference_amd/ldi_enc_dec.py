@@ -63,6 +63,8 @@ def build_parser():
   a('--bf16', type=_bool, default=False, help='bf16 autocast for the convs')
   a('--channels_last', type=_bool, default=True)
   a('--cpu', type=_bool, default=False, help='CPU run (no splat losses)')
+  a('--miopen_search', type=_bool, default=False,
+    help='exhaustive MIOpen solver search (torch.backends.cudnn.benchmark)')
   a('--hip_graph', type=_bool, default=False,
     help='capture the training step in a HIP graph (single process)')
   return p

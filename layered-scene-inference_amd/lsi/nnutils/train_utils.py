@@ -77,9 +77,12 @@ class Trainer(object):
     if use_gpu:
       torch.cuda.set_device(self.local_rank)
       self.device = torch.device('cuda', self.local_rank)
-      # static shapes: let MIOpen time its solvers once per layer (the step is
-      # bound by the convolutions; 16 % faster at batch 4, 256 x 768)
-      torch.backends.cudnn.benchmark = True
+      # --miopen_search: let MIOpen time every solver once per layer (static
+      # shapes; the step is bound by the convolutions: 16 % faster at batch 4,
+      # 256 x 768).  Off by default: with ROCm 7.2 one of the candidate
+      # igemm_bwd kernels the search tries was seen to fault (GPU memory access
+      # fault inside MIOpen's search, depending on where buffers happen to lie).
+      torch.backends.cudnn.benchmark = bool(getattr(opts, 'miopen_search', False))
     if self.world > 1:
       import torch.distributed as dist
       if not dist.is_initialized():
