@@ -16,7 +16,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, 'csrc')
 SO = os.path.join(PKG, 'liblsi_hip.so')
 SOURCES = ['lsi_splat.hip', 'lsi_splat_stream.hip', 'lsi_splat_tile.hip',
-           'lsi_sampling.hip', 'lsi_fused.hip']
+           'lsi_sampling.hip']
 HEADERS = [os.path.join(CSRC, 'lsi_common.h'),
            os.path.join(CSRC, 'lsi_splat_internal.h'),
            os.path.join(ROOT, 'include', 'lsi_hip.h')]
@@ -50,8 +50,7 @@ def build(force=False, verbose=False, hooks=False):
   """hooks=True builds liblsi_hip_hooks.so: the same library with the stream
   kernel's timing-experiment hooks compiled in (tools/phase_probe.py,
   bench.py --debug-flags; select it with LSI_HIP_LIB=hooks)."""
-  srcs = [os.path.join(CSRC, s) for s in SOURCES
-          if os.path.exists(os.path.join(CSRC, s))]
+  srcs = [os.path.join(CSRC, s) for s in SOURCES]
   so = SO_HOOKS if hooks else SO
   ext = '.hooks.o' if hooks else '.o'
   flags = HIPCC_FLAGS + (['-DLSI_STREAM_HOOKS=1'] if hooks else [])

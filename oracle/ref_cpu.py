@@ -32,6 +32,11 @@ def lib():
     _lib.lsi_ref_forward_splat.argtypes = (
         [fp, fp, fp, fp] + [ctypes.c_int] * 6 + [ctypes.c_double] * 4 +
         [ctypes.c_int, fp, fp, fp, ip, fp, ctypes.c_int])
+    _lib.lsi_ref_forward_splat_ws.restype = ctypes.c_int
+    _lib.lsi_ref_forward_splat_ws.argtypes = (
+        _lib.lsi_ref_forward_splat.argtypes + [fp, ctypes.c_size_t])
+    _lib.lsi_ref_canvas_floats.restype = ctypes.c_size_t
+    _lib.lsi_ref_canvas_floats.argtypes = [ctypes.c_int] * 6
     _lib.lsi_ref_num_threads.restype = ctypes.c_int
   return _lib
 
@@ -76,3 +81,31 @@ def forward_splat(tex, mask, disp, mat, trg_downsampling=1, bg_layer_disp=0,
   if debug:
     out.update(idx4=idx4, upd4=upd4)
   return out
+
+
+class Context(object):
+  """Pre-allocated outputs and canvas scratch for repeated compose-mode calls
+  of one shape (bench.py's CPU baseline: no allocation or first-touch page
+  faults inside the timed loop)."""
+
+  def __init__(self, nl, b, h, w, ht, wt, nthreads=0):
+    self.shape = (nl, b, h, w, ht, wt)
+    self.nthreads = int(nthreads)
+    n = int(lib().lsi_ref_canvas_floats(nl, b, h, ht, wt, self.nthreads))
+    self.canv = np.zeros((n,), np.float32)   # touched once here
+    self.img = np.zeros((1, b, ht, wt, 3), np.float32)
+    self.wts = np.zeros((1, b, ht, wt, 1), np.float32)
+
+  def forward_splat(self, tex, mask, disp, mat, trg_downsampling, bg_layer_disp,
+                    max_disp, zbuf_scale):
+    nl, b, h, w, ht, wt = self.shape
+    assert tex.shape == (nl, b, h, w, 3) and tex.dtype == np.float32
+    rc = lib().lsi_ref_forward_splat_ws(
+        _p(tex), _p(mask), _p(disp), _p(mat), nl, b, h, w, ht, wt,
+        float(trg_downsampling), float(bg_layer_disp), float(max_disp),
+        float(zbuf_scale), 1, _p(self.img), _p(self.wts), _p(None),
+        _p(None, ctypes.c_int32), _p(None), self.nthreads, _p(self.canv),
+        self.canv.size)
+    if rc != 0:
+      raise RuntimeError('lsi_ref_forward_splat_ws failed: %d' % rc)
+    return {'img': self.img, 'wts': self.wts}

@@ -63,6 +63,45 @@ def test_two_rank_gloo_sharding_and_timing_reduction():
   np.testing.assert_array_equal(r0['mat'], r1['mat'])  # same cameras
 
 
+def test_bare_shell_multi_gpu_launch_selftest():
+  """`python bench.py --gpus 2` from a bare shell re-launches itself under
+  torch.distributed.run, one rank per GPU, and rank 0 prints ONE JSON line with
+  n_gpus = 2.  Here the ranks use gloo and skip the GPU work
+  (--selftest-backend): the launch, rendezvous, shard and max-reduction logic
+  is the same code the GPU run goes through."""
+  import json
+  import subprocess
+  env = dict(os.environ)
+  for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+    env.pop(k, None)
+  out = subprocess.run(
+      [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2',
+       '--selftest-backend', 'gloo'], env=env, capture_output=True, text=True,
+      timeout=300)
+  assert out.returncode == 0, out.stderr[-2000:]
+  lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+  assert len(lines) == 1, out.stdout
+  rec = json.loads(lines[0])
+  assert rec['n_gpus'] == 2 and rec['scaling'] == 'strong'
+  assert rec['views_per_step'] == 32          # cfg3: 16 views per rank
+  assert abs(rec['elapsed_max'] - 2.0e-3) < 1e-9   # max over ranks
+
+
+def test_self_launch_command_line():
+  sys.path.insert(0, ROOT)
+  import bench
+  argv = bench.self_launch_argv(['--gpus', '8', '--steps', '5'], 8, port=1234)
+  assert argv[1:3] == ['-m', 'torch.distributed.run']
+  assert '--nproc-per-node' in argv and argv[argv.index('--nproc-per-node') + 1] == '8'
+  assert argv[argv.index('--master-addr') + 1] == '127.0.0.1'
+  assert argv[-4:] == ['--gpus', '8', '--steps', '5']
+  assert bench.DEFAULT_WORKLOAD == 'cfg3'
+  # every workload's input sets exceed the Infinity Cache when rotated
+  for wl, (nl, h, w, batch, per_gpu, _, _, _) in bench.WORKLOADS.items():
+    n = bench.rotation_sets(nl, batch, h, w)
+    assert n * nl * batch * h * w * 16 >= bench.ROTATE_BYTES or n == 64
+
+
 def test_shard_rejects_uneven_split():
   import pytest
   sys.path.insert(0, ROOT)

@@ -1,0 +1,109 @@
+"""Parity at BASELINE.json's FULL sizes: every
+configuration's shape goes through the HIP path once and is compared with the
+plain-C oracle (oracle/lsi_ref_cpu.c) on the same seeded inputs -- the inputs
+bench.py generates (`make_inputs`: smooth disparities, KITTI-like or look-at
+cameras).  Bars as in tests/test_splat_gpu.py: pixel indices bit-exact, RGB
+|err| <= 2e-5, weights / disparity 1e-4 relative.
+
+  cfg3  4-layer 256x768, batch 32, KITTI      -> STREAM
+  cfg4  3-layer 256x256, batch 8 and 64, look-at poses + soft masks -> TILE
+  cfg5  4-layer 512x1536, batch 1 (both band modes) and 8, KITTI -> STREAM
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+IMG_ATOL, WTS_RTOL, DSP_RTOL = 2e-5, 1e-4, 1e-4
+ZB = 50.0
+
+
+@pytest.fixture(scope='module')
+def dev(built_lib):
+  if not torch.cuda.is_available():
+    pytest.fail('gpu test selected but no ROCm device is visible')
+  return torch.device('cuda:0')
+
+
+def _inputs(workload, batch, seed, with_mask=False):
+  import sys
+  sys.path.insert(0, ROOT)
+  import bench
+  nl, h, w, _, _, cams, max_disp, bg = bench.WORKLOADS[workload]
+  tex, disp, mat = bench.make_inputs(nl, batch, h, w, cams, max_disp, seed,
+                                     torch.device('cpu'))
+  mask = None
+  if with_mask:
+    gen = torch.Generator(device='cpu').manual_seed(seed + 1)
+    mask = torch.rand((nl, batch, h, w, 1), generator=gen)
+  return tex, mask, disp, mat, max_disp, bg
+
+
+def _render(dev, tex, mask, disp, mat, max_disp, bg, path, want_disp,
+            experiment=0, compose=True):
+  from lsi.geometry import ldi
+  src = [tex.to(dev), None if mask is None else mask.to(dev), disp.to(dev)]
+  return ldi.forward_splat_matrix(
+      src, mat, compose_layers=compose, compute_trg_disp=want_disp,
+      trg_downsampling=0.5, bg_layer_disp=bg, max_disp=max_disp,
+      zbuf_scale=ZB, path=path, experiment=experiment)
+
+
+def _check(out, want, want_disp):
+  np.testing.assert_allclose(out[0].cpu().numpy(), want['img'], rtol=0,
+                             atol=IMG_ATOL)
+  np.testing.assert_allclose(out[1].cpu().numpy(), want['wts'], rtol=WTS_RTOL)
+  if want_disp:
+    np.testing.assert_allclose(out[2].cpu().numpy(), want['disp'],
+                               rtol=DSP_RTOL, atol=1e-7)
+
+
+@pytest.mark.parametrize('batch', [8, 64])
+def test_cfg4_tile_path_full_size(batch, dev, ref_cpu):
+  """Synthetic 3-layer 256x256 with general (look-at) poses and soft masks:
+  the any-pose TILE kernel, whose tile height depends on B and Ht."""
+  tex, mask, disp, mat, md, bg = _inputs('cfg4', batch, 40 + batch, True)
+  want = ref_cpu.forward_splat(tex.numpy(), mask.numpy(), disp.numpy(),
+                               mat.numpy(), 0.5, bg, md, ZB, True)
+  out = _render(dev, tex, mask, disp, mat, md, bg, 'auto', True)
+  _check(out, want, True)
+  out = _render(dev, tex, None, disp, mat, md, bg, 'tile', False)
+  want = ref_cpu.forward_splat(tex.numpy(), None, disp.numpy(), mat.numpy(),
+                               0.5, bg, md, ZB, True, want_disp=False)
+  _check(out, want, False)
+
+
+@pytest.mark.parametrize('mode', [0, 1, 2])  # planner's choice, halo, exchange
+def test_cfg5_stream_path_full_size_one_view(mode, dev, ref_cpu):
+  """KITTI 4-layer 512x1536 (Wt = 768: six 256-pixel segments per source row):
+  STREAM in both band decompositions, plus bit-exact pixel indices."""
+  from lsi.geometry import ldi
+  tex, _, disp, mat, md, bg = _inputs('cfg5', 1, 50)
+  want = ref_cpu.forward_splat(tex.numpy(), None, disp.numpy(), mat.numpy(),
+                               0.5, bg, md, ZB, True, want_disp=False,
+                               debug=(mode == 0))
+  out = _render(dev, tex, None, disp, mat, md, bg, 'stream', False,
+                experiment=mode << 16)
+  _check(out, want, False)
+  if mode == 0:
+    idx4, upd4 = ldi.project_indices(disp.to(dev), None, mat, 0.5, md, ZB)
+    assert np.array_equal(idx4.cpu().numpy(), want['idx4'])
+    np.testing.assert_allclose(upd4.cpu().numpy(), want['upd4'], rtol=2e-5)
+
+
+@pytest.mark.parametrize('workload,batch', [('cfg5', 8), ('cfg3', 32),
+                                            ('cfg2', 4)])
+def test_kitti_configs_full_batch(workload, batch, dev, ref_cpu):
+  """The whole batch of configs 2, 3 and 5 on one GPU, compose and per-layer."""
+  tex, _, disp, mat, md, bg = _inputs(workload, batch, 60 + batch)
+  for compose in (True, False):
+    want = ref_cpu.forward_splat(tex.numpy(), None, disp.numpy(), mat.numpy(),
+                                 0.5, bg, md, ZB, compose, want_disp=False)
+    out = _render(dev, tex, None, disp, mat, md, bg, 'auto', False,
+                  compose=compose)
+    _check(out, want, False)
+    if workload != 'cfg2':
+      break   # per-layer outputs of the large configs: covered by cfg2's shape

@@ -223,3 +223,25 @@ def test_torch_gradient_oracle_matches_forward_and_finite_differences():
         fd2 = (loss_of(*ap) - loss_of(*args)) / eps
         assert (abs(float(fd2) - float(grad[ix])) <= 1e-3 * max(1.0, abs(float(fd2)))
                 or abs(float(fd) - float(fd2)) > 1e-3), (ix, fd, fd2, grad[ix])
+
+
+@pytest.mark.parametrize('case', ['fs_kitti_L2_s05.npz', 'fs_general_L3_s05.npz',
+                                  'fs_cfg1_synth_L1_64.npz'])
+@pytest.mark.parametrize('compose', [True, False])
+def test_cpu_baseline_a_matches_the_goldens(case, compose):
+  """oracle/baseline_tf_graph.py (bench.py's CPU baseline A: the reference's
+  op-for-op decomposition on torch-CPU) renders the reference's goldens.  Its
+  batched matmul is the library's (FMA / blocked order), so a handful of pixels
+  may round to the neighbouring cell: the bar is the image tolerance x4 and
+  1e-3 on the weights, not bit-exact indices."""
+  import torch
+  import baseline_tf_graph as A
+  g = golden(case)
+  s, bg, md, zb = [float(v) for v in g['params']]
+  tag = 'compose' if compose else 'indep'
+  img, wts, dsp = A.forward_splat(
+      torch.tensor(g['tex']), torch.tensor(g['mask']), torch.tensor(g['disp']),
+      torch.tensor(g['M']), s, bg, md, zb, compose, True)
+  np.testing.assert_allclose(img.numpy(), g[tag + '_img'], rtol=0, atol=1e-4)
+  np.testing.assert_allclose(wts.numpy(), g[tag + '_wts'], rtol=1e-3)
+  np.testing.assert_allclose(dsp.numpy(), g[tag + '_disp'], rtol=1e-3, atol=1e-6)
