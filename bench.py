@@ -69,7 +69,8 @@ def box_blur(x, radius):
   return torch.nn.functional.avg_pool2d(pad, k, stride=1)
 
 
-def make_inputs(nl, b, h, w, cams, max_disp, seed, dev, disp_kind='smooth'):
+def make_inputs(nl, b, h, w, cams, max_disp, seed, dev, disp_kind='smooth',
+                tex_layout='nhwc'):
   """Seeded synthetic LDI + cameras.
 
   disp_kind:
@@ -82,6 +83,8 @@ def make_inputs(nl, b, h, w, cams, max_disp, seed, dev, disp_kind='smooth'):
   """
   gen = torch.Generator(device='cpu').manual_seed(seed)
   tex = torch.rand((nl, b, h, w, 3), generator=gen).to(dev)
+  if tex_layout == 'planar':  # same logical tensor stored L x B x 3 x H x W
+    tex = tex.permute(0, 1, 4, 2, 3).contiguous().permute(0, 1, 3, 4, 2)
   noise = torch.rand((nl * b, 1, h, w), generator=gen).to(dev)
   if disp_kind == 'stress':
     field = (0.01 + 0.99 * noise).reshape(nl, b, h, w, 1)
@@ -362,11 +365,11 @@ def measure_traffic(args, timeout_s=150):
 def build_renderer(workload, b_local, seed, dev, args):
   nl, h, w, batch, per_gpu, cams, max_disp, bg = WORKLOADS[workload]
   tex, disp, mat = make_inputs(nl, b_local, h, w, cams, max_disp, seed, dev,
-                               args.disp)
+                               args.disp, args.tex_layout)
   extra = []
   for i in range(1, rotation_sets(nl, b_local, h, w)):
     t2, d2, _ = make_inputs(nl, b_local, h, w, cams, max_disp,
-                            seed + 7919 * i, dev, args.disp)
+                            seed + 7919 * i, dev, args.disp, args.tex_layout)
     extra.append((t2, d2))
   return Renderer(tex, disp, mat, max_disp, bg, args.path, args.band_rows,
                   args.threads, extra)
@@ -441,6 +444,10 @@ def main():
                   'LSI_HIP_LIB=hooks (build.py --hooks)')
   ap.add_argument('--disp', default='smooth',
                   choices=['smooth', 'rough', 'stress'])
+  ap.add_argument('--tex-layout', default='nhwc', choices=['nhwc', 'planar'],
+                  help='storage of the textures: the reference\'s channels-last '
+                  'L x B x H x W x 3 (default) or planar L x B x 3 x H x W (what '
+                  'a conv decoder emits); same logical tensor either way')
   args = ap.parse_args()
 
   world = int(os.environ.get('WORLD_SIZE', '1'))

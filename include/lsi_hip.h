@@ -48,6 +48,10 @@ extern "C" {
 #define LSI_WANT_DISP 2u     /* compute_trg_disp=True (ldi.py:179-180)        */
 #define LSI_HAS_MASK 4u      /* mask pointer is given (else mask == 1)        */
 #define LSI_WS_KEEP 8u       /* workspace state is kept between calls (below) */
+#define LSI_DETERMINISTIC 16u /* bitwise run-to-run reproducible results: the  */
+                             /* STREAM path then adds its partial sums in a   */
+                             /* fixed order (slower); TILE is always          */
+                             /* reproducible, ATOMIC / ROWBAND never are      */
 
 /* LsiSplatDesc.path: which kernel family renders the splat.                  */
 #define LSI_PATH_AUTO 0      /* library decides from the descriptor          */

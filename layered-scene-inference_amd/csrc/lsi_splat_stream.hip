@@ -60,7 +60,10 @@ using namespace lsi;
 namespace {
 
 constexpr int SEG = 256;   // source pixels per task (64 lanes x 4)
-constexpr int MAXNW = 16;
+#ifndef LSI_STREAM_MAXT
+#define LSI_STREAM_MAXT 1024
+#endif
+constexpr int MAXNW = LSI_STREAM_MAXT / 64;
 // lsi_stream_ok's return value: window cells, plus this bit when every batch
 // element has normaliser == 1 and M row 3 == (0,0,0,1) (division-free kernel)
 constexpr int LSI_STREAM_SIMPLE_BIT = 1 << 20;
@@ -79,14 +82,21 @@ struct __attribute__((aligned(16))) TaskB {
   int y, xs;       // source row, first source pixel of the segment
 };
 
+struct __attribute__((aligned(16))) TaskC {
+  float tmin, tmax;  // clamp thresholds on a side weight (clamp_threshold)
+  int l0, l1;        // layers [l0, l1) of this task
+};
+
 struct alignas(16) StreamCfg {  // (kernarg offset: see epilogue_args)
   int R;      // target rows per workgroup
-  int wmax;   // window cells per task
-  int tpw;    // windows per wave: nw * tpw tasks are in flight per step
-  int cap;    // task-table entries, a multiple of nw * tpw
+  int wmax;   // window cells per wave
+  int cap;    // task-table entries per chunk
   int nb;     // 64-cell units per target row
-  int steps_per_chunk;  // cap / (nw * tpw)
-  float inv_nb, inv_nwin, inv_gx;  // reciprocals for division-free indexing
+  int ngrp;   // compose mode: layer groups per (row, segment) ...
+  int lpg;    // ... of this many layers each
+  int qcap;   // per-wave queue entries for corners outside the window scheme
+  float inv_nb, inv_gx;  // reciprocals for division-free indexing
+  float inv_per_row, inv_ngrp, inv_nseg;
   // boundary-row exchange area in the workspace (see stream_exchange_layout)
   int* xcount;     // [npass][B][nbands] arrival counters, zero between calls
   float4* xpart;   // [npass][B][nbands][2][Wt] partial rows
@@ -220,6 +230,53 @@ __device__ __forceinline__ UnitArgs unit_args() {
   return u;
 }
 
+// n-th float above / below a positive finite float
+__device__ __forceinline__ float next_up(float t) {
+  return __int_as_float(__float_as_int(t) + 1);
+}
+__device__ __forceinline__ float next_down(float t) {
+  return __int_as_float(__float_as_int(t) - 1);
+}
+
+// Smallest side weight w with fl(w * wy) > 1e-3f (sampling.py:218-222 keeps a
+// corner iff its rounded weight product exceeds 1e-3).  fp32 rounding is
+// monotone, so "w >= threshold" is EXACTLY "fl(w*wy) > 1e-3f" for every w:
+// one compare instead of a multiply and a compare in the hot loop.  +Inf when
+// no weight <= 1 qualifies.
+__device__ __forceinline__ float clamp_threshold(float wy) {
+  if (!(wy > 0.0f)) return __builtin_inff();
+  float t = div_rn(1.0e-3f, wy);
+  if (!(t < 4.0f)) return __builtin_inff();
+  for (int k = 0; k < 8; ++k) {
+    const float p = next_down(t);
+    if (p * wy > 1.0e-3f) t = p; else break;
+  }
+  for (int k = 0; k < 8; ++k) {
+    if (!(t * wy > 1.0e-3f)) t = next_up(t); else break;
+  }
+  return t;
+}
+
+// lane l-1's value by DPP wave_shr:1 (VALU, no LDS round trip); lane 0 gets 0
+__device__ __forceinline__ float lane_below(float v) {
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x138, 0xf,
+                                                 0xf, true));
+}
+
+#define LSI_RFL(x) __builtin_amdgcn_readfirstlane(x)
+
+// streamed inputs: every byte is read once (halo rows: twice)
+typedef float lsi_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4_stream(const float* p) {
+#ifdef LSI_STREAM_NT
+  const lsi_f4 v = __builtin_nontemporal_load(reinterpret_cast<const lsi_f4*>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+#else
+  return *reinterpret_cast<const float4*>(p);
+#endif
+}
+#define LSI_LD4(p) ld4_stream(p)
+
 // SIMPLE: the normaliser is exactly 1 and row 3 of M is (0,0,0,1) for every
 // batch element (rectified stereo): u = q0 and D = d with no division.
 // MODE 1 / 2: compose mode without a mask input (the training / benchmark
@@ -227,14 +284,13 @@ __device__ __forceinline__ UnitArgs unit_args() {
 // the other modes are gone.  MODE 0: everything, decided at run time.
 // FULL: W is a multiple of the 256-pixel segment: every lane always has pixels.
 template <int LAYOUT, bool SIMPLE, int MODE, bool FULL>  // LAYOUT 0: channels-last, 1: planar
-__global__ __launch_bounds__(1024) void splat_stream_kernel(SplatArgs a,
+__global__ __launch_bounds__(LSI_STREAM_MAXT) void splat_stream_kernel(SplatArgs a,
                                                            StreamCfg cfg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const LsiSplatDesc& d = a.d;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int T = blockDim.x, NW = T >> 6;
-  const int R = cfg.R, WMAX = cfg.wmax, TPW = cfg.tpw;
-  const int NWIN = NW * TPW;  // windows (= tasks) per step, <= 64
+  const int R = cfg.R, WMAX = cfg.wmax;
   const int Wt = d.Wt, Ht = d.Ht, W = d.W;
   // XCD-aware placement (speed only): workgroup i runs on XCD i % 8, each with
   // its own L2.  Neighbouring bands re-read each other's halo rows, so give
@@ -264,8 +320,7 @@ __global__ __launch_bounds__(1024) void splat_stream_kernel(SplatArgs a,
   //     band finishes second.  No source row is read twice.
   //  0: band = target rows [row0, row0 + R); it reads every source row that
   //     touches them (k in [row0 - 1, row0 + R - 1]) and drops the
-  //     contributions that fall outside: one extra k per band, no exchange
-  //     (cheaper when a band is only a few microseconds of work).
+  //     contributions that fall outside: one extra k per band, no exchange.
   const int nbands = gridDim.x;
   const int row0 = band * R;
   constexpr bool LEAN = MODE != 0;
@@ -276,15 +331,38 @@ __global__ __launch_bounds__(1024) void splat_stream_kernel(SplatArgs a,
   const int top_shared = (xchg && band > 0) ? 1 : 0;
   const int bot_shared = (xchg && row0 + R < Ht) ? 1 : 0;  // tile row R exists
 
-  float4* rb_all = reinterpret_cast<float4*>(smem_raw);  // [NWIN][WMAX]
-  unsigned* cnt_all = reinterpret_cast<unsigned*>(rb_all + NWIN * WMAX);
-  float* extras = reinterpret_cast<float*>(cnt_all + NW * WMAX);  // [R+1][Wt][4]
+  // ---- LDS carve (every offset a multiple of 16) --------------------------
+  float4* rb_all = reinterpret_cast<float4*>(smem_raw);      // [NW][WMAX + 16]
+  unsigned char* sc_all =
+      reinterpret_cast<unsigned char*>(
+          rb_all + NW * (2 * (((WMAX / 2 + 15) & ~15) + 8)));  // [NW][WMAX]
+  float* extras = reinterpret_cast<float*>(sc_all + NW * WMAX);  // tile [R+x][Wt][4]
   const int CAP = cfg.cap;
   TaskA* taskA = reinterpret_cast<TaskA*>(
-      extras + (R + cfg.exchange) * Wt * 4);  // [CAP]
+      extras + (R + cfg.exchange) * Wt * 4);                      // [CAP]
   TaskB* taskB = reinterpret_cast<TaskB*>(taskA + CAP);           // [CAP]
-  int* yrange = reinterpret_cast<int*>(taskB + CAP);  // [0..1] rows, [2] slot ticket, [4..5] exchange order
-  unsigned* cnt = cnt_all + wave * WMAX;
+  TaskC* taskC = reinterpret_cast<TaskC*>(taskB + CAP);           // [CAP]
+  // [0..1] source rows, [2] task tickets, [3] range found analytically,
+  // [4..5] exchange arrival order, [6] merge turn (deterministic mode),
+  // [8 ..] one lock per tile row
+  int* ctl = reinterpret_cast<int*>(taskC + CAP);
+  int* locks = ctl + 8;
+  // per-wave queue of corners the window cannot represent (see push below)
+  const int Q = cfg.qcap;
+  float4* const qv = reinterpret_cast<float4*>(
+                         ctl + ((8 + R + 2 + 3) & ~3)) + wave * Q;   // [NW][Q]
+  int* const qc = reinterpret_cast<int*>(
+                      reinterpret_cast<float4*>(ctl + ((8 + R + 2 + 3) & ~3)) +
+                      NW * Q) + wave * Q;                              // [NW][Q]
+  // Window cell c lives at slot (c >> 1) + (c & 1) * WHS: lanes are two cells
+  // apart, so their 16-byte cells are adjacent slots (no bank conflicts), and
+  // the odd half starts 8 slots off a 256-byte boundary so that a run of
+  // consecutive cells (the merge) is conflict-free too.
+  const int WHS = ((WMAX / 2 + 15) & ~15) + 8;
+  const int WCELLS = 2 * WHS;  // slots per window
+  float4* const rb = rb_all + wave * WCELLS;  // this wave's private window
+  unsigned char* const sc = sc_all + wave * WMAX;
+  float4* const tile4 = reinterpret_cast<float4*>(extras);
 
   // Everything read from global / kernarg memory inside the loops is copied to
   // registers first: the LDS ordering fences below are compiler memory
@@ -305,9 +383,9 @@ __global__ __launch_bounds__(1024) void splat_stream_kernel(SplatArgs a,
   const float* __restrict__ g_tex = a.tex;
   const float* __restrict__ g_disp = a.disp;
   const float* __restrict__ g_mask = a.mask;
-  // Timing-experiment hooks (tools/phase_probe.py, bench.py --debug-flags) are
-  // compiled only into the instrumented build (-DLSI_STREAM_HOOKS=1): they cost
-  // a dozen scalar registers the production kernel cannot spare.
+  // Timing stamps (tools/phase_probe.py) are compiled only into the
+  // instrumented build (-DLSI_STREAM_HOOKS=1): they cost scalar registers the
+  // production kernel cannot spare.
 #if LSI_STREAM_HOOKS
   const int dbg = d.reserved;
 #else
@@ -317,15 +395,31 @@ __global__ __launch_bounds__(1024) void splat_stream_kernel(SplatArgs a,
   const float xmax = (float)Wt - 1.0f, ymax = (float)Ht - 1.0f;
   const bool has_mask = LEAN ? false : (d.flags & LSI_HAS_MASK) != 0;
   const bool compose = LEAN ? true : (d.flags & LSI_COMPOSE) != 0;
+  const bool ordered = (d.flags & LSI_DETERMINISTIC) != 0;
   const float inv_md = div_rn(1.0f, max_disp);
 
   long long* tdbg = (dbg & 4)
-                        ? cfg.tstamps + ((size_t)b * gridDim.x + band) * 32
+                        ? cfg.tstamps + ((size_t)b * gridDim.x + band) * 160
                         : nullptr;
+#if LSI_STREAM_HOOKS
+  // per-wave cycle totals of the task loop's sections (tools/phase_probe.py)
+  long long prof[6] = {0, 0, 0, 0, 0, 0};
+  long long prof_t = 0;
+#define LSI_PROF_START() prof_t = (long long)__builtin_readcyclecounter()
+#define LSI_PROF(k)                                                   \
+  do {                                                                \
+    const long long now_ = (long long)__builtin_readcyclecounter();   \
+    prof[k] += now_ - prof_t;                                         \
+    prof_t = now_;                                                    \
+  } while (0)
+#else
+#define LSI_PROF_START()
+#define LSI_PROF(k)
+#endif
   int tslot = 0;
 #define LSI_TSTAMP()                                               \
   do {                                                             \
-    if (tdbg && tid == 0 && tslot < 32)                            \
+    if (tdbg && tid == 0 && tslot < 12)                            \
       tdbg[tslot++] = (long long)__builtin_readcyclecounter();     \
   } while (0)
   LSI_TSTAMP();
@@ -343,80 +437,104 @@ __global__ __launch_bounds__(1024) void splat_stream_kernel(SplatArgs a,
   };
 
   // ---- one-time init ------------------------------------------------------
-  // (task windows are zeroed by their owning wave when the task starts)
-  for (int i = tid; i < NW * WMAX; i += T) cnt_all[i] = 0u;
+  for (int i = tid; i < NW * WCELLS; i += T)
+    rb_all[i] = make_float4(0.f, 0.f, 0.f, 0.f);  // windows start (and are left) zero
   for (int i = tid; i < rows * Wt; i += T)
-    reinterpret_cast<float4*>(extras)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (tid == 0) yrange[2] = 0;  // slot tickets (first read after a barrier)
+    tile4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (tid < 8 + R + 2) ctl[tid] = 0;  // tickets, turn, locks
   LSI_TSTAMP();
   const int nseg = (W + SEG - 1) / SEG;
-  const float inv_nseg = 1.0f / (float)nseg;
+  const int NGRP = compose ? cfg.ngrp : 1;  // layer groups per (row, segment)
+  const int LPG = compose ? cfg.lpg : 1;    // layers per group
+  const int per_row = nseg * NGRP;
+  const float inv_per_row = compose ? cfg.inv_per_row : cfg.inv_nseg;
+  const float inv_ngrp = compose ? cfg.inv_ngrp : 1.0f;
   // Source rows of the band: floor(Y(y)) in [k_lo, k_hi].  Y is a Moebius
   // function of y, monotone where the normaliser is positive, so the rows form
   // a range whose ends are found by inverting Y and then checking the result
   // with the exact fp32 Y.  Wave 0 does this and fills the first chunk of the
-  // task table while the other waves clear the tile: the uniform arithmetic is
-  // not repeated by (and does not contend with) the other waves.  Maps that
-  // are decreasing, too flat for fp32 to keep monotone, or not finite at the
-  // ends take the scan further below instead.
-  // task table for tasks [tg0, tg0 + CAP) of ntask, rows from ylo on: one task
-  // per participating thread (threads first, first + stride, ...)
-  auto fill_tasks = [&](int tg0, int first, int stride, int ylo, int ntask) {
+  // task table while the other waves clear the tile.  Maps that are
+  // decreasing, too flat for fp32 to keep monotone, or not finite at the ends
+  // take the scan further below instead.
+  // task = (source row, 256-pixel segment, group of layers); table for tasks
+  // [tg0, tg0 + CAP) of ntask, rows from ylo on, layers from lbase on: one
+  // task per participating thread (threads first, first + stride, ...)
+  auto fill_tasks = [&](int tg0, int first, int stride, int ylo, int ntask,
+                        int lbase, int lend) {
     for (int t = first; t < CAP; t += stride) {
-        const int tg = tg0 + t;
-        TaskA ta; ta.row0 = -1000000; ta.wy0 = 0.f; ta.wy1 = 0.f; ta.win = 0;
-        TaskB tb; tb.nden = 1.0f; tb.rn = 1.0f; tb.y = 0; tb.xs = 0;
-        if (tg < ntask) {
-          // tg / nseg without an integer division (tg < 2^20: exact in fp32)
-          const int yi = (int)(((float)tg + 0.5f) * inv_nseg);
-          const int y = ylo + yi;
-          const int xs = (tg - yi * nseg) * SEG;
-          const float py = (float)y + 0.5f;
-          float nden;
-          const float Y = row_Y(y, nden);
-          if (finite_f(Y) && fabsf(Y) < 1.0e7f) {
-            const Axis ay = splat_axis(Y, ymax);
-            ta.row0 = (int)floorf(Y) - row0;
-            ta.wy0 = ay.w0;
-            ta.wy1 = ay.w1;
-            tb.nden = nden;
-            tb.rn = SIMPLE ? 1.0f : div_rn(1.0f, nden);
-            tb.y = y;
-            tb.xs = xs;
-            // window hint: cells reachable for d in [0, max_disp] on the segment
-            const int xe = min(xs + SEG, W);
-            float lo = __builtin_inff(), hi = -__builtin_inff();
-            auto x_of = [&](int xx, float dd) {
-              const float q0 = mrow(m, 0, (float)xx + 0.5f, py, dd);
-              return (SIMPLE ? q0 : div_rn(q0, nden)) * s - 0.5f;
-            };
-            if (m[0] > 0.0f) {  // X increases with x; with d by the sign of m03
-              const bool neg = m[3] < 0.0f;
-              lo = x_of(xs, neg ? max_disp : 0.0f);
-              hi = x_of(xe - 1, neg ? 0.0f : max_disp);
-            } else {
+      const int tg = tg0 + t;
+      TaskA ta; ta.row0 = -1000000; ta.wy0 = 0.f; ta.wy1 = 0.f; ta.win = 0;
+      TaskB tb; tb.nden = 1.0f; tb.rn = 1.0f; tb.y = 0; tb.xs = 0;
+      TaskC tc; tc.tmin = __builtin_inff(); tc.tmax = __builtin_inff();
+      tc.l0 = 0; tc.l1 = 0;
+      if (tg < ntask) {
+        // tg / per_row etc. without integer divisions (tg < 2^20: exact)
+        const int yi = (int)(((float)tg + 0.5f) * inv_per_row);
+        const int rem = tg - yi * per_row;
+        const int sg = (int)(((float)rem + 0.5f) * inv_ngrp);
+        const int grp = rem - sg * NGRP;
+        const int y = ylo + yi;
+        const int xs = sg * SEG;
+        tc.l0 = min(lbase + grp * LPG, lend);
+        tc.l1 = min(tc.l0 + LPG, lend);
+        const float py = (float)y + 0.5f;
+        float nden;
+        const float Y = row_Y(y, nden);
+        if (finite_f(Y) && fabsf(Y) < 1.0e7f && tc.l1 > tc.l0) {
+          const Axis ay = splat_axis(Y, ymax);
+          ta.row0 = (int)floorf(Y) - row0;
+          ta.wy0 = ay.w0;
+          ta.wy1 = ay.w1;
+          tb.nden = nden;
+          tb.rn = SIMPLE ? 1.0f : div_rn(1.0f, nden);
+          tb.y = y;
+          tb.xs = xs;
+          // clamp thresholds against the smaller / larger non-zero row weight
+          const float wymin =
+              (ay.w0 == 0.f) ? ay.w1
+                             : ((ay.w1 == 0.f) ? ay.w0 : fminf(ay.w0, ay.w1));
+          tc.tmin = clamp_threshold(wymin);
+          tc.tmax = clamp_threshold(fmaxf(ay.w0, ay.w1));
+          // window hint: cells reachable for d in [0, max_disp] on the segment
+          const int xe = min(xs + SEG, W);
+          float lo = __builtin_inff(), hi = -__builtin_inff();
+          auto x_of = [&](int xx, float dd) {
+            const float q0 = mrow(m, 0, (float)xx + 0.5f, py, dd);
+            return (SIMPLE ? q0 : div_rn(q0, nden)) * s - 0.5f;
+          };
+          if (m[0] > 0.0f) {  // X increases with x; with d by the sign of m03
+            const bool neg = m[3] < 0.0f;
+            lo = x_of(xs, neg ? max_disp : 0.0f);
+            hi = x_of(xe - 1, neg ? 0.0f : max_disp);
+          } else {
 #pragma unroll
-              for (int c = 0; c < 4; ++c) {
-                const float X = x_of((c & 1) ? (xe - 1) : xs,
-                                     (c & 2) ? max_disp : 0.0f);
-                lo = fminf(lo, X); hi = fmaxf(hi, X);
-              }
-            }
-            if (finite_f(lo) && finite_f(hi) && fabsf(lo) < 1.0e7f &&
-                fabsf(hi) < 1.0e7f) {
-              // cells [wlo, wlo+wwin) confined to the image: an in-window lane
-              // then needs no border mask (both its cells are valid)
-              const int c_lo = max((int)floorf(lo) - 1, 0);
-              const int c_hi = min((int)floorf(hi) + 2, Wt - 1);
-              const int wwin = max(0, min(WMAX, c_hi - c_lo + 1));
-              ta.win = c_lo | (wwin << 16);
+            for (int c = 0; c < 4; ++c) {
+              const float X = x_of((c & 1) ? (xe - 1) : xs,
+                                   (c & 2) ? max_disp : 0.0f);
+              lo = fminf(lo, X); hi = fmaxf(hi, X);
             }
           }
+          if (finite_f(lo) && finite_f(hi) && fabsf(lo) < 1.0e7f &&
+              fabsf(hi) < 1.0e7f) {
+            // cells [wlo, wlo+wwin) -- NOT confined to the image: cells left
+            // of column 0 or right of column Wt-1 are dummies that the merge
+            // drops, which is exactly the reference's border rule (a corner
+            // outside the image is masked, the others keep their weights:
+            // sampling.py:204-211).  Origin stored with a 32768 bias.
+            const int c_lo = max((int)floorf(lo) - 1, -32000);
+            const int c_hi = min((int)floorf(hi) + 4, 32000);
+            const int wwin = max(0, min(WMAX, c_hi - c_lo + 1));
+            ta.win = (c_lo + 32768) | (wwin << 16);
+          }
         }
-        taskA[t] = ta;
-        taskB[t] = tb;
       }
-    };
+      taskA[t] = ta;
+      taskB[t] = tb;
+      taskC[t] = tc;
+    }
+  };
+  const int npass = compose ? 1 : nlayers;
+  const int Lp = compose ? nlayers : 1;
   if (wave == 0) {
     int y_lo = d.H, y_hi = -1;
     bool ranged = false;
@@ -459,18 +577,16 @@ __global__ __launch_bounds__(1024) void splat_stream_kernel(SplatArgs a,
         if (good) { y_lo = lo; y_hi = hi; ranged = true; }
       }
     }
-    if (lane == 0) { yrange[0] = y_lo; yrange[1] = y_hi; yrange[3] = ranged; }
-    LSI_TSTAMP();
+    if (lane == 0) { ctl[0] = y_lo; ctl[1] = y_hi; ctl[3] = ranged; }
     if (ranged)
       fill_tasks(0, lane, 64, y_lo,
-                 ((y_hi >= y_lo) ? (y_hi - y_lo + 1) : 0) * nseg);
+                 ((y_hi >= y_lo) ? (y_hi - y_lo + 1) : 0) * per_row, 0, Lp);
   }
   LSI_TSTAMP();
   __syncthreads();
-  LSI_TSTAMP();
-  if (!yrange[3]) {  // general case: every thread tests its rows
+  if (!ctl[3]) {  // general case: every thread tests its rows
     __syncthreads();  // (everyone has read the flag)
-    if (tid == 0) { yrange[0] = d.H; yrange[1] = -1; }
+    if (tid == 0) { ctl[0] = d.H; ctl[1] = -1; }
     __syncthreads();
     int lo = d.H, hi = -1;
     for (int y = tid; y < d.H; y += T) {
@@ -482,158 +598,364 @@ __global__ __launch_bounds__(1024) void splat_stream_kernel(SplatArgs a,
         lo = min(lo, y); hi = max(hi, y);
       }
     }
-    if (hi >= 0) { atomicMin(&yrange[0], lo); atomicMax(&yrange[1], hi); }
+    if (hi >= 0) { atomicMin(&ctl[0], lo); atomicMax(&ctl[1], hi); }
     __syncthreads();
-    const int ylo = yrange[0], yhi = yrange[1];
-    fill_tasks(0, tid, T, ylo, ((yhi >= ylo) ? (yhi - ylo + 1) : 0) * nseg);
+    const int ylo = ctl[0], yhi = ctl[1];
+    fill_tasks(0, tid, T, ylo, ((yhi >= ylo) ? (yhi - ylo + 1) : 0) * per_row,
+               0, Lp);
     __syncthreads();
   }
-  const int y_lo = yrange[0], y_hi = yrange[1];
+  const int y_lo = ctl[0], y_hi = ctl[1];
   LSI_TSTAMP();
   const int nsrc = (y_hi >= y_lo) ? (y_hi - y_lo + 1) : 0;
   const size_t P = (size_t)Ht * Wt;
+  const int ntask = nsrc * per_row;
 
-  const int npass = compose ? 1 : nlayers;
-  const int Lp = compose ? nlayers : 1;
+  struct PxData { float4 d4, t0, t1, t2, m4; };
+
   for (int pass = 0; pass < npass; ++pass) {
     const int l_begin = compose ? 0 : pass;
-    const int ntask = nsrc * nseg;
-    const int nstep = div_small(ntask + NWIN - 1, NWIN, cfg.inv_nwin);
-
-    const int steps_per_chunk = cfg.steps_per_chunk;
-
-    for (int step = 0, sidx = 0; step < nstep; ++step, ++sidx) {
-      if (sidx == steps_per_chunk) sidx = 0;
-      // chunk 0 is in the table from the prologue, and still is at the start
-      // of a later pass unless this pass needed more than one chunk
-      if (sidx == 0 && (step > 0 || (pass > 0 && nstep > steps_per_chunk))) {
-        // (the previous step's closing barrier protects the table)
-        fill_tasks(step * NWIN, tid, T, y_lo, ntask);
+    for (int chunk0 = 0; chunk0 < ntask; chunk0 += CAP) {
+      // chunk 0 of pass 0 is in the table from the prologue
+      if (chunk0 > 0 || pass > 0) {
+        // (the previous chunk's closing barrier protects the table)
+        fill_tasks(chunk0, tid, T, y_lo, ntask, l_begin, l_begin + Lp);
+        if (tid == 0) { ctl[2] = 0; ctl[6] = 0; }
         __syncthreads();
       }
-      LSI_TSTAMP();
-      // ================= x-pass ==============================================
-      // task = (source row y, 256-pixel segment j), all layers of the pass.
-      // Waves draw task slots from a ticket counter (tasks differ in cost);
-      // the wave that draws slot t owns LDS window [t] until the merge.
-      for (;;) {
-        int slot = 0;
-        if (lane == 0) slot = atomicAdd(&yrange[2], 1);
-        slot = __builtin_amdgcn_readfirstlane(slot);
-        if (slot >= NWIN) break;
-        const TaskA ta = taskA[sidx * NWIN + slot];  // LDS broadcast reads
-        const TaskB tb = taskB[sidx * NWIN + slot];
-        // wave-uniform by construction; tell the compiler (scalar registers)
-        const int t_valid = __builtin_amdgcn_readfirstlane(
-            (ta.wy0 != 0.0f || ta.wy1 != 0.0f) ? 1 : 0);
-        if (!t_valid || (dbg & 64)) continue;  // dbg 64: overhead-only timing
-        const int t_row0 = __builtin_amdgcn_readfirstlane(ta.row0);
-        const int t_win = __builtin_amdgcn_readfirstlane(ta.win);
-        const int t_wlo = t_win & 0xffff, t_wwin = t_win >> 16;
-        const int y = __builtin_amdgcn_readfirstlane(tb.y);
-        const int xs = __builtin_amdgcn_readfirstlane(tb.xs);
-        const float nden = tb.nden;
-
-        float4* rb = rb_all + slot * WMAX;
-        const int x = xs + 4 * lane;
-        const bool inrange = FULL ? true : x < W;
-        const float py = (float)y + 0.5f;
-        // row-uniform pieces of q = M p, in the contract's rounding order
-        const float pym01 = py * m[1];
-        const float pym31 = py * m[13];
-        const float rn = tb.rn;
-        const float wy0 = ta.wy0, wy1 = ta.wy1;
-        // smallest non-zero row weight: a side is exactly factorisable iff its
-        // product with this one survives the 1e-3 clamp (rounding is monotone)
-        const float wymin =
-            (wy0 == 0.f) ? wy1 : ((wy1 == 0.f) ? wy0 : fminf(wy0, wy1));
-        const float wlo_f = (float)t_wlo;
-
-        struct PxData { float4 d4, t0, t1, t2, m4; };
-        // per-lane source pointers, advanced by one layer stride per load
-        const float* p_disp = g_disp + (long)l_begin * disp_sl +
-                              (long)b * disp_sb + (long)y * disp_sy + x;
-        const float* p_tex = g_tex + (long)l_begin * tex_sl + (long)b * tex_sb +
-                             (long)y * tex_sy + (LAYOUT == 0 ? 3 * x : x);
-        const float* p_mask = has_mask ? g_mask + (long)l_begin * mask_sl +
-                                             (long)b * mask_sb +
-                                             (long)y * mask_sy + x
-                                       : nullptr;
-        auto load_layer = [&](PxData& o) {
-          if (inrange) {
-            o.d4 = *reinterpret_cast<const float4*>(p_disp);
-            if (LAYOUT == 0) {
-              const float4* t4 = reinterpret_cast<const float4*>(p_tex);
-              o.t0 = t4[0]; o.t1 = t4[1]; o.t2 = t4[2];
-            } else {
-              o.t0 = *reinterpret_cast<const float4*>(p_tex);
-              o.t1 = *reinterpret_cast<const float4*>(p_tex + tex_sc);
-              o.t2 = *reinterpret_cast<const float4*>(p_tex + 2 * tex_sc);
-            }
-            if (has_mask) o.m4 = *reinterpret_cast<const float4*>(p_mask);
+      const int nchunk = min(CAP, ntask - chunk0);
+      // ================= task loop: no barrier inside ========================
+      // Waves draw tasks from a ticket counter; a wave splats its task's
+      // pixels along x into its private window (plain LDS read-modify-write),
+      // then adds the window into the task's two tile rows under row locks.
+      // The loads of the next layer -- or of the next task's first layer --
+      // are in flight during the window phase.
+      auto draw = [&]() {
+        int sl = 0;
+        if (lane == 0) sl = atomicAdd(&ctl[2], 1);
+        return LSI_RFL(sl);
+      };
+      const float* p_disp = g_disp;
+      const float* p_tex = g_tex;
+      const float* p_mask = g_mask;
+      int ld_left = 0;  // layers of the loader's task still to be issued
+      auto aim = [&](int sl) {  // source pointers at task sl's first layer
+        const TaskB tb = taskB[sl];
+        const TaskC tc = taskC[sl];
+        const int y = LSI_RFL(tb.y), xs = LSI_RFL(tb.xs), l0 = LSI_RFL(tc.l0);
+        ld_left = LSI_RFL(tc.l1) - l0;
+        // lanes past the end of the row load the row's last pixels again (the
+        // compute side masks them): no predicate on the loads
+        const int x = FULL ? xs + 4 * lane : min(xs + 4 * lane, W - 4);
+        p_disp = g_disp + (long)l0 * disp_sl + (long)b * disp_sb +
+                 (long)y * disp_sy + x;
+        p_tex = g_tex + (long)l0 * tex_sl + (long)b * tex_sb +
+                (long)y * tex_sy + (LAYOUT == 0 ? 3 * x : x);
+        if (has_mask)
+          p_mask = g_mask + (long)l0 * mask_sl + (long)b * mask_sb +
+                   (long)y * mask_sy + x;
+      };
+      // Always exactly one load per input: every path through the loop then
+      // has the same number of loads in flight, and the compiler can wait for
+      // one register set while the other one's loads stay outstanding.
+      auto load_layer = [&](PxData& o) {
+        o.d4 = LSI_LD4(p_disp);
+        if (LAYOUT == 0) {
+          o.t0 = LSI_LD4(p_tex); o.t1 = LSI_LD4(p_tex + 4);
+          o.t2 = LSI_LD4(p_tex + 8);
+        } else {
+          o.t0 = LSI_LD4(p_tex);
+          o.t1 = LSI_LD4(p_tex + tex_sc);
+          o.t2 = LSI_LD4(p_tex + 2 * tex_sc);
+        }
+        if (has_mask) o.m4 = LSI_LD4(p_mask);
+        p_disp += disp_sl;
+        p_tex += tex_sl;
+        if (has_mask) p_mask += mask_sl;
+      };
+      // merge order of the deterministic mode: strictly by ticket
+      auto wait_turn = [&](int sl) {
+        if (lane == 0) {
+          while (__hip_atomic_load(&ctl[6], __ATOMIC_ACQUIRE,
+                                   __HIP_MEMORY_SCOPE_WORKGROUP) != sl)
+            __builtin_amdgcn_s_sleep(2);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      };
+      auto first_started_from = [&](int sl) {  // (masked rows are never started)
+        while (sl < nchunk) {
+          const TaskA ta = taskA[sl];
+          if (LSI_RFL((ta.wy0 != 0.0f || ta.wy1 != 0.0f) ? 1 : 0)) break;
+          ++sl;
+        }
+        return sl;
+      };
+      auto pass_turn = [&](int sl) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        const int nx = first_started_from(sl + 1);
+        if (lane == 0)
+          __hip_atomic_store(&ctl[6], nx, __ATOMIC_RELEASE,
+                             __HIP_MEMORY_SCOPE_WORKGROUP);
+      };
+      auto lock_row = [&](int r) {
+        if (lane == 0) {
+          for (;;) {
+            int expect = 0;
+            if (__hip_atomic_compare_exchange_strong(
+                    &locks[r], &expect, 1, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED,
+                    __HIP_MEMORY_SCOPE_WORKGROUP))
+              break;
+            __builtin_amdgcn_s_sleep(1);
           }
-          p_disp += disp_sl;
-          p_tex += tex_sl;
-          if (has_mask) p_mask += mask_sl;
-        };
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      };
+      auto unlock_row = [&](int r) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0)
+          __hip_atomic_store(&locks[r], 0, __ATOMIC_RELEASE,
+                             __HIP_MEMORY_SCOPE_WORKGROUP);
+      };
 
-        // Clamp handling (sampling.py:218-222): corner weight w_x*w_y survives
-        // iff fl(w_x*w_y) > 1e-3.  A side whose product with the SMALLER row
-        // weight survives factorises exactly (rounding is monotone) and goes
-        // to the window; otherwise it is taken out of the window (weight 0)
-        // and only its product with the LARGER row weight can survive: that
-        // one corner is added to the extras tile.
-        const float wymax = fmaxf(wy0, wy1);
-        const int rmax = t_row0 + ((wy1 > wy0) ? 1 : 0);
-        const int has_max = __builtin_amdgcn_readfirstlane(
-            ((wymax != wymin) && rmax >= 0 && rmax < rows && !(dbg & 1)) ? 1
-                                                                         : 0);
-        float* const emax = extras + ((long)rmax * Wt + t_wlo) * 4;
-        // last admissible left-cell offset; a window of fewer than two cells
-        // (the whole segment maps outside the image) admits no lane at all
-        const unsigned wspan = (unsigned)max(t_wwin - 2, 0);
-        const int win_ok = t_wwin >= 2 ? 1 : 0;
-        const unsigned long long win_mask = win_ok ? ~0ull : 0ull;
-        // lanes exempt from the "strictly increasing" test: lane 0, and the
-        // tail lanes beyond the image (no in-window lane follows them)
-        const unsigned long long inr_mask = FULL ? ~0ull : __ballot(inrange);
-        const unsigned long long edge_mask = ~inr_mask | 1ull;
-        const int l_end = l_begin + Lp;
+      // Corners that the factorised window cannot represent exactly (a side
+      // whose product with only the LARGER row weight survives the clamp;
+      // pixels whose cells fall outside the window) are queued per wave as
+      // (tile cell, value) and added to the tile under the row locks: at the
+      // task's merge, or earlier when the queue is full.  No fp32 atomics and
+      // no tile access in the pixel loop.
+      int qn = 0;  // wave-uniform fill
+      int q_row0 = 0;  // tile row of the current task (locks for a flush)
+      bool q_use_a = false, q_use_b = false;
+      auto apply_queue = [&]() {  // caller holds the rows
+        for (int i = lane; i < qn; i += 64) {
+          const float4 v = qv[i];
+          float* e = extras + (long)qc[i] * 4;
+          atomic_add_f32(e + 0, v.x);  // two records may name the same cell
+          atomic_add_f32(e + 1, v.y);
+          atomic_add_f32(e + 2, v.z);
+          atomic_add_f32(e + 3, v.w);
+        }
+        qn = 0;
+      };
+      int cur_slot = 0;
+      // queue full (rare): these lanes' corners go to the tile at once
+      auto direct = [&](bool pred, int tcell, float4 val) {
+        if (ordered) {
+          wait_turn(cur_slot);  // (the turn is passed on after the merge)
+        } else {
+          if (q_use_a) lock_row(q_row0);
+          if (q_use_b) lock_row(q_row0 + 1);
+        }
+        if (pred) {
+          float* e = extras + (long)tcell * 4;
+          atomic_add_f32(e + 0, val.x);
+          atomic_add_f32(e + 1, val.y);
+          atomic_add_f32(e + 2, val.z);
+          atomic_add_f32(e + 3, val.w);
+        }
+        if (!ordered) {
+          if (q_use_b) unlock_row(q_row0 + 1);
+          if (q_use_a) unlock_row(q_row0);
+        }
+      };
+      auto push = [&](bool pred, int tcell, float4 val) {
+        const unsigned long long mask = __ballot(pred);
+        if (mask == 0ull) return;
+        const int n = __builtin_popcountll(mask);
+        if (qn + n <= Q) {
+          const int idx =
+              qn + (int)__builtin_amdgcn_mbcnt_hi(
+                       (unsigned)(mask >> 32),
+                       __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+          if (pred) {
+            qv[idx] = val;
+            qc[idx] = tcell;
+          }
+          qn += n;
+        } else {
+          direct(pred, tcell, val);
+        }
+      };
+      // exact 4-corner footprint of one pixel (sampling.py:193-222) for lanes
+      // whose cells are not inside the window: clipped cells, border masks,
+      // clamp on the full product; non-finite inputs add nothing
+      auto push_corners = [&](bool pred, float4 V, float x0, float gx, float fx,
+                              float wy0_, float wy1_, int trow0) {
+        const float x1 = x0 + 1.0f;
+        const float x0s = fminf(fmaxf(x0, 0.0f), xmax);
+        const float x1s = fminf(fmaxf(x1, 0.0f), xmax);
+        const float wx[2] = {(x0 == x0s) ? gx : 0.0f, (x1 == x1s) ? fx : 0.0f};
+        const int cx[2] = {(int)x0s, (int)x1s};
+        const float wy[2] = {wy0_, wy1_};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int r = trow0 + (k >> 1);
+          const float c = wx[k & 1] * wy[k >> 1];
+          const bool ok = pred && (c > 1.0e-3f) && r >= 0 && r < rows;
+          push(ok, r * Wt + cx[k & 1],
+               make_float4(V.x * c, V.y * c, V.z * c, V.w * c));
+        }
+      };
 
-        PxData cur;
-        cur.d4 = cur.t0 = cur.t1 = cur.t2 = make_float4(0.f, 0.f, 0.f, 0.f);
-        cur.m4 = make_float4(1.f, 1.f, 1.f, 1.f);
-        load_layer(cur);
-        // zero this task's window while the first loads are in flight (same
-        // wave, in-order LDS: no barrier needed before its own RMWs)
-        for (int c = lane; c < t_wwin; c += 64)
-          rb[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-        LSI_COMPILER_FENCE();
+      if (ordered) {  // the first turn belongs to the first task that starts
+        const int f0 = first_started_from(0);
+        if (tid == 0) ctl[6] = f0;
+        __syncthreads();
+      }
+      // ---- the wave's item stream -------------------------------------------
+      // An item = one layer of a task: 4 pixels per lane.  The loader side
+      // (tickets, addresses, global loads) runs two items ahead of the compute
+      // side: two register sets take turns, each refilled right after the
+      // projection has consumed it, so a wave keeps two items' loads in flight
+      // (the loaded HBM latency is about two item periods).
+      // Every register set carries the tag of the item it holds: -1 (none), or
+      // the task's slot | bit 20 (first layer of its task) | bit 21 (last).
+      // (Wave-uniform state is passed through readfirstlane where it steers a
+      // branch: the compiler then emits scalar branches, not exec masking.)
+      int ld_done = 0;   // tickets exhausted
+      int ld_slot = 0;   // the loader's task
+      int ld_first = 0;  // its next item is its first
+      auto issue = [&](PxData& dst) -> int {
+        if (LSI_RFL(ld_left) == 0 && LSI_RFL(ld_done) == 0) {
+          const int sl = draw();
+          if (sl >= nchunk) {
+            ld_done = 1;
+          } else {
+            const TaskA ta = taskA[sl];
+            // rows masked at the border add nothing: not even started (this
+            // register set then idles for one turn)
+            if (LSI_RFL((ta.wy0 != 0.0f || ta.wy1 != 0.0f) ? 1 : 0)) {
+              aim(sl);
+              ld_slot = sl;
+              ld_first = 1 << 20;
+            }
+          }
+        }
+        int tag = -1;
+        const bool have = LSI_RFL(ld_left) != 0;
+        if (!have) {  // nothing to load: a harmless re-read of the first bytes
+          p_disp = g_disp; p_tex = g_tex;
+          if (has_mask) p_mask = g_mask;
+        }
+        load_layer(dst);
+        if (have) {
+          ld_left = LSI_RFL(ld_left) - 1;
+          tag = ld_slot | ld_first | (ld_left == 0 ? (1 << 21) : 0);
+          ld_first = 0;
+        }
+        return LSI_RFL(tag);
+      };
 
-        for (int l = l_begin; l < l_end; ++l) {
+      // compute side: state of the task in progress (wave-uniform unless noted)
+      int slot = 0;
+      int t_row0 = 0, t_wlo = 0, t_wwin = 0, cmax = 0, has_max = 0, rmax_row = 0;
+      int win_ok = 0, fast_ok = 0, fastA_ok = 0;
+      unsigned wspan = 0u, wspanA = 0u;
+      float nden = 1.f, rn = 1.f, tmin = 0.f, wy0 = 0.f, wy1 = 0.f;
+      float wymin = 0.f, wymax = 0.f, wlo_f = 0.f;
+      bool inrange = true;  // per lane
+      unsigned long long inr_mask = ~0ull, edge_mask = 1ull, win_mask = 0ull;
+      f2 qb[2], q3b[2];     // per lane: layer-independent part of q = M p
+      qb[0] = qb[1] = q3b[0] = q3b[1] = f2{0.f, 0.f};
+
+      auto item = [&](PxData& cur, const int tag) -> int {
+        // (a set without an item only asks the loader again: the loads of a
+        // set are always issued at this one place, so the compiler never has
+        // to reconcile register sets that are still in flight)
+        const bool live = tag >= 0;
+        if (live && (tag & (1 << 20))) {  // ---- the item starts a task ------
+          slot = tag & 0xfffff;
+          const TaskA ta = taskA[slot];  // LDS broadcast reads
+          const TaskB tb = taskB[slot];
+          const TaskC tc = taskC[slot];
+          // wave-uniform by construction; tell the compiler (scalar registers)
+          t_row0 = LSI_RFL(ta.row0);
+          const int t_win = LSI_RFL(ta.win);
+          t_wlo = (t_win & 0xffff) - 32768; t_wwin = t_win >> 16;
+          const int y = LSI_RFL(tb.y);
+          const int xs = LSI_RFL(tb.xs);
+          nden = tb.nden;
+          tmin = tc.tmin;
+          const int x = xs + 4 * lane;
+          inrange = FULL ? true : x < W;
+          const float py = (float)y + 0.5f;
+          // layer-independent part of q = M p, in the contract's rounding
+          // order: ((px*m00 + py*m01) + m02), then + d*m03 per layer
+          const float pym01 = py * m[1];
+          const float pym31 = py * m[13];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const f2 px = {(float)(x + 2 * h) + 0.5f, (float)(x + 2 * h) + 1.5f};
+            qb[h] = px * m[0] + pym01;
+            qb[h] = qb[h] + m[2];
+            if (!SIMPLE) {
+              q3b[h] = px * m[12] + pym31;
+              q3b[h] = q3b[h] + m[14];
+            }
+          }
+          rn = tb.rn;
+          wy0 = ta.wy0; wy1 = ta.wy1;
+          // smallest non-zero row weight: a side is exactly factorisable iff
+          // its product with this one survives the 1e-3 clamp (rounding is
+          // monotone)
+          wymin = (wy0 == 0.f) ? wy1 : ((wy1 == 0.f) ? wy0 : fminf(wy0, wy1));
+          wlo_f = (float)t_wlo;
+          // Clamp handling (sampling.py:218-222): corner weight w_x*w_y
+          // survives iff fl(w_x*w_y) > 1e-3.  A side whose product with the
+          // SMALLER row weight survives factorises exactly and goes to the
+          // window; otherwise it is taken out of the window (weight 0) and only
+          // its product with the LARGER row weight can survive: that one corner
+          // is queued for the tile.
+          wymax = fmaxf(wy0, wy1);
+          const int rmax = t_row0 + ((wy1 > wy0) ? 1 : 0);
+          has_max =
+              LSI_RFL(((wymax != wymin) && rmax >= 0 && rmax < rows) ? 1 : 0);
+          cmax = rmax * Wt + t_wlo;  // tile cell of window cell 0, row rmax
+          rmax_row = rmax;
+          // last admissible left-cell offset; a window of fewer than two cells
+          // (the whole segment maps outside the image) admits no lane at all
+          wspan = (unsigned)max(t_wwin - 2, 0);
+          win_ok = t_wwin >= 2 ? 1 : 0;
+          // the fast routes assume at most one clamped side per pixel
+          fast_ok = LSI_RFL((win_ok && tmin <= 0.5f) ? 1 : 0);
+          // route A touches cells cl0 .. cl0 + 3
+          wspanA = (unsigned)max(t_wwin - 4, 0);
+          fastA_ok = LSI_RFL((t_wwin >= 4 && tmin <= 0.5f) ? 1 : 0);
+          win_mask = win_ok ? ~0ull : 0ull;
+          // lanes exempt from the "strictly increasing" test: lane 0, and the
+          // tail lanes beyond the image (no in-window lane follows them)
+          inr_mask = FULL ? ~0ull : __ballot(inrange);
+          edge_mask = ~inr_mask | 1ull;
+          cur_slot = slot;
+          q_row0 = t_row0;
+          q_use_a = wy0 != 0.f && t_row0 >= 0 && t_row0 < rows;
+          q_use_b = wy1 != 0.f && t_row0 + 1 >= 0 && t_row0 + 1 < rows;
+          LSI_PROF(5);  // task setup
+        }
+#if LSI_STREAM_HOOKS
+        if (LEAN) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        LSI_PROF(0);  // waiting for this item's loads
+#endif
+        int next_tag = -1;
+        float x0v[4], w0v[4], w1v[4];
+        float4 Vv[4];  // route A: the lane's 4 cell sums; else V of its 4 pixels
+        int cl0 = 0, routeA = 0;
+        if (live) {
           // ---- projection of the 4 pixels as two packed pairs (v_pk_*_f32) --
-          float x0v[4], w0v[4], w1v[4];
-          float4 Vv[4];
           {
             const float dv[4] = {cur.d4.x, cur.d4.y, cur.d4.z, cur.d4.w};
             float pwv[4];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-              const f2 px = {(float)(x + 2 * h) + 0.5f,
-                             (float)(x + 2 * h) + 1.5f};
               const f2 dvp = {dv[2 * h], dv[2 * h + 1]};
               // q0 = ((px*m00 + py*m01) + m02) + d*m03, each op rounded
-              f2 q0 = px * m[0] + pym01;
-              q0 = q0 + m[2];
-              q0 = q0 + dvp * m[3];
+              const f2 q0 = qb[h] + dvp * m[3];
               f2 q3, u;
               if (SIMPLE) {
                 q3 = dvp;
                 u = q0;  // index-critical u = q0 / n' with n' == 1 exactly
               } else {
-                q3 = px * m[12] + pym31;
-                q3 = q3 + m[14];
-                q3 = q3 + dvp * m[15];
+                q3 = q3b[h] + dvp * m[15];
                 u.x = div_rn(q0.x, nden);  // index-critical: IEEE division
                 u.y = div_rn(q0.y, nden);
               }
@@ -662,29 +984,91 @@ __global__ __launch_bounds__(1024) void splat_stream_kernel(SplatArgs a,
               w1v[2 * h] = fx.x; w1v[2 * h + 1] = fx.y;
               pwv[2 * h] = e.x; pwv[2 * h + 1] = e.y;
             }
-            // V = (r, g, b, 1) * pixel weight, for all 4 pixels: after this the
-            // layer's input registers are dead and can take the next loads
-            if (LAYOUT == 0) {
-              Vv[0] = make_float4(cur.t0.x * pwv[0], cur.t0.y * pwv[0],
-                                  cur.t0.z * pwv[0], pwv[0]);
-              Vv[1] = make_float4(cur.t0.w * pwv[1], cur.t1.x * pwv[1],
-                                  cur.t1.y * pwv[1], pwv[1]);
-              Vv[2] = make_float4(cur.t1.z * pwv[2], cur.t1.w * pwv[2],
-                                  cur.t2.x * pwv[2], pwv[2]);
-              Vv[3] = make_float4(cur.t2.y * pwv[3], cur.t2.z * pwv[3],
-                                  cur.t2.w * pwv[3], pwv[3]);
-            } else {
-              Vv[0] = make_float4(cur.t0.x * pwv[0], cur.t1.x * pwv[0],
-                                  cur.t2.x * pwv[0], pwv[0]);
-              Vv[1] = make_float4(cur.t0.y * pwv[1], cur.t1.y * pwv[1],
-                                  cur.t2.y * pwv[1], pwv[1]);
-              Vv[2] = make_float4(cur.t0.z * pwv[2], cur.t1.z * pwv[2],
-                                  cur.t2.z * pwv[2], pwv[2]);
-              Vv[3] = make_float4(cur.t0.w * pwv[3], cur.t1.w * pwv[3],
-                                  cur.t2.w * pwv[3], pwv[3]);
+            // pixel i's colour channels (register selection at compile time)
+            auto tex_of = [&](int i, float& r, float& g, float& b_) {
+              if (LAYOUT == 0) {
+                const float t[12] = {cur.t0.x, cur.t0.y, cur.t0.z, cur.t0.w,
+                                     cur.t1.x, cur.t1.y, cur.t1.z, cur.t1.w,
+                                     cur.t2.x, cur.t2.y, cur.t2.z, cur.t2.w};
+                r = t[3 * i]; g = t[3 * i + 1]; b_ = t[3 * i + 2];
+              } else {
+                const float t0[4] = {cur.t0.x, cur.t0.y, cur.t0.z, cur.t0.w};
+                const float t1[4] = {cur.t1.x, cur.t1.y, cur.t1.z, cur.t1.w};
+                const float t2[4] = {cur.t2.x, cur.t2.y, cur.t2.z, cur.t2.w};
+                r = t0[i]; g = t1[i]; b_ = t2[i];
+              }
+            };
+            // ---- route A: a lane's 4 pixels land in cells cl0 .. cl0+3 ------
+            // Their 8 side contributions are summed per cell in registers and
+            // the window gets 4 read-modify-writes per lane instead of 8 (the
+            // kernel is bound by LDS cycles).  Lanes' cells of one RMW are
+            // distinct when floor(X) of the lanes' FIRST pixels increases
+            // strictly across the wave.
+            cl0 = (int)(x0v[0] - wlo_f);
+            int dl[4];
+            dl[0] = 0;
+            unsigned long long regA =
+                __ballot((unsigned)cl0 <= wspanA) &
+                (__ballot(x0v[0] > lane_below(x0v[0])) | edge_mask);
+#pragma unroll
+            for (int i = 1; i < 4; ++i) {
+              dl[i] = (int)(x0v[i] - x0v[0]);
+              regA &= __ballot((unsigned)dl[i] <= 2u);
             }
+            routeA = LSI_RFL((((~regA & inr_mask) == 0ull) && fastA_ok) ? 1 : 0);
+            if (routeA) {
+#pragma unroll
+              for (int k = 0; k < 4; ++k) Vv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                float w0 = w0v[i], w1 = w1v[i];
+                float r, g, b_;
+                tex_of(i, r, g, b_);
+                const float4 V =
+                    make_float4(r * pwv[i], g * pwv[i], b_ * pwv[i], pwv[i]);
+                // clamp (at most the smaller side: tmin <= 0.5 on this route)
+                const unsigned long long clamped =
+                    __ballot(!(fminf(w0, w1) >= tmin)) & inr_mask;
+                if (clamped != 0ull) {
+                  const bool c0 = !(w0 >= tmin), c1 = !(w1 >= tmin);
+                  if (has_max) {
+                    const float kq = (c0 ? w0 : w1) * wymax;
+                    const int cellq = t_wlo + cl0 + dl[i] + (c0 ? 0 : 1);
+                    push(inrange && (c0 || c1) && kq > 1.0e-3f &&
+                             (unsigned)cellq < (unsigned)Wt,
+                         rmax_row * Wt + cellq,
+                         make_float4(V.x * kq, V.y * kq, V.z * kq, V.w * kq));
+                  }
+                  if (c0) w0 = 0.0f;
+                  if (c1) w1 = 0.0f;
+                }
+                if (i == 0) {
+                  Vv[0] = make_float4(V.x * w0, V.y * w0, V.z * w0, V.w * w0);
+                  Vv[1] = make_float4(V.x * w1, V.y * w1, V.z * w1, V.w * w1);
+                } else {
+                  const bool e0 = dl[i] == 0, e1 = dl[i] == 1, e2 = dl[i] == 2;
+                  const float a0 = e0 ? w0 : 0.0f;
+                  const float a1 = e1 ? w0 : (e0 ? w1 : 0.0f);
+                  const float a2 = e2 ? w0 : (e1 ? w1 : 0.0f);
+                  const float a3 = e2 ? w1 : 0.0f;
+                  Vv[0] = f4_fma(Vv[0], V, a0);
+                  Vv[1] = f4_fma(Vv[1], V, a1);
+                  Vv[2] = f4_fma(Vv[2], V, a2);
+                  Vv[3] = f4_fma(Vv[3], V, a3);
+                }
+              }
+            } else {
+              // V = (r, g, b, 1) * pixel weight, for all 4 pixels
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                float r, g, b_;
+                tex_of(i, r, g, b_);
+                Vv[i] = make_float4(r * pwv[i], g * pwv[i], b_ * pwv[i], pwv[i]);
+              }
+            }
+            // (after this the layer's input registers are dead and can take
+            // the next loads)
           }
-          // next layer's loads in flight during the LDS phase, no register copy
           // The derived values are pinned here so that the projection is not
           // sunk below the loads: the loads then overwrite dead registers and
           // need no copies.
@@ -694,174 +1078,236 @@ __global__ __launch_bounds__(1024) void splat_stream_kernel(SplatArgs a,
                               "+v"(Vv[i].w), "+v"(x0v[i]), "+v"(w0v[i]),
                               "+v"(w1v[i]));
           }
-          if (l + 1 < l_end && !(dbg & 256)) load_layer(cur);  // 256: timing
-
-          // ---- LDS phase, pixel by pixel (cells of one lane's pixels overlap)
+          LSI_PROF(1);  // projection
+        }
+        next_tag = issue(cur);  // the set takes the item two ahead
+        LSI_PROF(2);  // ticket, addresses, load issue
+        if (live) {
+          if (!(dbg & 128)) {  // 128: no window phase (timing only)
+          // ---- window phase ---------------------------------------------------
+          // One test per layer decides between the branch-free fast route (all
+          // 4 pixels of every lane land inside the window, and floor(X) is
+          // strictly increasing across the wave, so the lanes' left cells are
+          // distinct) and the exact general route.
+          if (routeA) {
+            // cells cl0, cl0+2 share a half of the window, cl0+1, cl0+3 the other
+            const int par = cl0 & 1, hlf = cl0 >> 1;
+            float4* ce = rb + hlf + par * WHS;              // cell cl0
+            float4* co = rb + hlf + par + (1 - par) * WHS;  // cell cl0 + 1
+            if (FULL || inrange) {
+              float4 t;
+              t = ce[0]; t.x += Vv[0].x; t.y += Vv[0].y; t.z += Vv[0].z; t.w += Vv[0].w; ce[0] = t;
+              LSI_COMPILER_FENCE();
+              t = co[0]; t.x += Vv[1].x; t.y += Vv[1].y; t.z += Vv[1].z; t.w += Vv[1].w; co[0] = t;
+              LSI_COMPILER_FENCE();
+              t = ce[1]; t.x += Vv[2].x; t.y += Vv[2].y; t.z += Vv[2].z; t.w += Vv[2].w; ce[1] = t;
+              LSI_COMPILER_FENCE();
+              t = co[1]; t.x += Vv[3].x; t.y += Vv[3].y; t.z += Vv[3].z; t.w += Vv[3].w; co[1] = t;
+            }
+            LSI_COMPILER_FENCE();
+          } else {
+          int clv[4];
+          unsigned long long regular = ~0ull;
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            const float x0 = x0v[i];
-            float w0 = w0v[i], w1 = w1v[i];
-            const float4 V = Vv[i];
             // left-cell offset in the window (+-Inf saturates; NaN gives
-            // offset 0 but both its side weights are then clamped to 0 below)
-            const int cl = (int)(x0 - wlo_f);
-#ifdef LSI_EXPERIMENT_NOCHECK  // timing experiment only: results are wrong
-            {
-              float4* cellx = rb + (cl & 127);
-              if (inrange) {
-                cellx[0] = f4_fma(cellx[0], V, w0);
+            // offset 0 but both its side weights are then clamped to 0)
+            clv[i] = (int)(x0v[i] - wlo_f);
+            regular &= __ballot((unsigned)clv[i] <= wspan);
+            regular &= __ballot(x0v[i] > lane_below(x0v[i])) | edge_mask;
+          }
+          if (((~regular & inr_mask) == 0ull) && fast_ok) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              float w0 = w0v[i], w1 = w1v[i];
+              const float4 V = Vv[i];
+              // w0 + w1 = 1: at most the smaller side can be clamped
+              const unsigned long long clamped =
+                  __ballot(!(fminf(w0, w1) >= tmin)) & inr_mask;
+              if (clamped != 0ull) {
+                // (tmin <= 0.5 on this route: only the smaller side can be)
+                const bool c0 = !(w0 >= tmin), c1 = !(w1 >= tmin);
+                if (has_max) {
+                  const float k = (c0 ? w0 : w1) * wymax;
+                  const int cellq = t_wlo + clv[i] + (c0 ? 0 : 1);
+                  push(inrange && (c0 || c1) && k > 1.0e-3f &&
+                           (unsigned)cellq < (unsigned)Wt,
+                       rmax_row * Wt + cellq,
+                       make_float4(V.x * k, V.y * k, V.z * k, V.w * k));
+                }
+                if (c0) w0 = 0.0f;
+                if (c1) w1 = 0.0f;
+              }
+              float4* cell = rb + (clv[i] >> 1) + (clv[i] & 1) * WHS;
+              float4* cell1 = rb + ((clv[i] + 1) >> 1) + ((clv[i] + 1) & 1) * WHS;
+              if (FULL || inrange) {
+                *cell = f4_fma(*cell, V, w0);
                 LSI_COMPILER_FENCE();
-                cellx[1] = f4_fma(cellx[1], V, w1);
+                *cell1 = f4_fma(*cell1, V, w1);
               }
               LSI_COMPILER_FENCE();
-              continue;
             }
-#endif
-            // in-window lanes: both cells inside the (in-image) window.  Each
-            // ballot is taken straight from one compare; the masks are
-            // combined with scalar ops.
-            const bool in_b = (unsigned)cl <= wspan;
-            const bool inw = in_b && inrange && win_ok;
-            const unsigned long long inw_mask = __ballot(in_b) & inr_mask & win_mask;
-            // lane l-1's floor(X) by DPP wave_shr:1 (VALU, no LDS round trip)
-            const float prev = __int_as_float(__builtin_amdgcn_mov_dpp(
-                __float_as_int(x0), 0x138, 0xf, 0xf, true));
-            const unsigned long long mono_ok = __ballot(x0 > prev) | edge_mask;
-            // clamped sides: !(p > 1e-3) is also true for NaN weights
-            const bool c0 = !(w0 * wymin > 1.0e-3f);
-            const bool c1 = !(w1 * wymin > 1.0e-3f);
-            const unsigned long long clamp_mask =
-                (__ballot(c0) | __ballot(c1)) & inw_mask;
-            if (has_max) {
-              if (clamp_mask != 0ull) {
+          } else {
+            // ---- general route, pixel by pixel ------------------------------
+            // (one copy of the code: the loop is not unrolled, the pixel's
+            // values are selected -- this route is rare)
+#pragma unroll 1
+            for (int i = 0; i < 4; ++i) {
+              auto pick = [&](float a0, float a1, float a2, float a3) {
+                return i == 0 ? a0 : (i == 1 ? a1 : (i == 2 ? a2 : a3));
+              };
+              const float x0 = pick(x0v[0], x0v[1], x0v[2], x0v[3]);
+              float w0 = pick(w0v[0], w0v[1], w0v[2], w0v[3]);
+              float w1 = pick(w1v[0], w1v[1], w1v[2], w1v[3]);
+              const float4 V = make_float4(
+                  pick(Vv[0].x, Vv[1].x, Vv[2].x, Vv[3].x),
+                  pick(Vv[0].y, Vv[1].y, Vv[2].y, Vv[3].y),
+                  pick(Vv[0].z, Vv[1].z, Vv[2].z, Vv[3].z),
+                  pick(Vv[0].w, Vv[1].w, Vv[2].w, Vv[3].w));
+              const int cl = (int)(x0 - wlo_f);
+              const bool in_b = (unsigned)cl <= wspan;
+              const bool inw = in_b && inrange && win_ok;
+              const unsigned long long inw_mask =
+                  __ballot(in_b) & inr_mask & win_mask;
+              const unsigned long long mono_ok =
+                  __ballot(x0 > lane_below(x0)) | edge_mask;
+              // clamped sides: !(p > 1e-3) is also true for NaN weights
+              const bool c0 = !(w0 * wymin > 1.0e-3f);
+              const bool c1 = !(w1 * wymin > 1.0e-3f);
+              if (has_max) {
                 const float k0 = w0 * wymax, k1 = w1 * wymax;
-                if (inw && c0 && k0 > 1.0e-3f) {
-                  float* e = emax + cl * 4;
-                  atomic_add_f32(e + 0, V.x * k0);
-                  atomic_add_f32(e + 1, V.y * k0);
-                  atomic_add_f32(e + 2, V.z * k0);
-                  atomic_add_f32(e + 3, V.w * k0);
-                }
-                if (inw && c1 && k1 > 1.0e-3f) {
-                  float* e = emax + cl * 4 + 4;
-                  atomic_add_f32(e + 0, V.x * k1);
-                  atomic_add_f32(e + 1, V.y * k1);
-                  atomic_add_f32(e + 2, V.z * k1);
-                  atomic_add_f32(e + 3, V.w * k1);
-                }
+                push(inw && c0 && k0 > 1.0e-3f &&
+                         (unsigned)(t_wlo + cl) < (unsigned)Wt, cmax + cl,
+                     make_float4(V.x * k0, V.y * k0, V.z * k0, V.w * k0));
+                push(inw && c1 && k1 > 1.0e-3f &&
+                         (unsigned)(t_wlo + cl + 1) < (unsigned)Wt, cmax + cl + 1,
+                     make_float4(V.x * k1, V.y * k1, V.z * k1, V.w * k1));
               }
-            }
-            // lanes outside the window: exact slow path (cells outside the
-            // image and non-finite X fail its range tests and add nothing)
-            if ((inr_mask & ~inw_mask) != 0ull && !(dbg & 1)) {
-              if (inrange && !inw && V.w != 0.0f)
-                slow_corners(extras, V, x0, w0, w1, xmax, wy0, wy1, t_row0,
-                             rows, Wt);
-            }
-            if (c0) w0 = 0.0f;
-            if (c1) w1 = 0.0f;
-            float4* cell = rb + cl;  // dereferenced by in-window lanes only
-            if (mono_ok == ~0ull || (dbg & 2)) {
-              if (inw && !(dbg & 128)) {  // dbg 128: no window traffic (timing)
-                cell[0] = f4_fma(cell[0], V, w0);
-                LSI_COMPILER_FENCE();
-                cell[1] = f4_fma(cell[1], V, w1);
-              }
-              LSI_COMPILER_FENCE();
-            } else if (inw_mask != 0ull) {
-              // some lanes may share cells: serialise by arrival rank
-              unsigned* cn = cnt + cl;
-              unsigned rank = 0u;
-              if (inw) rank = atomicAdd(cn, 1u);
-              for (unsigned r = 0;; ++r) {
-                if (__ballot(inw && rank >= r) == 0ull) break;
-                if (inw && rank == r) {
-                  cell[0] = f4_fma(cell[0], V, w0);
+              // lanes outside the window: exact 4-corner path (cells outside
+              // the image and non-finite X fail its range tests, add nothing)
+              push_corners(inrange && !inw && V.w != 0.0f, V, x0, w0, w1, wy0,
+                           wy1, t_row0);
+              if (c0) w0 = 0.0f;
+              if (c1) w1 = 0.0f;
+              // (dereferenced by in-window lanes only)
+              float4* cell = rb + (cl >> 1) + (cl & 1) * WHS;
+              float4* cell1 = rb + ((cl + 1) >> 1) + ((cl + 1) & 1) * WHS;
+              if (mono_ok == ~0ull) {
+                if (inw) {
+                  *cell = f4_fma(*cell, V, w0);
                   LSI_COMPILER_FENCE();
-                  cell[1] = f4_fma(cell[1], V, w1);
+                  *cell1 = f4_fma(*cell1, V, w1);
                 }
                 LSI_COMPILER_FENCE();
+              } else if (inw_mask != 0ull) {
+                // some lanes may share a left cell: rounds of election through
+                // a byte per cell; the winners of a round have distinct cells
+                bool pending = inw;
+                for (;;) {
+                  if (__ballot(pending) == 0ull) break;
+                  if (pending) sc[cl] = (unsigned char)lane;
+                  LSI_COMPILER_FENCE();
+                  const bool won = pending && sc[cl] == (unsigned char)lane;
+                  LSI_COMPILER_FENCE();
+                  if (won) {
+                    *cell = f4_fma(*cell, V, w0);
+                    LSI_COMPILER_FENCE();
+                    *cell1 = f4_fma(*cell1, V, w1);
+                  }
+                  LSI_COMPILER_FENCE();
+                  pending = pending && !won;
+                }
               }
-              if (inw) *cn = 0u;
-              LSI_COMPILER_FENCE();
             }
           }
+          }
+          }
         }
-      }
-      if (tdbg && lane == 0 && step == 0) tdbg[16 + wave] = (long long)__builtin_readcyclecounter();
-      LSI_TSTAMP();
-      __syncthreads();
-      LSI_TSTAMP();
+        LSI_PROF(3);  // window phase
+        if (live && (tag & (1 << 21))) {
+          // ---- last layer done: window -> the task's two tile rows ----------
+          const bool use_a = q_use_a, use_b = q_use_b;
+          if (ordered) {
+            wait_turn(slot);
+          } else {  // ascending order: no deadlock
+            if (use_a) lock_row(t_row0);
+            if (use_b) lock_row(t_row0 + 1);
+          }
+          if (qn != 0) apply_queue();
+          float4* trow = tile4 + (long)t_row0 * Wt + t_wlo;
+#ifndef LSI_MERGE_BATCHED
+          for (int c = lane; c < t_wwin; c += 64) {
+            float4* wc = rb + (c >> 1) + (c & 1) * WHS;
+            const float4 v = *wc;
+            *wc = make_float4(0.f, 0.f, 0.f, 0.f);  // ready for the next task
+            const bool inside = (unsigned)(t_wlo + c) < (unsigned)Wt;
+            if (use_a && inside) trow[c] = f4_fma(trow[c], v, wy0);
+            if (use_b && inside) trow[Wt + c] = f4_fma(trow[Wt + c], v, wy1);
+          }
+#else
+          // two cells per lane and round: all reads first, then all writes
+          // (one LDS round trip for six accesses)
+          for (int c0 = 0; c0 < t_wwin; c0 += 128) {
+            const int ca = c0 + lane, cb = ca + 64;
+            const bool va = ca < t_wwin, vb = cb < t_wwin;
+            float4* wa = rb + (ca >> 1) + (ca & 1) * WHS;
+            float4* wb = rb + (cb >> 1) + (cb & 1) * WHS;
+            const bool ia = va && (unsigned)(t_wlo + ca) < (unsigned)Wt;
+            const bool ib = vb && (unsigned)(t_wlo + cb) < (unsigned)Wt;
+            const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 xa = z4, xb = z4, a0 = z4, a1 = z4, b0 = z4, b1 = z4;
+            if (va) xa = *wa;
+            if (vb) xb = *wb;
+            if (use_a && ia) a0 = trow[ca];
+            if (use_b && ia) a1 = trow[Wt + ca];
+            if (use_a && ib) b0 = trow[cb];
+            if (use_b && ib) b1 = trow[Wt + cb];
+            LSI_COMPILER_FENCE();
+            if (va) *wa = z4;  // ready for the next task
+            if (vb) *wb = z4;
+            if (use_a && ia) trow[ca] = f4_fma(a0, xa, wy0);
+            if (use_b && ia) trow[Wt + ca] = f4_fma(a1, xa, wy1);
+            if (use_a && ib) trow[cb] = f4_fma(b0, xb, wy0);
+            if (use_b && ib) trow[Wt + cb] = f4_fma(b1, xb, wy1);
+          }
+#endif
+          if (ordered) {
+            pass_turn(slot);
+          } else {
+            if (use_b) unlock_row(t_row0 + 1);
+            if (use_a) unlock_row(t_row0);
+          }
+        }
+        LSI_PROF(4);  // merge
+        return next_tag;
+      };
 
-      // ================= merge: cell owners gather the windows =============
-      if (tid == 0) yrange[2] = 0;  // next step's tickets (no draws until then)
-      {
-        const UnitArgs ua = unit_args();
-        const int NB = ua.nb, nunits = rows * NB;
-        // lane t holds task slot t's table entry; the slots that touch a unit
-        // are found with one ballot and their entries broadcast by readlane
-        TaskA mine;
-        mine.row0 = -1000000; mine.wy0 = 0.f; mine.wy1 = 0.f; mine.win = 0;
-        if (lane < NWIN) mine = taskA[sidx * NWIN + lane];
-        const int mine_wlo = mine.win & 0xffff, mine_wwin = mine.win >> 16;
-        for (int unit = wave; unit < nunits; unit += NW) {
-          const int r = div_small(unit, NB, ua.inv_nb);
-          const int c0 = (unit - r * NB) * 64;
-          const int cell = c0 + lane;
-          const bool hit =
-              ((mine.row0 == r && mine.wy0 != 0.f) ||
-               (mine.row0 + 1 == r && mine.wy1 != 0.f)) &&
-              (mine_wlo <= c0 + 63) && (mine_wlo + mine_wwin > c0);
-          unsigned long long todo = __ballot(hit);
-          // entry t of the table, broadcast; value of window t at this lane's
-          // cell (0 outside the window) and the row weight that applies
-          auto fetch = [&](int t, float4& v, float& wy) {
-            const int q_row0 = __builtin_amdgcn_readlane(mine.row0, t);
-            const int q_win = __builtin_amdgcn_readlane(mine.win, t);
-            const int q_wlo = q_win & 0xffff, q_wwin = q_win >> 16;
-            const float q_wy0 = __int_as_float(
-                __builtin_amdgcn_readlane(__float_as_int(mine.wy0), t));
-            const float q_wy1 = __int_as_float(
-                __builtin_amdgcn_readlane(__float_as_int(mine.wy1), t));
-            wy = (q_row0 == r) ? q_wy0 : q_wy1;
-            const int rel = cell - q_wlo;
-            const bool in = rel >= 0 && rel < q_wwin && cell < Wt;
-            v = rb_all[t * WMAX + (in ? rel : 0)];
-            if (!in) wy = 0.0f;
-          };
-          float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-          const bool any = todo != 0ull;
-          while (todo) {  // two independent LDS reads in flight per iteration
-            const int t0 = __builtin_ctzll(todo);
-            todo &= todo - 1;
-            float4 va, vb = make_float4(0.f, 0.f, 0.f, 0.f);
-            float wa, wb = 0.0f;
-            fetch(t0, va, wa);
-            if (todo) {
-              const int t1 = __builtin_ctzll(todo);
-              todo &= todo - 1;
-              fetch(t1, vb, wb);
-            }
-            acc = f4_fma(acc, va, wa);
-            acc = f4_fma(acc, vb, wb);
-          }
-          if (any && cell < Wt) {  // the unit's owner adds into the tile
-            float4* tcell = reinterpret_cast<float4*>(extras) + r * Wt + cell;
-            float4 tv = *tcell;
-            tv.x += acc.x; tv.y += acc.y; tv.z += acc.z; tv.w += acc.w;
-            *tcell = tv;
-          }
-        }
+      PxData setA, setB;
+      setA.d4 = setA.t0 = setA.t1 = setA.t2 = make_float4(0.f, 0.f, 0.f, 0.f);
+      setA.m4 = make_float4(1.f, 1.f, 1.f, 1.f);
+      setB = setA;
+      int tagA = issue(setA);
+      int tagB = issue(setB);
+      LSI_PROF_START();
+      // (a set without an item -- a masked row was drawn, or the tickets ran
+      // out -- tries again; the stream ends when both sets are empty and no
+      // ticket is left)
+      while (LSI_RFL((tagA >= 0 || tagB >= 0 || ld_done == 0) ? 1 : 0)) {
+        tagA = item(setA, tagA);
+        tagB = item(setB, tagB);
+      }
+      if (tdbg && lane == 0 && chunk0 == 0 && pass == 0) {
+        tdbg[12 + wave] = (long long)__builtin_readcyclecounter();
+#if LSI_STREAM_HOOKS
+        for (int k = 0; k < 6; ++k) tdbg[32 + wave * 8 + k] = prof[k];
+#endif
       }
       LSI_TSTAMP();
-      // windows and the task table are reused by the next step; after the
-      // last one every wave goes on to its own cells' epilogue
-      if (step + 1 < nstep) __syncthreads();
+      __syncthreads();  // every window is merged: the tile is complete
       LSI_TSTAMP();
     }
 
     // ================= epilogue for this pass ===============================
-    // (each wave finishes the units it merged: no barrier needed before)
     const EpilogueArgs ea = epilogue_args();
     const UnitArgs ua = unit_args();
     const int NB = ua.nb, nunits = rows * NB;
@@ -887,7 +1333,7 @@ __global__ __launch_bounds__(1024) void splat_stream_kernel(SplatArgs a,
       const int r = div_small(unit, NB, ua.inv_nb);
       const int cell = (unit - r * NB) * 64 + lane;
       if (cell >= Wt) continue;
-      float4* tcell = reinterpret_cast<float4*>(extras) + r * Wt + cell;
+      float4* tcell = tile4 + r * Wt + cell;
       const float4 A = *tcell;
       if (r == 0 && top_shared) {
         store_coherent(xrow(band, 1) + cell, A);      // lower band's share
@@ -906,20 +1352,20 @@ __global__ __launch_bounds__(1024) void splat_stream_kernel(SplatArgs a,
       __builtin_amdgcn_s_waitcnt(0);
       __syncthreads();
       if (tid == 0) {
-        yrange[4] = top_shared
-                        ? __hip_atomic_fetch_add(&ea.xcount[xb + band], 1,
-                                                 __ATOMIC_RELAXED,
-                                                 __HIP_MEMORY_SCOPE_AGENT)
-                        : 0;
-        yrange[5] = bot_shared
-                        ? __hip_atomic_fetch_add(&ea.xcount[xb + band + 1], 1,
-                                                 __ATOMIC_RELAXED,
-                                                 __HIP_MEMORY_SCOPE_AGENT)
-                        : 0;
+        ctl[4] = top_shared
+                     ? __hip_atomic_fetch_add(&ea.xcount[xb + band], 1,
+                                              __ATOMIC_RELAXED,
+                                              __HIP_MEMORY_SCOPE_AGENT)
+                     : 0;
+        ctl[5] = bot_shared
+                     ? __hip_atomic_fetch_add(&ea.xcount[xb + band + 1], 1,
+                                              __ATOMIC_RELAXED,
+                                              __HIP_MEMORY_SCOPE_AGENT)
+                     : 0;
       }
       __syncthreads();
-      const bool fin_top = top_shared && yrange[4] == 1;
-      const bool fin_bot = bot_shared && yrange[5] == 1;
+      const bool fin_top = top_shared && ctl[4] == 1;
+      const bool fin_bot = bot_shared && ctl[5] == 1;
       if (fin_top || fin_bot) {
         for (int unit = wave; unit < nunits; unit += NW) {
           const int r = div_small(unit, NB, ua.inv_nb);
@@ -927,8 +1373,7 @@ __global__ __launch_bounds__(1024) void splat_stream_kernel(SplatArgs a,
           if (cell >= Wt) continue;
           const bool top = (r == 0 && fin_top), bot = (r == R && fin_bot);
           if (!top && !bot) continue;
-          const float4 mine_v =
-              *(reinterpret_cast<float4*>(extras) + r * Wt + cell);
+          const float4 mine_v = *(tile4 + r * Wt + cell);
           const float4* other = top ? xrow(band, 0) : xrow(band + 1, 1);
           const float4 o4 = load_coherent(other + cell);
           finish(r, cell, make_float4(mine_v.x + o4.x, mine_v.y + o4.y,
@@ -946,11 +1391,8 @@ __global__ __launch_bounds__(1024) void splat_stream_kernel(SplatArgs a,
       if (pass + 1 < npass) {  // shared tile rows start the next pass empty
         __syncthreads();
         for (int i = tid; i < Wt; i += T) {
-          if (top_shared)
-            reinterpret_cast<float4*>(extras)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (bot_shared)
-            reinterpret_cast<float4*>(extras)[R * Wt + i] =
-                make_float4(0.f, 0.f, 0.f, 0.f);
+          if (top_shared) tile4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (bot_shared) tile4[R * Wt + i] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
       }
     }
@@ -959,17 +1401,22 @@ __global__ __launch_bounds__(1024) void splat_stream_kernel(SplatArgs a,
   }
 }
 
-// task-table entries: whole steps, about 256 tasks per refill
-int stream_cap(int nw, int tpw) {
-  const int nwin = nw * tpw;
-  return nwin * (256 / nwin > 0 ? 256 / nwin : 1);
+// task-table entries per chunk
+int stream_cap(int ntask) {
+  int cap = (ntask + 15) / 16 * 16;
+  if (cap < 16) cap = 16;
+  if (cap > 512) cap = 512;
+  return cap;
 }
 
 size_t stream_lds_bytes(const LsiSplatDesc* d, int tile_rows, int nw, int wmax,
-                        int tpw) {
-  return (size_t)nw * tpw * wmax * 16 + (size_t)nw * wmax * 4 +
+                        int cap, int qcap) {
+  return (size_t)nw * (2 * (((wmax / 2 + 15) & ~15) + 8)) * 16 +
+         (size_t)nw * wmax +
          (size_t)tile_rows * d->Wt * 16 +
-         (size_t)stream_cap(nw, tpw) * (sizeof(TaskA) + sizeof(TaskB)) + 32;
+         (size_t)cap * (sizeof(TaskA) + sizeof(TaskB) + sizeof(TaskC)) +
+         (size_t)((8 + tile_rows + 2 + 3) & ~3) * 4 + (size_t)nw * qcap * 20 +
+         16;
 }
 
 // layout class of the texture strides: 0 channels-last, 1 planar, -1 neither
@@ -1023,8 +1470,8 @@ extern "C" int lsi_stream_ok(const LsiSplatDesc* d, const float* M) {
     if (!(span == span)) return 0;
     need = fmaxf(need, span);
   }
-  int win = (int)ceilf(need) + 8;
-  win = (win + 63) / 64 * 64;
+  int win = (int)ceilf(need) + 8;  // the window's margin: 1 cell left, 4 right
+  win = (win + 15) / 16 * 16;
   if (win < 64) win = 64;
   if (win > 512) win = 512;  // beyond this the excess takes the exact slow path
   return win | (simple ? LSI_STREAM_SIMPLE_BIT : 0);
@@ -1048,69 +1495,90 @@ size_t lsi_stream_workspace_bytes(const LsiSplatDesc* d) {
   return x.count_bytes + x.part_bytes;
 }
 
-// Band height, waves and windows per workgroup.  One workgroup runs per CU at
-// a time (registers), so the cost model is: rounds of workgroups x (fixed
-// prologue/epilogue + per-step barriers and merge + the longest chain of tasks
-// on a SIMD).  Units: shader cycles, fitted to tools/phase_probe.py timelines.
-static int stream_plan(const LsiSplatDesc* d, int wmax, StreamCfg* cfg,
-                       int* nw_out) {
+// Band height, waves per workgroup and layer groups per task.  Units: shader
+// cycles.  The cost model: a workgroup spends a fixed prologue (clear tile and
+// windows, row range, task table), then its waves stream through the tasks
+// with no barrier -- bounded either by the waves' own latency chains or by the
+// CU's instruction issue shared with the co-resident workgroups -- then the
+// last waves finish alone (tail), then the epilogue.
+struct StreamPlan { int R, nw, xch, ngrp, lpg, cap, qcap; size_t lds; double est; };
+
+static int stream_plan(const LsiSplatDesc* d, int wmax, StreamPlan* out) {
   const int nseg = (d->W + SEG - 1) / SEG;
-  const int tpw_override = (d->reserved >> 12) & 0xf;  // experiments only
+  const int grp_override = (d->reserved >> 12) & 0xf;  // experiments only
   static const char* cap_env = getenv("LSI_STREAM_LDS_CAP");  // experiments
-  const size_t lds_cap = cap_env ? (size_t)atol(cap_env) : 156 * 1024;
-  double best = -1.0;
-  int bR = 0, bnw = 0, btpw = 0, bx = 0;
-  const int layers = (d->flags & LSI_COMPOSE) ? d->L : 1;
-  const int npass = (d->flags & LSI_COMPOSE) ? 1 : d->L;
+  const size_t lds_cap = cap_env ? (size_t)atol(cap_env) : 160 * 1024;
+  static const char* tl_env = getenv("LSI_STREAM_TLAT");
+  static const char* ti_env = getenv("LSI_STREAM_TISSUE");
+  // per (task, layer) item = 4 pixels per lane: a wave alone needs ~t_lat for
+  // it; a CU retires one item per ~t_issue when enough waves share its SIMDs
+  const double t_lat = tl_env ? atof(tl_env) : 3000.0;
+  const double t_issue = ti_env ? atof(ti_env) : 400.0;
+  const bool compose = (d->flags & LSI_COMPOSE) != 0;
+  const int layers = compose ? d->L : 1;
+  const int npass = compose ? 1 : d->L;
   const int force_mode = (d->reserved >> 16) & 3;  // experiments: 1 halo, 2 exchange
+  StreamPlan best; best.est = -1.0; best.nw = 0;
   for (int xch = 0; xch <= 1; ++xch) {
     if (force_mode && xch != force_mode - 1) continue;
     for (int R = 1; R <= 64; R *= 2) {
       if (d->tune_rows > 0 && R != d->tune_rows) continue;
       if (d->tune_rows <= 0 && R > 1 && R / 2 >= d->Ht) break;
       const long nwg = (long)((d->Ht + R - 1) / R) * d->B;
-      const long rounds = (nwg + 255) / 256;
       // source rows per band ~ R / s (one more target row's worth when the
-      // band re-reads its halo); one task per (row, 256-pixel segment)
-      const int ntask =
-          (int)ceilf((float)(R + 1 - xch) / d->trg_downsampling) * nseg;
-      // a task alone on a SIMD is latency-bound (~500 cycles per pixel
-      // iteration: two dependent LDS round trips); the CU's four SIMDs issue
-      // one pixel iteration per ~42 cycles when enough waves share them
-      const double t_lat = layers * 4 * 500.0, t_issue = layers * 4 * 42.5;
-      for (int c = MAXNW; c >= 4; --c) {
-        if (d->tune_threads > 0 && c != (d->tune_threads + 63) / 64) continue;
-        for (int t = 1; t <= 8 && c * t <= 64; ++t) {
-          if (tpw_override && t != tpw_override) continue;
-          if (stream_lds_bytes(d, R + xch, c, wmax, t) > lds_cap) break;
-          const int steps = (ntask + c * t - 1) / (c * t);
-          const double per_step = (double)ntask / steps;  // tasks in a step
-          // tickets balance the waves; the step still ends ~a third of a
-          // wave's share after the average wave (measured), then merges
-          const double step_cost = 6000.0 + 0.35 * (per_step / c) * t_lat;
-          const double xpass =
-              fmax((double)ntask / c * t_lat, ntask * t_issue) + 0.5 * t_lat;
-          const double est =
-              (double)rounds *
-              (8000.0 +
-               npass * (3000.0 + 6500.0 * xch + steps * step_cost + xpass));
-          if (best < 0.0 || est < best) {
-            best = est; bR = R; bnw = c; btpw = t; bx = xch;
+      // band re-reads its halo)
+      const int srows =
+          (int)ceilf((float)(R + 1 - xch) / d->trg_downsampling);
+      for (int ngrp = 1; ngrp <= layers; ++ngrp) {
+        if (grp_override && ngrp != (grp_override < layers ? grp_override : layers))
+          continue;
+        const int lpg = (layers + ngrp - 1) / ngrp;
+        if ((layers + lpg - 1) / lpg != ngrp) continue;  // same split, fewer groups
+        const int ntask = srows * nseg * ngrp;
+        const int cap_override = (d->reserved >> 20) & 0xff;  // experiments
+        const int cap = cap_override ? cap_override * 16 : stream_cap(ntask);
+        for (int c = MAXNW; c >= 4; --c) {
+          if (d->tune_threads > 0 && c != (d->tune_threads + 63) / 64) continue;
+          int q = 64;
+          while (q >= 16 &&
+                 stream_lds_bytes(d, R + xch, c, wmax, cap, q) > lds_cap)
+            q /= 2;
+          if (q < 16) continue;
+          const size_t lds = stream_lds_bytes(d, R + xch, c, wmax, cap, q);
+          long k = (long)(160 * 1024 / lds);   // co-resident workgroups per CU
+          if (k > MAXNW / c) k = MAXNW / c;    // (128 VGPRs: 16 waves per CU)
+          if (k < 1) k = 1;
+          const long kk = (nwg + 255) / 256 < k ? (nwg + 255) / 256 : k;
+          const long rounds = (nwg + 256 * kk - 1) / (256 * kk);
+          const double cells = (double)(R + xch) * d->Wt + (double)c * wmax;
+          const double fixed = 5000.0 + cells / (c * 64.0) * 10.0 +
+                               (double)cap / c * 3.0;
+          // a wave's time per item: its own latency chain, or its share of
+          // the CU's issue capacity when every wave is busy
+          const double per_item = fmax(t_lat, (double)(c * kk) * t_issue);
+          // waves take tasks in rounds: the last round is rarely full
+          const double task_rounds = ceil((double)ntask / c);
+          const double loop = task_rounds * (lpg * per_item + 1600.0);
+          const double epi = (double)(R + xch) * d->Wt / (c * 64.0) * 70.0 +
+                             2500.0 + 16000.0 * xch;
+          const double est = (double)rounds * (fixed + npass * (loop + epi));
+          if (best.est < 0.0 || est < best.est) {
+            best.est = est; best.R = R; best.nw = c; best.xch = xch;
+            best.ngrp = ngrp; best.lpg = lpg; best.cap = cap; best.qcap = q;
+            best.lds = lds;
           }
         }
       }
     }
   }
-  if (bnw == 0) return LSI_EINVAL;
-  cfg->R = bR;
-  cfg->tpw = btpw;
-  cfg->exchange = bx;
-  *nw_out = bnw;
+  if (best.nw == 0) return LSI_EINVAL;
+  *out = best;
   static const bool verbose = getenv("LSI_STREAM_VERBOSE") != nullptr;
   if (verbose)
-    fprintf(stderr, "lsi stream plan: R=%d waves=%d windows/wave=%d %s est=%.0f "
-            "cycles lds=%zu\n", bR, bnw, btpw, bx ? "exchange" : "halo", best,
-            stream_lds_bytes(d, bR + bx, bnw, wmax, btpw));
+    fprintf(stderr, "lsi stream plan: R=%d waves=%d %s layer-groups=%d x %d "
+            "table=%d queue=%d est=%.0f cycles lds=%zu\n", best.R, best.nw,
+            best.xch ? "exchange" : "halo", best.ngrp, best.lpg, best.cap,
+            best.qcap, best.est, best.lds);
   return LSI_OK;
 }
 
@@ -1127,18 +1595,27 @@ int lsi_stream_launch(const SplatArgs& a, hipStream_t stream) {
   const int NB = (d->Wt + 63) / 64;
   StreamCfg cfg;
   cfg.wmax = d->tune_window & ~LSI_STREAM_SIMPLE_BIT;
-  int nw = 0;
-  if (stream_plan(d, cfg.wmax, &cfg, &nw) != LSI_OK) return LSI_EINVAL;
-  const int R = cfg.R, tpw = cfg.tpw;
+  StreamPlan plan;
+  if (stream_plan(d, cfg.wmax, &plan) != LSI_OK) return LSI_EINVAL;
+  const int R = plan.R, nw = plan.nw;
   const int threads = nw * 64;
-  const size_t lds = stream_lds_bytes(d, R + cfg.exchange, nw, cfg.wmax, tpw);
+  const size_t lds = plan.lds;
   if (lds > 160 * 1024) return LSI_EINVAL;
-  cfg.cap = stream_cap(nw, tpw);
+  cfg.R = R;
+  cfg.exchange = plan.xch;
+  cfg.cap = plan.cap;
+  cfg.ngrp = plan.ngrp;
+  cfg.lpg = plan.lpg;
+  cfg.qcap = plan.qcap;
   cfg.nb = NB;
-  cfg.steps_per_chunk = cfg.cap / (nw * tpw);
   cfg.inv_nb = 1.0f / (float)NB;
-  cfg.inv_nwin = 1.0f / (float)(nw * tpw);
   cfg.inv_gx = 1.0f / (float)((d->Ht + R - 1) / R);
+  {
+    const int nseg = (d->W + SEG - 1) / SEG;
+    cfg.inv_per_row = 1.0f / (float)(nseg * plan.ngrp);
+    cfg.inv_ngrp = 1.0f / (float)plan.ngrp;
+    cfg.inv_nseg = 1.0f / (float)nseg;
+  }
   // boundary-row exchange area
   const XLayout x = stream_exchange_layout(d, R);
   if (!a.canvas && (cfg.exchange || (d->reserved & 4))) return LSI_ENULL;
@@ -1158,7 +1635,7 @@ int lsi_stream_launch(const SplatArgs& a, hipStream_t stream) {
   cfg.tstamps = nullptr;
   if (d->reserved & 4) {  // phase probe: stamps after the regular workspace
     const size_t off = (lsi_splat_workspace_bytes(d) + 255) / 256 * 256;
-    if (a.ws_bytes < off + (size_t)x.nbands * d->B * 32 * 8) return LSI_EWORKSPACE;
+    if (a.ws_bytes < off + (size_t)x.nbands * d->B * 160 * 8) return LSI_EWORKSPACE;
     cfg.tstamps = reinterpret_cast<long long*>(
         reinterpret_cast<char*>(a.canvas) + off);
   }

@@ -12,12 +12,13 @@ import torch
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # LSI_HIP_LIB=hooks selects the instrumented build (build.py --hooks) whose
 # stream kernel honours the timing-experiment bits of LsiSplatDesc.reserved
-SO_PATH = os.path.join(_PKG, 'liblsi_hip_hooks.so' if
-                       os.environ.get('LSI_HIP_LIB') == 'hooks' else
-                       'liblsi_hip.so')
+# (any other value picks liblsi_hip_<value>.so: experiment builds)
+SO_PATH = os.path.join(_PKG, 'liblsi_hip_%s.so' % os.environ['LSI_HIP_LIB'] if
+                       os.environ.get('LSI_HIP_LIB') else 'liblsi_hip.so')
 
 LSI_OK = 0
 LSI_COMPOSE, LSI_WANT_DISP, LSI_HAS_MASK, LSI_WS_KEEP = 1, 2, 4, 8
+LSI_DETERMINISTIC = 16
 LSI_PATH_AUTO, LSI_PATH_ATOMIC, LSI_PATH_ROWBAND, LSI_PATH_STREAM = 0, 1, 2, 3
 LSI_PATH_TILE = 4
 PATH_NAMES = {1: 'atomic', 2: 'rowband', 3: 'stream', 4: 'tile'}

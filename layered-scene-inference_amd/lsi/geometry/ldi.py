@@ -134,6 +134,8 @@ class _ForwardSplat(torch.autograd.Function):
       flags |= _C.LSI_WANT_DISP
     if mask is not None:
       flags |= _C.LSI_HAS_MASK
+    if cfg.get('deterministic'):
+      flags |= _C.LSI_DETERMINISTIC
     bg_wt = _C.bg_weight(cfg['bg_layer_disp'], cfg['max_disp'],
                          cfg['zbuf_scale'])
     desc = _desc(tex, mask, disp, ht, wt, float(s), float(cfg['max_disp']),
@@ -198,13 +200,15 @@ def forward_splat_matrix(ldi_src, src2trg_mat, compose_layers=True,
                          compute_trg_disp=False, trg_downsampling=1,
                          bg_layer_disp=0, max_disp=1, zbuf_scale=10,
                          mat_host=None, path='auto', band_rows=0, threads=0,
-                         experiment=0):
+                         experiment=0, deterministic=False):
   """forward_splat with the B x 4 x 4 src->trg projection matrix given as data.
 
   `mat_host` (optional CPU copy of the matrices) lets the row-band LDS path be
   selected without a device->host copy; when omitted and `src2trg_mat` is on the
   GPU it is fetched once (one small synchronising copy).  `band_rows`,
   `threads` and `experiment` (LsiSplatDesc.reserved) are tuning/test knobs.
+  `deterministic` (LSI_DETERMINISTIC) asks for bitwise run-to-run reproducible
+  sums on the stream path (fixed merge order; a little slower).
   """
   tex, mask, disp = ldi_src
   if mat_host is None and path not in ('atomic', 'tile'):
@@ -214,7 +218,8 @@ def forward_splat_matrix(ldi_src, src2trg_mat, compose_layers=True,
              compute_trg_disp=bool(compute_trg_disp),
              trg_downsampling=trg_downsampling, bg_layer_disp=bg_layer_disp,
              max_disp=max_disp, zbuf_scale=zbuf_scale, path=path,
-             band_rows=band_rows, threads=threads, experiment=experiment)
+             band_rows=band_rows, threads=threads, experiment=experiment,
+             deterministic=bool(deterministic))
   img, wts, dsp = _ForwardSplat.apply(tex, mask, disp, mat, mat_host, cfg)
   if compute_trg_disp:
     return img, wts, dsp

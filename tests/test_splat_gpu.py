@@ -483,20 +483,28 @@ def test_stream_path_routes(kind, shape, compose, dev, ref_cpu):
     np.testing.assert_allclose(wts.cpu().numpy(), want['wts'], rtol=WTS_RTOL)
 
 
-def test_stream_path_is_run_to_run_stable(dev):
-  """Only the rare exact-slow-path corners use fp32 atomics: runs agree to the
-  last few ulps (the atomic paths only agree to summation-order noise)."""
+@pytest.mark.parametrize('kind', ['smooth', 'iid'])
+def test_stream_path_is_run_to_run_stable(kind, dev):
+  """Default mode: windows are merged into the tile in arrival order, so runs
+  agree to summation-order noise of a handful of terms.  LSI_DETERMINISTIC:
+  merges in ticket order -- runs are bitwise identical."""
   from lsi.geometry import ldi
   rs = np.random.RandomState(21)
-  tex, disp, mat = _stream_case(rs, 2, 2, 128, 512, 'smooth')
+  tex, disp, mat = _stream_case(rs, 2, 2, 128, 512, kind)
   ldi_src = [torch.tensor(tex, device=dev), None, torch.tensor(disp, device=dev)]
-  outs = [ldi.forward_splat_matrix(ldi_src, torch.tensor(mat),
-                                   trg_downsampling=0.5, bg_layer_disp=1e-3,
-                                   max_disp=0.4, zbuf_scale=50, path='stream')
-          for _ in range(3)]
+  def run(det):
+    return ldi.forward_splat_matrix(ldi_src, torch.tensor(mat),
+                                    trg_downsampling=0.5, bg_layer_disp=1e-3,
+                                    max_disp=0.4, zbuf_scale=50, path='stream',
+                                    deterministic=det)
+  outs = [run(False) for _ in range(3)]
   for img, wts in outs[1:]:
     assert float((img - outs[0][0]).abs().max()) <= 1e-6
     torch.testing.assert_close(wts, outs[0][1], rtol=1e-6, atol=0)
+  dets = [run(True) for _ in range(4)]
+  for img, wts in dets[1:]:
+    assert torch.equal(img, dets[0][0]) and torch.equal(wts, dets[0][1])
+  torch.testing.assert_close(dets[0][0], outs[0][0], rtol=0, atol=1e-6)
 
 
 def test_stream_path_rejects_what_it_cannot_render(dev):
@@ -721,8 +729,9 @@ def test_stream_path_under_hostile_row_uniform_projections(seed, dev, ref_cpu):
   probe = ldi._desc(torch.empty((nl, b, h, w, 3), device='meta'), None,
                     torch.empty((nl, b, h, w, 1), device='meta'), h // 2, w // 2,
                     s, 0.4, 50.0, 0.0, 0, 0)
+  mat_t = torch.tensor(mat)  # (kept alive while its pointer is in use)
   ok = _C.lib().lsi_stream_ok(ctypes.byref(probe),
-                              ctypes.c_void_p(torch.tensor(mat).data_ptr()))
+                              ctypes.c_void_p(mat_t.data_ptr()))
   assert ok, 'the generator must produce matrices the stream path accepts'
   for compose in (True, False):
     want = ref_cpu.forward_splat(tex, mask, disp, mat, s, 1e-3, 0.4, 50, compose)
@@ -742,9 +751,10 @@ def test_stream_path_under_hostile_row_uniform_projections(seed, dev, ref_cpu):
 @pytest.mark.parametrize('mode', [1, 2])
 @pytest.mark.parametrize('compose', [True, False])
 def test_stream_task_table_is_refilled_in_chunks(compose, mode, dev, ref_cpu):
-  """8-row bands at trg_downsampling 0.25 over 2304-pixel rows: 32 source rows
-  x 9 segments = 288 tasks per band, more than the 256-entry task table -- the
-  table is refilled mid-band, and again at the start of every later pass."""
+  """8-row bands at trg_downsampling 0.25 over 2304-pixel rows: 36 source rows
+  x 9 segments (x layer groups) tasks per band against a task table held to
+  64 entries (experiments field, bits 20+) -- the table is refilled mid-band,
+  and again at the start of every later pass."""
   from lsi.geometry import ldi
   rs = np.random.RandomState(77)
   nl, b, h, w = 2, 1, 96, 2304
@@ -756,7 +766,7 @@ def test_stream_task_table_is_refilled_in_chunks(compose, mode, dev, ref_cpu):
   img, wts = ldi.forward_splat_matrix(
       ldi_src, torch.tensor(mat), compose_layers=compose, trg_downsampling=s,
       bg_layer_disp=1e-3, max_disp=0.4, zbuf_scale=50, path='stream',
-      band_rows=8, experiment=mode << 16)
+      band_rows=8, experiment=(mode << 16) | (4 << 20))
   np.testing.assert_allclose(wts.cpu().numpy(), want['wts'], rtol=WTS_RTOL)
   np.testing.assert_allclose(img.cpu().numpy(), want['img'], rtol=0,
                              atol=IMG_ATOL)
