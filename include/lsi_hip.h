@@ -237,6 +237,99 @@ int lsi_bilinear_bwd(int32_t B, int32_t Hs, int32_t Ws, int32_t C, int32_t Ht,
                      const float* g_out, float* g_imgs, float* g_coords,
                      lsi_stream_t stream);
 
+/* ------------------------------------------------------------------------ */
+/* Losses on LDIs / rendered views and layer composition: one fused pass     */
+/* each (csrc/lsi_loss.hip).  Scalars are DEVICE floats (no host sync);      */
+/* gradients come out contiguous in the inputs' logical shape.               */
+/* ------------------------------------------------------------------------ */
+
+/* Inputs of zbuffer_composition_loss (lsi/loss/loss.py:66-115), element     */
+/* strides: imgs [l,b,y,x,c] c in 0..2, masks/disps [l,b,y,x], trg [b,y,x,c] */
+typedef struct LsiLossDesc {
+  int32_t L, B, H, W;
+  int64_t img_sl, img_sb, img_sy, img_sx, img_sc;
+  int64_t mask_sl, mask_sb, mask_sy, mask_sx;
+  int64_t disp_sl, disp_sb, disp_sy, disp_sx;
+  int64_t trg_sb, trg_sy, trg_sx, trg_sc;
+  float bg_layer_disp, max_disp, zbuf_scale;
+  int32_t reserved;
+} LsiLossDesc;
+
+/* Bytes of device scratch every *_loss_fwd needs (partial sums). */
+size_t lsi_loss_workspace_bytes(void);
+
+/*
+ * loss.zbuffer_composition_loss, lsi/loss/loss.py:66-115: white background
+ * layer at bg_layer_disp appended; p_l = zbuffer_weights(d_l/max_disp)*m_l
+ * normalised over the layers; 0.5 * mean(sum_l (img_l - trg)^2 * p_l).
+ * masks may be NULL (ones).  out_loss: one device float.
+ */
+int lsi_zbuf_comp_loss_fwd(const LsiLossDesc* desc, const float* imgs,
+                           const float* masks, const float* disps,
+                           const float* trg, float* out_loss, void* workspace,
+                           size_t workspace_bytes, lsi_stream_t stream);
+/* Gradients w.r.t. imgs [L,B,H,W,3], masks [L,B,H,W] (NULL when masks is) and
+ * disps [L,B,H,W], scaled by the device scalar g_loss. */
+int lsi_zbuf_comp_loss_bwd(const LsiLossDesc* desc, const float* imgs,
+                           const float* masks, const float* disps,
+                           const float* trg, const float* g_loss, float* g_imgs,
+                           float* g_masks, float* g_disps, lsi_stream_t stream);
+
+/*
+ * The two regularisers of the disparities in one read of disp [l,b,y,x]:
+ *   out2[0] = ldi.disp_smoothness_loss  (lsi/geometry/ldi.py:33-68): mean |d_xx|
+ *             + mean |d_xy| + mean |d_yx| + mean |d_yy| of forward differences
+ *   out2[1] = loss.decreasing_disp_loss (lsi/loss/loss.py:48-63): mean relu(
+ *             d_{l+1} - stop_gradient(d_l)); 0 when L == 1
+ */
+int lsi_disp_reg_loss_fwd(int32_t L, int32_t B, int32_t H, int32_t W,
+                          int64_t sl, int64_t sb, int64_t sy, int64_t sx,
+                          const float* disp, float* out2, void* workspace,
+                          size_t workspace_bytes, lsi_stream_t stream);
+/* g_disp [L,B,H,W] = g2[0] * d out2[0]/d disp + g2[1] * d out2[1]/d disp. */
+int lsi_disp_reg_loss_bwd(int32_t L, int32_t B, int32_t H, int32_t W,
+                          int64_t sl, int64_t sb, int64_t sy, int64_t sx,
+                          const float* disp, const float* g2, float* g_disp,
+                          lsi_stream_t stream);
+
+/*
+ * View-synthesis loss of the training script, ldi_enc_dec.py:337-357: AREA
+ * resize of target [B,H,W,3] (element strides) to Ht x Wt (integer factors),
+ * mean_c |t - r_l|, min over the nl layers of recons [nl,B,Ht,Wt,3]
+ * (contiguous), crop x_min / y_min pixels on every side, mean.
+ */
+int lsi_view_synth_loss_fwd(int32_t nl, int32_t B, int32_t Ht, int32_t Wt,
+                            int32_t H, int32_t W, int32_t x_min, int32_t y_min,
+                            const float* recons, const float* target,
+                            int64_t t_sb, int64_t t_sy, int64_t t_sx,
+                            int64_t t_sc, float* out_loss, void* workspace,
+                            size_t workspace_bytes, lsi_stream_t stream);
+/* g_recons [nl,B,Ht,Wt,3]; reduce_min's gradient is split among tied layers. */
+int lsi_view_synth_loss_bwd(int32_t nl, int32_t B, int32_t Ht, int32_t Wt,
+                            int32_t H, int32_t W, int32_t x_min, int32_t y_min,
+                            const float* recons, const float* target,
+                            int64_t t_sb, int64_t t_sy, int64_t t_sx,
+                            int64_t t_sc, const float* g_loss, float* g_recons,
+                            lsi_stream_t stream);
+
+/*
+ * layers.compose, lsi/geometry/layers.py:29-70 with helpers.soft_z_buffering
+ * (lsi/nnutils/helpers.py:140-160): white background layer at min_disp,
+ * per-pixel softmax of log(mask + 1e-8) - depth / temp over the L + 1 layers,
+ * hard (first arg-max of the probabilities) or soft blend.
+ * imgs [L,N,C], masks [L,N], dmaps [L,N], out [N,C]; all contiguous.
+ */
+int lsi_compose_fwd(int32_t L, int64_t N, int32_t C, const float* imgs,
+                    const float* masks, const float* dmaps, int32_t soft,
+                    float min_disp, float depth_softmax_temp, float* out,
+                    lsi_stream_t stream);
+/* layers.compose_depth, layers.py:73-115.  dmax = max(relu(dmaps), min_disp)
+ * over the whole tensor (used when bg_layer != 0).  out [N]. */
+int lsi_compose_depth_fwd(int32_t L, int64_t N, const float* masks,
+                          const float* dmaps, int32_t bg_layer, float dmax,
+                          float min_disp, float depth_softmax_temp, float* out,
+                          lsi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

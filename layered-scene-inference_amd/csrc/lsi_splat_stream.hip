@@ -158,6 +158,15 @@ __device__ __forceinline__ float4 load_coherent(const float4* p) {
                      __uint_as_float((unsigned)(hi >> 32)));
 }
 
+// t + v*w on all four channels as two packed FMAs (v_pk_fma_f32)
+__device__ __forceinline__ float4 f4_pkfma(float4 t, float4 v, float w) {
+  f2 lo = {t.x, t.y}, hi = {t.z, t.w};
+  const f2 vlo = {v.x, v.y}, vhi = {v.z, v.w}, ww = {w, w};
+  lo = __builtin_elementwise_fma(vlo, ww, lo);
+  hi = __builtin_elementwise_fma(vhi, ww, hi);
+  return make_float4(lo.x, lo.y, hi.x, hi.y);
+}
+
 // accumulations are not index-critical: fused multiply-add
 __device__ __forceinline__ float4 f4_fma(float4 t, float4 v, float w) {
   t.x = __fmaf_rn(v.x, w, t.x); t.y = __fmaf_rn(v.y, w, t.y);
@@ -1020,7 +1029,7 @@ __global__ __launch_bounds__(LSI_STREAM_MAXT) void splat_stream_kernel(SplatArgs
 #pragma unroll
               for (int k = 0; k < 4; ++k) Vv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-              for (int i = 0; i < 4; ++i) {
+              for (int i = 0; i < ((dbg & 512) ? 0 : 4); ++i) {  // 512: counters only
                 float w0 = w0v[i], w1 = w1v[i];
                 float r, g, b_;
                 tex_of(i, r, g, b_);
@@ -1051,10 +1060,10 @@ __global__ __launch_bounds__(LSI_STREAM_MAXT) void splat_stream_kernel(SplatArgs
                   const float a1 = e1 ? w0 : (e0 ? w1 : 0.0f);
                   const float a2 = e2 ? w0 : (e1 ? w1 : 0.0f);
                   const float a3 = e2 ? w1 : 0.0f;
-                  Vv[0] = f4_fma(Vv[0], V, a0);
-                  Vv[1] = f4_fma(Vv[1], V, a1);
-                  Vv[2] = f4_fma(Vv[2], V, a2);
-                  Vv[3] = f4_fma(Vv[3], V, a3);
+                  Vv[0] = f4_pkfma(Vv[0], V, a0);
+                  Vv[1] = f4_pkfma(Vv[1], V, a1);
+                  Vv[2] = f4_pkfma(Vv[2], V, a2);
+                  Vv[3] = f4_pkfma(Vv[3], V, a3);
                 }
               }
             } else {

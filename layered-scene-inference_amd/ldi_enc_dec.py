@@ -241,10 +241,19 @@ class Trainer(train_utils.Trainer):
           indep_splat_loss = indep_splat_loss + term
 
     # regularisers (ldi_enc_dec.py:388-396)
-    disp_smoothness_loss = (ldi_utils.disp_smoothness_loss(ldi_src[2]) +
-                            ldi_utils.disp_smoothness_loss(ldi_trg[2]))
-    incr_depth_loss = (loss.decreasing_disp_loss(ldi_src[2]) +
-                       loss.decreasing_disp_loss(ldi_trg[2]))
+    if self.device.type == 'cuda':
+      # both regularisers from one read of each disparity tensor (fused HIP
+      # kernel lsi_disp_reg_loss_fwd)
+      from lsi.loss import _hip as loss_hip  # pylint: disable=g-import-not-at-top
+      sm_s, dc_s = loss_hip.disp_regularisers(ldi_src[2])
+      sm_t, dc_t = loss_hip.disp_regularisers(ldi_trg[2])
+      disp_smoothness_loss = sm_s + sm_t
+      incr_depth_loss = (dc_s + dc_t) if opts.n_layers > 1 else zero
+    else:
+      disp_smoothness_loss = (ldi_utils.disp_smoothness_loss(ldi_src[2]) +
+                              ldi_utils.disp_smoothness_loss(ldi_trg[2]))
+      incr_depth_loss = (loss.decreasing_disp_loss(ldi_src[2]) +
+                         loss.decreasing_disp_loss(ldi_trg[2]))
 
     total = zero
     if opts.self_cons_wt > 0:

@@ -41,9 +41,23 @@ class LsiSplatDesc(ctypes.Structure):
        ('tune_window', ctypes.c_int32), ('reserved', ctypes.c_int32)])
 
 
+class LsiLossDesc(ctypes.Structure):
+  _fields_ = (
+      [(n, ctypes.c_int32) for n in ('L', 'B', 'H', 'W')] +
+      [(n, ctypes.c_int64) for n in (
+          'img_sl', 'img_sb', 'img_sy', 'img_sx', 'img_sc',
+          'mask_sl', 'mask_sb', 'mask_sy', 'mask_sx',
+          'disp_sl', 'disp_sb', 'disp_sy', 'disp_sx',
+          'trg_sb', 'trg_sy', 'trg_sx', 'trg_sc')] +
+      [(n, ctypes.c_float) for n in ('bg_layer_disp', 'max_disp', 'zbuf_scale')] +
+      [('reserved', ctypes.c_int32)])
+
+
 # name -> (restype, argtypes); every symbol include/lsi_hip.h declares.
 _I32, _I64, _VP, _SZ = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p, ctypes.c_size_t
 _DP = ctypes.POINTER(LsiSplatDesc)
+_LP = ctypes.POINTER(LsiLossDesc)
+_F32 = ctypes.c_float
 SIGNATURES = {
     'lsi_version': (ctypes.c_int, []),
     'lsi_strerror': (ctypes.c_char_p, [ctypes.c_int]),
@@ -60,6 +74,20 @@ SIGNATURES = {
     'lsi_scatter_add': (ctypes.c_int, [_I32, _I64, _I64] + [_VP] * 4),
     'lsi_bilinear_fwd': (ctypes.c_int, [_I32] * 6 + [_VP] * 4),
     'lsi_bilinear_bwd': (ctypes.c_int, [_I32] * 6 + [_VP] * 6),
+    'lsi_loss_workspace_bytes': (_SZ, []),
+    'lsi_zbuf_comp_loss_fwd': (ctypes.c_int, [_LP] + [_VP] * 6 + [_SZ, _VP]),
+    'lsi_zbuf_comp_loss_bwd': (ctypes.c_int, [_LP] + [_VP] * 9),
+    'lsi_disp_reg_loss_fwd': (ctypes.c_int, [_I32] * 4 + [_I64] * 4 + [_VP] * 3 +
+                              [_SZ, _VP]),
+    'lsi_disp_reg_loss_bwd': (ctypes.c_int, [_I32] * 4 + [_I64] * 4 + [_VP] * 4),
+    'lsi_view_synth_loss_fwd': (ctypes.c_int, [_I32] * 8 + [_VP] * 2 + [_I64] * 4 +
+                                [_VP] * 2 + [_SZ, _VP]),
+    'lsi_view_synth_loss_bwd': (ctypes.c_int, [_I32] * 8 + [_VP] * 2 + [_I64] * 4 +
+                                [_VP] * 3),
+    'lsi_compose_fwd': (ctypes.c_int, [_I32, _I64, _I32] + [_VP] * 3 +
+                        [_I32, _F32, _F32, _VP, _VP]),
+    'lsi_compose_depth_fwd': (ctypes.c_int, [_I32, _I64] + [_VP] * 2 +
+                              [_I32, _F32, _F32, _F32, _VP, _VP]),
 }
 
 _lib = None

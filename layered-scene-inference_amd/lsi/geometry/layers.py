@@ -16,7 +16,11 @@ def compose(imgs, masks, dmaps, soft=False, min_disp=1e-6,
             depth_softmax_temp=1):
   """Composes layer images into one image with a white background layer at
   min_disp (reference layers.py:29-70).  imgs: L x [...] x C, masks/dmaps:
-  L x [...] x 1.  Returns [...] x C."""
+  L x [...] x 1.  Returns [...] x C.  On a ROCm device: one HIP pass
+  (lsi_compose_fwd, forward only)."""
+  if imgs.is_cuda:
+    from lsi.loss import _hip  # pylint: disable=g-import-not-at-top
+    return _hip.compose(imgs, masks, dmaps, soft, min_disp, depth_softmax_temp)
   n_layers = imgs.shape[0]
   dmaps = torch.relu(dmaps)
   imgs = torch.cat([imgs, torch.ones_like(imgs[:1])], 0)
@@ -31,7 +35,12 @@ def compose(imgs, masks, dmaps, soft=False, min_disp=1e-6,
 
 def compose_depth(masks, dmaps, bg_layer=False, min_disp=1e-6,
                   depth_softmax_temp=1):
-  """Composes layer disparities into one map (reference layers.py:73-115)."""
+  """Composes layer disparities into one map (reference layers.py:73-115).  On
+  a ROCm device: lsi_compose_depth_fwd."""
+  if masks.is_cuda:
+    from lsi.loss import _hip  # pylint: disable=g-import-not-at-top
+    return _hip.compose_depth(masks, dmaps, bg_layer, min_disp,
+                              depth_softmax_temp)
   n_layers = masks.shape[0]
   dmaps = torch.relu(dmaps)
   bg_disp = torch.ones_like(dmaps[:1]) * min_disp

@@ -24,7 +24,11 @@ def gradient(pred):
 
 
 def disp_smoothness_loss(pred_disp):
-  """Mean absolute second differences (reference ldi.py:47-68)."""
+  """Mean absolute second differences (reference ldi.py:47-68).  On a ROCm
+  device: the fused HIP kernel (lsi_disp_reg_loss_fwd)."""
+  if pred_disp.is_cuda:
+    from lsi.loss import _hip  # pylint: disable=g-import-not-at-top
+    return _hip.disp_regularisers(pred_disp)[0]
   dx, dy = gradient(pred_disp)
   dx2, dxdy = gradient(dx)
   dydx, dy2 = gradient(dy)

@@ -4,15 +4,9 @@ import torch
 from lsi.nnutils import helpers as nn_helpers
 
 
-def _seq_matmul(a, b):
-  """Small-matrix product accumulated sequentially over k with separately
-  rounded multiply and add -- the evaluation order pinned by the parity oracle
-  (oracle/lsi_oracle.py: matmul_seq), so that a projection matrix computed here
-  is bit-identical to the oracle's."""
-  out = a[..., :, 0:1] * b[..., 0:1, :]
-  for k in range(1, a.shape[-1]):
-    out = out + a[..., :, k:k + 1] * b[..., k:k + 1, :]
-  return out
+# Small-matrix product in the order pinned by the parity oracle: a projection
+# matrix computed here is bit-identical to the oracle's.
+_seq_matmul = nn_helpers.seq_matmul
 
 
 def _inv3(k_mat):

@@ -21,10 +21,15 @@ def event_prob(layer_masks):
 
 def decreasing_disp_loss(layer_disps):
   """Penalises disparities that increase from one layer to the next, with the
-  nearer layer detached (reference loss.py:48-63)."""
+  nearer layer detached (reference loss.py:48-63).  On a ROCm device: the fused
+  HIP kernel (lsi_disp_reg_loss_fwd); CPU tensors: the same arithmetic in
+  torch ops (host logic, checked against the goldens)."""
   n_layers = layer_disps.shape[0]
   if n_layers == 1:
     return 0
+  if layer_disps.is_cuda:
+    from lsi.loss import _hip  # pylint: disable=g-import-not-at-top
+    return _hip.disp_regularisers(layer_disps)[1]
   disps_pre = layer_disps[0:n_layers - 1].detach()
   disps_post = layer_disps[1:n_layers]
   return torch.relu(disps_post - disps_pre).mean()
@@ -33,7 +38,13 @@ def decreasing_disp_loss(layer_disps):
 def zbuffer_composition_loss(layer_imgs, layer_masks, layer_disps, trg_imgs,
                              bg_layer_disp=0, max_disp=1, zbuf_scale=10):
   """Depth+mask weighted self-consistency loss with a white background layer
-  (reference loss.py:66-115)."""
+  (reference loss.py:66-115).  On a ROCm device: one fused HIP pass
+  (lsi_zbuf_comp_loss_fwd / _bwd)."""
+  if layer_imgs.is_cuda:
+    from lsi.loss import _hip  # pylint: disable=g-import-not-at-top
+    return _hip.zbuffer_composition_loss(layer_imgs, layer_masks, layer_disps,
+                                         trg_imgs, bg_layer_disp, max_disp,
+                                         zbuf_scale)
   layer_imgs = torch.cat([layer_imgs, torch.ones_like(layer_imgs[:1])], 0)
   layer_masks = torch.cat([layer_masks, torch.ones_like(layer_masks[:1])], 0)
   layer_disps = torch.cat(
@@ -68,6 +79,11 @@ def view_synthesis_loss(recons_splat, to_recons_img, splat_bdry_ignore=0.05):
   (ldi_enc_dec.py:337-357): AREA-downsample the target to the splat's size,
   mean |diff| over channels, min over layers, crop the border, mean."""
   _, _, ht, wt, _ = recons_splat.shape
+  if recons_splat.is_cuda:
+    from lsi.loss import _hip  # pylint: disable=g-import-not-at-top
+    return _hip.view_synthesis_loss(recons_splat, to_recons_img,
+                                    _py2_round(wt * splat_bdry_ignore),
+                                    _py2_round(ht * splat_bdry_ignore))
   tgt = area_downsample(to_recons_img, ht, wt)
   pw = torch.min(torch.mean(torch.abs(tgt.unsqueeze(0) - recons_splat), dim=4),
                  dim=0)[0]

@@ -31,14 +31,27 @@ def pixel_coords(bs, h, w, device=None):
   return grid.unsqueeze(0).expand(bs, h, w, 3).contiguous()
 
 
+def seq_matmul(a, b):
+  """Matrix product accumulated sequentially over k, every multiply and add a
+  separately rounded fp32 elementwise op (no FMA, no blocked BLAS order): the
+  evaluation order the parity oracle pins for TF's small matmuls
+  (oracle/lsi_oracle.py: matmul_seq).  Coordinates, masks and thresholds
+  derived from it are bit-identical to the oracle's."""
+  out = a[..., :, 0:1] * b[..., 0:1, :]
+  for k in range(1, a.shape[-1]):
+    out = out + a[..., :, k:k + 1] * b[..., k:k + 1, :]
+  return out
+
+
 def transform_pts(pts_coords_init, tform_mat):
   """Per-pixel D x D matrix transform, [...] x H x W x D (reference
-  helpers.py:116-137)."""
+  helpers.py:116-137).  The product is the sequential-k one (seq_matmul):
+  the pixel coordinates it yields feed floor / threshold decisions."""
   shape = pts_coords_init.shape
   d = tform_mat.shape[-1]
   lead = tuple(tform_mat.shape[:-2])
   flat = pts_coords_init.reshape(lead + (-1, d))
-  out = torch.matmul(flat, tform_mat.transpose(-1, -2))
+  out = seq_matmul(flat, tform_mat.transpose(-1, -2))
   return out.reshape(shape)
 
 

@@ -333,6 +333,52 @@ def make_losses(mods):
         out['smooth_loss'])
 
 
+def make_view_synthesis():
+  """The view-synthesis loss is inline in the reference's training script
+  (ldi_enc_dec.py:337-351), which cannot be imported (TF1 session program).
+  Its statements are read from the script IN PLACE at generation time and
+  executed on the shim; only inputs and outputs are stored."""
+  import argparse
+  import math
+  import textwrap
+  path = '/root/reference/ldi_enc_dec.py'
+  with open(path, 'r') as f:
+    lines = f.readlines()
+  # from 'to_recons_img_downsampled = ...' through the crop of pwise_splat_loss
+  first = next(i for i, l in enumerate(lines)
+               if 'to_recons_img_downsampled = tf.image.resize_images(' in l)
+  last = next(i for i, l in enumerate(lines)
+              if 'pwise_splat_loss = pwise_splat_loss[:, y_min:y_max, x_min:x_max]' in l)
+  assert 330 <= first < last <= 360, (first, last)
+  code = compile(textwrap.dedent(''.join(lines[first:last + 1])), path, 'exec')
+
+  def py2_round(x):  # python 2: half away from zero, returns a float
+    return math.copysign(math.floor(abs(x) + 0.5), x)
+
+  rs = np.random.RandomState(77)
+  out = {}
+  for tag, nl, b, h, w, s, bdry in (('compose', 1, 2, 16, 24, 0.5, 0.05),
+                                    ('indep', 3, 2, 20, 40, 0.5, 0.05),
+                                    ('full', 2, 1, 12, 20, 1.0, 0.1)):
+    ht, wt = int(h * s), int(w * s)
+    recons = rs.rand(nl, b, ht, wt, 3).astype(np.float32)
+    target = rs.rand(b, h, w, 3).astype(np.float32)
+    if nl > 1:  # exact ties between layers (reduce_min's gradient splits)
+      recons[1, :, :2] = recons[0, :, :2]
+    ns = {'tf': tf, 'to_recons_img': T(target), 'recons_splat': T(recons),
+          'opts': argparse.Namespace(splat_bdry_ignore=bdry),
+          'round': py2_round, 'int': int}
+    exec(code, ns)  # pylint: disable=exec-used
+    pw = ns['pwise_splat_loss']
+    out[tag + '_recons'] = recons
+    out[tag + '_target'] = target
+    out[tag + '_bdry'] = np.float32(bdry)
+    out[tag + '_pwise'] = pw.a
+    out[tag + '_loss'] = tf.reduce_mean(pw).a
+    print('view synthesis', tag, pw.a.shape, float(out[tag + '_loss']))
+  np.savez_compressed(os.path.join(OUT, 'view_synthesis.npz'), **out)
+
+
 def main():
   os.makedirs(OUT, exist_ok=True)
   mods = tf.load_reference()
@@ -342,6 +388,7 @@ def main():
   make_layers(mods)
   make_disocclusion(mods)
   make_losses(mods)
+  make_view_synthesis()
   total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
   print('wrote %d bytes under %s' % (total, OUT))
 

@@ -467,6 +467,34 @@ class _NN(object):
 nn = _NN()
 
 
+class _Image(object):
+  """tf.image: only what the view-synthesis loss uses (ldi_enc_dec.py:337-340):
+  resize_images(..., method=AREA) to an integer fraction of the size, i.e. the
+  exact box mean (TF's resize_area averages the source pixels a target pixel
+  covers; for integer factors every one of them has weight 1)."""
+
+  class ResizeMethod(object):
+    BILINEAR, NEAREST_NEIGHBOR, BICUBIC, AREA = 0, 1, 2, 3
+
+  @staticmethod
+  def resize_images(images, size, method=0, align_corners=False):
+    a = _f(images)
+    ht, wt = [int(v) for v in size]
+    b, h, w, c = a.shape
+    if method != _Image.ResizeMethod.AREA or h % ht or w % wt:
+      raise NotImplementedError('shim: AREA resize by integer factors only')
+    fy, fx = h // ht, w // wt
+    out = a.reshape(b, ht, fy, wt, fx, c).astype(np.float32)
+    acc = np.zeros((b, ht, wt, c), np.float32)
+    for dy in builtins.range(fy):      # rows, then columns, in order
+      for dx in builtins.range(fx):
+        acc = acc + out[:, :, dy, :, dx, :]
+    return Tensor((acc * np.float32(1.0 / (fy * fx))).astype(np.float32))
+
+
+image = _Image()
+
+
 def install():
   """Registers this module as `tensorflow` plus an `absl.logging` stub."""
   me = sys.modules[__name__]

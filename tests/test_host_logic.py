@@ -2,7 +2,10 @@
 the reference-generated goldens, on CPU tensors.  The HIP-backed ops
 (forward_splat, splat, bilinear, scatter_add) are covered by the -m gpu tests."""
 import numpy as np
+import pytest
 import torch
+
+import lsi_oracle as O
 
 from conftest import golden
 from lsi.geometry import homography, layers, ldi, projection
@@ -123,3 +126,26 @@ def test_bilinear_taps_variant_on_cpu():
                              atol=0)
   np.testing.assert_allclose(torch.stack(wts).numpy(), g['taps_wts'], rtol=1e-6,
                              atol=1e-7)
+
+
+@pytest.mark.parametrize('tag', ['compose', 'indep', 'full'])
+def test_view_synthesis_loss_matches_the_reference_script_lines(tag):
+  """tests/golden/view_synthesis.npz holds the output of the reference's own
+  statements (ldi_enc_dec.py:337-351, executed in place by
+  oracle/make_goldens.py): AREA resize, L1, mean over channels, min over
+  layers, py2-rounded border crop.  Both the oracle's restatement and the
+  torch mirror (CPU tensors) must reproduce it."""
+  import torch
+  from lsi.loss import loss
+  g = golden('view_synthesis.npz')
+  recons, target = g[tag + '_recons'], g[tag + '_target']
+  bdry = float(g[tag + '_bdry'])
+  want = float(g[tag + '_loss'])
+  got_oracle = float(O.view_synthesis_loss(recons, target, bdry))
+  assert abs(got_oracle - want) <= 1e-6 * abs(want)
+  got = float(loss.view_synthesis_loss(torch.tensor(recons), torch.tensor(target),
+                                       bdry))
+  assert abs(got - want) <= 1e-6 * abs(want)
+  assert g[tag + '_pwise'].shape[1:] == (
+      recons.shape[2] - 2 * loss._py2_round(recons.shape[2] * bdry),
+      recons.shape[3] - 2 * loss._py2_round(recons.shape[3] * bdry))
