@@ -185,6 +185,37 @@ int lsi_splat_bwd(const LsiSplatDesc* desc, const float* tex, const float* disp,
                   void* workspace, size_t workspace_bytes, lsi_stream_t stream);
 
 /*
+ * forward_splat's two variants of one source view in ONE sweep: the reference's
+ * training step renders every LDI twice, once per layer (compose_layers=False)
+ * and once composed (compose_layers=True), ldi_enc_dec.py:302-334, repeating
+ * identical per-layer splats (ldi.py:129-155).  desc->flags must not contain
+ * LSI_COMPOSE or LSI_WANT_DISP.  Outputs: out_img / out_wts [L,B,Ht,Wt,3|1]
+ * (per layer) and out_img_c / out_wts_c [1,B,Ht,Wt,3|1] (composed).  The STREAM
+ * path sums the layers' tiles in LDS; the other paths render per layer and
+ * derive the composed view from those outputs.  Workspace as lsi_splat_fwd.
+ */
+int lsi_splat_fwd_both(const LsiSplatDesc* desc, const float* tex,
+                       const float* disp, const float* mask, const float* M,
+                       float* out_img, float* out_wts, float* out_img_c,
+                       float* out_wts_c, void* workspace,
+                       size_t workspace_bytes, lsi_stream_t stream);
+
+/*
+ * Gradient of lsi_splat_fwd_both: the per-layer canvases receive the gradients
+ * of both outputs (g_img / g_wts for the per-layer ones, g_img_c / g_wts_c for
+ * the composed one; either pair may be NULL).  One gather pass over the source
+ * pixels.  Workspace: lsi_splat_bwd_workspace_bytes(desc).
+ */
+int lsi_splat_bwd_both(const LsiSplatDesc* desc, const float* tex,
+                       const float* disp, const float* mask, const float* M,
+                       const float* out_img, const float* out_wts,
+                       const float* out_img_c, const float* out_wts_c,
+                       const float* g_img, const float* g_wts,
+                       const float* g_img_c, const float* g_wts_c, float* g_tex,
+                       float* g_disp_in, float* g_mask, void* workspace,
+                       size_t workspace_bytes, lsi_stream_t stream);
+
+/*
  * Parity/debug view of the projection stage: for every source pixel the four
  * flat target indices (tl,tr,bl,br; x + y*Wt within the batch element,
  * sampling.py:234-241) and the four updates of the weight splat,

@@ -2,7 +2,8 @@
 // weight + 4-corner bilinear splat + normalise/compose, ldi.py:71-182 with
 // sampling.py:171-254 and helpers.py:82-85,116-137,180-193 fused in.
 //
-// Two kernel families behind lsi_splat_fwd (include/lsi_hip.h):
+// Two of the four kernel families behind lsi_splat_fwd (include/lsi_hip.h; the
+// others: lsi_splat_stream.hip, lsi_splat_tile.hip):
 //
 //  LSI_PATH_ATOMIC   any projection matrix.  One thread per source pixel,
 //                    fp32 global atomics (global_atomic_add_f32) into
@@ -68,10 +69,18 @@ __global__ __launch_bounds__(256) void splat_atomic_kernel(SplatArgs a) {
   ch[0] = tp[0] * pw; ch[1] = tp[d.tex_sc] * pw; ch[2] = tp[2 * d.tex_sc] * pw;
   ch[3] = pw; ch[4] = active ? p.dd * pw : 0.0f;  // (dd may be NaN when dropped)
   const int nch = a.nch;
-  // partner = the other lane of the pair (2m, 2m+1): quad_perm [1,0,3,2]
-  const int key = active ? (p.idx[0] ^ (p.idx[3] << 12)) : -1 - (int)threadIdx.x;
-  const int pkey = __builtin_amdgcn_update_dpp(0, key, 0xB1, 0xf, 0xf, true);
-  const bool same = (key == pkey);        // both active, same four cells
+  // partner = the other lane of the pair (2m, 2m+1): quad_perm [1,0,3,2].
+  // The pair is merged only when all four cells agree: tl and br are compared
+  // exactly (two exchanges; tr and bl follow from them for valid footprints:
+  // both lanes' cells are the clipped corners of the same two columns / rows).
+  const int k0 = active ? p.idx[0] : -1 - (int)threadIdx.x;
+  const int k3 = active ? p.idx[3] : -1 - (int)threadIdx.x;
+  const int pk0 = __builtin_amdgcn_update_dpp(0, k0, 0xB1, 0xf, 0xf, true);
+  const int pk3 = __builtin_amdgcn_update_dpp(0, k3, 0xB1, 0xf, 0xf, true);
+  const int k1 = active ? p.idx[1] : -1, k2 = active ? p.idx[2] : -1;
+  const int pk1 = __builtin_amdgcn_update_dpp(0, k1, 0xB1, 0xf, 0xf, true);
+  const int pk2 = __builtin_amdgcn_update_dpp(0, k2, 0xB1, 0xf, 0xf, true);
+  const bool same = (k0 == pk0) && (k3 == pk3) && (k1 == pk1) && (k2 == pk2);
   const bool odd = threadIdx.x & 1;
   const size_t P = (size_t)d.Ht * d.Wt;
   const int lc = a.shared ? 0 : l;
@@ -435,6 +444,61 @@ __global__ __launch_bounds__(256) void splat_bwd_kernel(
   g_disp[o] = gd;
 }
 
+// Pre-pass of lsi_splat_bwd_both: layer l's canvas receives the gradient of
+// its own (independent) output plus the composed output's, whose canvas is the
+// sum of the layers' canvases (ldi.py:167-171).
+__global__ __launch_bounds__(256) void splat_bwd_pre_both_kernel(
+    size_t n1, int L, const float* __restrict__ img_i,
+    const float* __restrict__ wts_i, const float* __restrict__ img_c,
+    const float* __restrict__ wts_c, const float* __restrict__ g_img_i,
+    const float* __restrict__ g_wts_i, const float* __restrict__ g_img_c,
+    const float* __restrict__ g_wts_c, float4* __restrict__ G) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;  // (b, pixel)
+  if (i >= n1) return;
+  float4 gc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (g_img_c) {
+    const float inv = 1.0f / safe_den(wts_c[i]);
+    const float g0 = g_img_c[3 * i], g1 = g_img_c[3 * i + 1], g2 = g_img_c[3 * i + 2];
+    float gw = g_wts_c ? g_wts_c[i] : 0.0f;
+    gw -= (g0 * img_c[3 * i] + g1 * img_c[3 * i + 1] + g2 * img_c[3 * i + 2]) * inv;
+    gc = make_float4(g0 * inv, g1 * inv, g2 * inv, gw);
+  }
+  for (int l = 0; l < L; ++l) {
+    const size_t j = (size_t)l * n1 + i;
+    float4 g = gc;
+    if (g_img_i) {
+      const float inv = 1.0f / safe_den(wts_i[j]);
+      const float g0 = g_img_i[3 * j], g1 = g_img_i[3 * j + 1], g2 = g_img_i[3 * j + 2];
+      float gw = g_wts_i ? g_wts_i[j] : 0.0f;
+      gw -= (g0 * img_i[3 * j] + g1 * img_i[3 * j + 1] + g2 * img_i[3 * j + 2]) * inv;
+      g.x += g0 * inv; g.y += g1 * inv; g.z += g2 * inv; g.w += gw;
+    }
+    G[j] = g;
+  }
+}
+
+// Composed outputs from the per-layer ones, for the kernel families that do
+// not produce both in one sweep: canvas_l = img_l * W'_l (the normalisation
+// undone; one rounding more than the fused sum), ldi.py:167-174.
+__global__ __launch_bounds__(256) void compose_from_layers_kernel(
+    size_t n1, int L, const float* __restrict__ img_i,
+    const float* __restrict__ wts_i, float* __restrict__ img_c,
+    float* __restrict__ wts_c) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n1) return;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, w = 0.f;
+  for (int l = 0; l < L; ++l) {
+    const size_t j = (size_t)l * n1 + i;
+    const float wl = wts_i[j], wd = safe_den(wl);
+    a0 += img_i[3 * j] * wd; a1 += img_i[3 * j + 1] * wd; a2 += img_i[3 * j + 2] * wd;
+    w += wl;
+  }
+  const float wd = safe_den(w);
+  img_c[3 * i] = div_rn(a0, wd); img_c[3 * i + 1] = div_rn(a1, wd);
+  img_c[3 * i + 2] = div_rn(a2, wd);
+  wts_c[i] = w;
+}
+
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
@@ -540,6 +604,7 @@ int lsi_splat_fwd(const LsiSplatDesc* d, const float* tex, const float* disp,
   a.ncanv = canvas_count(d);
   a.shared = (d->flags & LSI_COMPOSE) && !(d->flags & LSI_WANT_DISP);
   a.band_rows = 0;
+  a.out_img_c = a.out_wts_c = nullptr;
 
   int path = d->path;
   // AUTO without a host copy of M: the any-pose tile path (callers that have
@@ -601,6 +666,7 @@ int lsi_project_indices(const LsiSplatDesc* d, const float* disp,
   a.out_img = a.out_wts = a.out_disp = a.canvas = nullptr;
   a.ws_bytes = 0;
   a.nch = 4; a.ncanv = 1; a.shared = 0; a.band_rows = 0;
+  a.out_img_c = a.out_wts_c = nullptr;
   const int npx = d->H * d->W;
   hipLaunchKernelGGL(project_indices_kernel,
                      dim3((npx + 255) / 256, d->B, d->L), dim3(256), 0,
@@ -639,6 +705,77 @@ int lsi_splat_bwd(const LsiSplatDesc* d, const float* tex, const float* disp,
   a.out_img = a.out_wts = a.out_disp = a.canvas = nullptr;
   a.ws_bytes = 0;
   a.nch = 4; a.ncanv = 1; a.shared = 0; a.band_rows = 0;
+  a.out_img_c = a.out_wts_c = nullptr;
+  const int npx = d->H * d->W;
+  hipLaunchKernelGGL(splat_bwd_kernel, dim3((npx + 255) / 256, d->B, d->L),
+                     dim3(256), 0, stream, a, (const float4*)workspace, g_tex,
+                     g_disp_in, (d->flags & LSI_HAS_MASK) ? g_mask : nullptr);
+  return hipGetLastError() == hipSuccess ? LSI_OK : LSI_ELAUNCH;
+}
+
+int lsi_splat_fwd_both(const LsiSplatDesc* d, const float* tex,
+                       const float* disp, const float* mask, const float* M,
+                       float* out_img, float* out_wts, float* out_img_c,
+                       float* out_wts_c, void* workspace,
+                       size_t workspace_bytes, lsi_stream_t stream_) {
+  int rc = check_desc(d);
+  if (rc != LSI_OK) return rc;
+  if (d->flags & (LSI_COMPOSE | LSI_WANT_DISP)) return LSI_EINVAL;
+  if (!out_img_c || !out_wts_c || !out_img || !out_wts) return LSI_ENULL;
+  hipStream_t stream = (hipStream_t)stream_;
+  if (d->path == LSI_PATH_STREAM) {
+    // one sweep: every layer's tile is written out and added to a second tile
+    if (!tex || !disp || !M) return LSI_ENULL;
+    if ((d->flags & LSI_HAS_MASK) && !mask) return LSI_ENULL;
+    SplatArgs a;
+    a.d = *d;
+    a.tex = tex; a.disp = disp; a.mask = mask; a.M = M;
+    a.out_img = out_img; a.out_wts = out_wts; a.out_disp = nullptr;
+    a.canvas = (float*)workspace; a.ws_bytes = workspace_bytes;
+    a.nch = 4; a.ncanv = d->L; a.shared = 0; a.band_rows = 0;
+    a.out_img_c = out_img_c; a.out_wts_c = out_wts_c;
+    return lsi_stream_launch(a, stream);
+  }
+  // other kernel families: the per-layer pass, then the layers are summed
+  rc = lsi_splat_fwd(d, tex, disp, mask, M, out_img, out_wts, nullptr,
+                     workspace, workspace_bytes, stream_);
+  if (rc != LSI_OK) return rc;
+  const size_t n1 = (size_t)d->B * d->Ht * d->Wt;
+  hipLaunchKernelGGL(compose_from_layers_kernel,
+                     dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, stream,
+                     n1, d->L, out_img, out_wts, out_img_c, out_wts_c);
+  return hipGetLastError() == hipSuccess ? LSI_OK : LSI_ELAUNCH;
+}
+
+int lsi_splat_bwd_both(const LsiSplatDesc* d, const float* tex,
+                       const float* disp, const float* mask, const float* M,
+                       const float* out_img, const float* out_wts,
+                       const float* out_img_c, const float* out_wts_c,
+                       const float* g_img, const float* g_wts,
+                       const float* g_img_c, const float* g_wts_c, float* g_tex,
+                       float* g_disp_in, float* g_mask, void* workspace,
+                       size_t workspace_bytes, lsi_stream_t stream_) {
+  int rc = check_desc(d);
+  if (rc != LSI_OK) return rc;
+  if (d->flags & LSI_COMPOSE) return LSI_EINVAL;
+  if (!tex || !disp || !M || !g_tex || !g_disp_in || !workspace) return LSI_ENULL;
+  if (g_img && (!out_img || !out_wts)) return LSI_ENULL;
+  if (g_img_c && (!out_img_c || !out_wts_c)) return LSI_ENULL;
+  if ((d->flags & LSI_HAS_MASK) && !mask) return LSI_ENULL;
+  if (workspace_bytes < lsi_splat_bwd_workspace_bytes(d)) return LSI_EWORKSPACE;
+  hipStream_t stream = (hipStream_t)stream_;
+  const size_t n1 = (size_t)d->B * d->Ht * d->Wt;
+  hipLaunchKernelGGL(splat_bwd_pre_both_kernel,
+                     dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, stream,
+                     n1, d->L, out_img, out_wts, out_img_c, out_wts_c, g_img,
+                     g_wts, g_img_c, g_wts_c, (float4*)workspace);
+  SplatArgs a;
+  a.d = *d;
+  a.tex = tex; a.disp = disp; a.mask = mask; a.M = M;
+  a.out_img = a.out_wts = a.out_disp = a.canvas = nullptr;
+  a.ws_bytes = 0;
+  a.nch = 4; a.ncanv = 1; a.shared = 0; a.band_rows = 0;
+  a.out_img_c = a.out_wts_c = nullptr;
   const int npx = d->H * d->W;
   hipLaunchKernelGGL(splat_bwd_kernel, dim3((npx + 255) / 256, d->B, d->L),
                      dim3(256), 0, stream, a, (const float4*)workspace, g_tex,

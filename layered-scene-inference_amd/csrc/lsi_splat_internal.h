@@ -19,6 +19,10 @@ struct SplatArgs {
   int ncanv;      // canvases per batch element (1 or L)
   int shared;     // 1: compose without disparity, all layers share a canvas
   int band_rows;  // ROWBAND: target rows per workgroup
+  // lsi_splat_fwd_both: the composed outputs next to the per-layer ones (NULL
+  // otherwise)
+  float* out_img_c;
+  float* out_wts_c;
 };
 
 // LSI_PATH_STREAM launcher and workspace need (lsi_splat_stream.hip).

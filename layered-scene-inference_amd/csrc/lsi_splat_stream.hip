@@ -95,6 +95,7 @@ struct alignas(16) StreamCfg {  // (kernarg offset: see epilogue_args)
   int ngrp;   // compose mode: layer groups per (row, segment) ...
   int lpg;    // ... of this many layers each
   int qcap;   // per-wave queue entries for corners outside the window scheme
+  int both;   // lsi_splat_fwd_both: a second tile sums the layers' tiles
   float inv_nb, inv_gx;  // reciprocals for division-free indexing
   float inv_per_row, inv_ngrp, inv_nseg;
   // boundary-row exchange area in the workspace (see stream_exchange_layout)
@@ -210,6 +211,7 @@ __device__ __forceinline__ void slow_corners(float* extras, float4 V, float x0,
 typedef const __attribute__((address_space(4))) char* KernargPtr;
 struct EpilogueArgs {
   float* out_img; float* out_wts; int* xcount; float4* xpart; float bg; int B;
+  float* out_img_c; float* out_wts_c;
 };
 __device__ __forceinline__ EpilogueArgs epilogue_args() {
   KernargPtr ka = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
@@ -221,6 +223,7 @@ __device__ __forceinline__ EpilogueArgs epilogue_args() {
                      ~(alignof(StreamCfg) - 1)));
   EpilogueArgs e;
   e.out_img = ap->out_img; e.out_wts = ap->out_wts;
+  e.out_img_c = ap->out_img_c; e.out_wts_c = ap->out_wts_c;
   e.bg = ap->d.bg_wt; e.B = ap->d.B;
   e.xcount = cp->xcount; e.xpart = cp->xpart;
   return e;
@@ -347,8 +350,11 @@ __global__ __launch_bounds__(LSI_STREAM_MAXT) void splat_stream_kernel(SplatArgs
           rb_all + NW * (2 * (((WMAX / 2 + 15) & ~15) + 8)));  // [NW][WMAX]
   float* extras = reinterpret_cast<float*>(sc_all + NW * WMAX);  // tile [R+x][Wt][4]
   const int CAP = cfg.cap;
+  // (both outputs: the composed tile follows the layer's tile)
+  float4* const ctile4 =
+      reinterpret_cast<float4*>(extras + (R + cfg.exchange) * Wt * 4);
   TaskA* taskA = reinterpret_cast<TaskA*>(
-      extras + (R + cfg.exchange) * Wt * 4);                      // [CAP]
+      extras + (R + cfg.exchange) * Wt * 4 * (cfg.both ? 2 : 1));  // [CAP]
   TaskB* taskB = reinterpret_cast<TaskB*>(taskA + CAP);           // [CAP]
   TaskC* taskC = reinterpret_cast<TaskC*>(taskB + CAP);           // [CAP]
   // [0..1] source rows, [2] task tickets, [3] range found analytically,
@@ -450,6 +456,9 @@ __global__ __launch_bounds__(LSI_STREAM_MAXT) void splat_stream_kernel(SplatArgs
     rb_all[i] = make_float4(0.f, 0.f, 0.f, 0.f);  // windows start (and are left) zero
   for (int i = tid; i < rows * Wt; i += T)
     tile4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (cfg.both)
+    for (int i = tid; i < rows * Wt; i += T)
+      ctile4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   if (tid < 8 + R + 2) ctl[tid] = 0;  // tickets, turn, locks
   LSI_TSTAMP();
   const int nseg = (W + SEG - 1) / SEG;
@@ -1350,6 +1359,22 @@ __global__ __launch_bounds__(LSI_STREAM_MAXT) void splat_stream_kernel(SplatArgs
         store_coherent(xrow(band + 1, 0) + cell, A);  // upper band's share
       } else {
         finish(r, cell, A);
+        if (cfg.both) {  // (halo bands only: every tile row is final here)
+          float4 c4 = ctile4[r * Wt + cell];
+          c4.x += A.x; c4.y += A.y; c4.z += A.z; c4.w += A.w;
+          if (pass + 1 < npass) {
+            ctile4[r * Wt + cell] = c4;
+          } else {  // ldi.py:167-174: sum of the layers' canvases, normalised
+            const float lbg_c = (float)nlayers * ea.bg;
+            const float Wsum = c4.w + lbg_c;
+            const float wd = safe_den(Wsum);
+            const size_t o = (size_t)b * P + (size_t)(row0 + r) * Wt + cell;
+            ea.out_img_c[3 * o + 0] = div_rn(c4.x + lbg_c, wd);
+            ea.out_img_c[3 * o + 1] = div_rn(c4.y + lbg_c, wd);
+            ea.out_img_c[3 * o + 2] = div_rn(c4.z + lbg_c, wd);
+            ea.out_wts_c[o] = Wsum;
+          }
+        }
         if (pass + 1 < npass) *tcell = make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
@@ -1419,7 +1444,7 @@ int stream_cap(int ntask) {
 }
 
 size_t stream_lds_bytes(const LsiSplatDesc* d, int tile_rows, int nw, int wmax,
-                        int cap, int qcap) {
+                        int cap, int qcap) {  // (tile_rows: both tiles counted)
   return (size_t)nw * (2 * (((wmax / 2 + 15) & ~15) + 8)) * 16 +
          (size_t)nw * wmax +
          (size_t)tile_rows * d->Wt * 16 +
@@ -1512,7 +1537,8 @@ size_t lsi_stream_workspace_bytes(const LsiSplatDesc* d) {
 // last waves finish alone (tail), then the epilogue.
 struct StreamPlan { int R, nw, xch, ngrp, lpg, cap, qcap; size_t lds; double est; };
 
-static int stream_plan(const LsiSplatDesc* d, int wmax, StreamPlan* out) {
+static int stream_plan(const LsiSplatDesc* d, int wmax, bool both,
+                       StreamPlan* out) {
   const int nseg = (d->W + SEG - 1) / SEG;
   const int grp_override = (d->reserved >> 12) & 0xf;  // experiments only
   static const char* cap_env = getenv("LSI_STREAM_LDS_CAP");  // experiments
@@ -1528,8 +1554,8 @@ static int stream_plan(const LsiSplatDesc* d, int wmax, StreamPlan* out) {
   const int npass = compose ? 1 : d->L;
   const int force_mode = (d->reserved >> 16) & 3;  // experiments: 1 halo, 2 exchange
   StreamPlan best; best.est = -1.0; best.nw = 0;
-  for (int xch = 0; xch <= 1; ++xch) {
-    if (force_mode && xch != force_mode - 1) continue;
+  for (int xch = 0; xch <= (both ? 0 : 1); ++xch) {
+    if (force_mode && !both && xch != force_mode - 1) continue;
     for (int R = 1; R <= 64; R *= 2) {
       if (d->tune_rows > 0 && R != d->tune_rows) continue;
       if (d->tune_rows <= 0 && R > 1 && R / 2 >= d->Ht) break;
@@ -1549,11 +1575,12 @@ static int stream_plan(const LsiSplatDesc* d, int wmax, StreamPlan* out) {
         for (int c = MAXNW; c >= 4; --c) {
           if (d->tune_threads > 0 && c != (d->tune_threads + 63) / 64) continue;
           int q = 64;
+          const int trows = (R + xch) * (both ? 2 : 1);
           while (q >= 16 &&
-                 stream_lds_bytes(d, R + xch, c, wmax, cap, q) > lds_cap)
+                 stream_lds_bytes(d, trows, c, wmax, cap, q) > lds_cap)
             q /= 2;
           if (q < 16) continue;
-          const size_t lds = stream_lds_bytes(d, R + xch, c, wmax, cap, q);
+          const size_t lds = stream_lds_bytes(d, trows, c, wmax, cap, q);
           long k = (long)(160 * 1024 / lds);   // co-resident workgroups per CU
           if (k > MAXNW / c) k = MAXNW / c;    // (128 VGPRs: 16 waves per CU)
           if (k < 1) k = 1;
@@ -1605,7 +1632,9 @@ int lsi_stream_launch(const SplatArgs& a, hipStream_t stream) {
   StreamCfg cfg;
   cfg.wmax = d->tune_window & ~LSI_STREAM_SIMPLE_BIT;
   StreamPlan plan;
-  if (stream_plan(d, cfg.wmax, &plan) != LSI_OK) return LSI_EINVAL;
+  const bool both = a.out_img_c != nullptr;
+  if (both && (d->flags & LSI_COMPOSE)) return LSI_EINVAL;
+  if (stream_plan(d, cfg.wmax, both, &plan) != LSI_OK) return LSI_EINVAL;
   const int R = plan.R, nw = plan.nw;
   const int threads = nw * 64;
   const size_t lds = plan.lds;
@@ -1616,6 +1645,7 @@ int lsi_stream_launch(const SplatArgs& a, hipStream_t stream) {
   cfg.ngrp = plan.ngrp;
   cfg.lpg = plan.lpg;
   cfg.qcap = plan.qcap;
+  cfg.both = both ? 1 : 0;
   cfg.nb = NB;
   cfg.inv_nb = 1.0f / (float)NB;
   cfg.inv_gx = 1.0f / (float)((d->Ht + R - 1) / R);

@@ -219,26 +219,26 @@ class Trainer(train_utils.Trainer):
     # view synthesis via forward splatting (ldi_enc_dec.py:296-357)
     zero = imgs_src.new_zeros(())
     indep_splat_loss, compose_splat_loss = zero, zero
-    for use_compose, wt in ((False, opts.indep_splat_wt),
-                            (True, opts.compose_splat_wt)):
-      if wt <= 0 or self.device.type != 'cuda':
-        continue
+    # One sweep per direction renders the per-layer AND the composed view
+    # (the reference makes four forward_splat calls whose per-layer splats
+    # are identical pairwise).
+    if self.device.type == 'cuda' and (opts.indep_splat_wt > 0 or
+                                       opts.compose_splat_wt > 0):
       for which in ('trg', 'src'):
         if which == 'trg':
           target, l = imgs_trg, ldi_src
         else:
           target, l = imgs_src, ldi_trg
-        recons_splat, _ = ldi_utils.forward_splat_matrix(
-            l, mats[which], compose_layers=use_compose,
-            trg_downsampling=opts.trg_splat_downsampling,
+        img_i, _, img_c, _ = ldi_utils.forward_splat_both(
+            l, mats[which], trg_downsampling=opts.trg_splat_downsampling,
             zbuf_scale=opts.zbuf_scale, bg_layer_disp=opts.bg_layer_disp,
             max_disp=opts.max_disp, mat_host=self.host_mats[which])
-        term = loss.view_synthesis_loss(recons_splat, target,
-                                        opts.splat_bdry_ignore)
-        if use_compose:
-          compose_splat_loss = compose_splat_loss + term
-        else:
-          indep_splat_loss = indep_splat_loss + term
+        if opts.indep_splat_wt > 0:
+          indep_splat_loss = indep_splat_loss + loss.view_synthesis_loss(
+              img_i, target, opts.splat_bdry_ignore)
+        if opts.compose_splat_wt > 0:
+          compose_splat_loss = compose_splat_loss + loss.view_synthesis_loss(
+              img_c, target, opts.splat_bdry_ignore)
 
     # regularisers (ldi_enc_dec.py:388-396)
     if self.device.type == 'cuda':

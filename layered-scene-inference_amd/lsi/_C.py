@@ -68,6 +68,8 @@ SIGNATURES = {
     'lsi_splat_fwd': (ctypes.c_int, [_DP] + [_VP] * 8 + [_SZ, _VP]),
     'lsi_splat_bwd_workspace_bytes': (_SZ, [_DP]),
     'lsi_splat_bwd': (ctypes.c_int, [_DP] + [_VP] * 12 + [_SZ, _VP]),
+    'lsi_splat_fwd_both': (ctypes.c_int, [_DP] + [_VP] * 9 + [_SZ, _VP]),
+    'lsi_splat_bwd_both': (ctypes.c_int, [_DP] + [_VP] * 16 + [_SZ, _VP]),
     'lsi_project_indices': (ctypes.c_int, [_DP] + [_VP] * 6),
     'lsi_splat_generic': (ctypes.c_int, [_I32] * 6 + [_VP] * 4),
     'lsi_splat_generic_bwd': (ctypes.c_int, [_I32] * 6 + [_VP] * 6),

@@ -200,6 +200,102 @@ class _ForwardSplat(torch.autograd.Function):
     return g_tex, g_mask, g_disp, None, None, None
 
 
+class _ForwardSplatBoth(torch.autograd.Function):
+  """lsi_splat_fwd_both / lsi_splat_bwd_both: the per-layer and the composed
+  rendering of one LDI from one sweep over its pixels."""
+
+  @staticmethod
+  def forward(ctx, tex, mask, disp, mat, mat_host, cfg):
+    dev = _C.require_device(tex, mask, disp, mat)
+    nl, b, h, w, c = tex.shape
+    if c != 3:
+      raise ValueError('forward_splat renders 3-channel textures (got %d)' % c)
+    s = cfg['trg_downsampling']
+    ht, wt = h * s, w * s
+    if ht != int(ht) or wt != int(wt):
+      raise ValueError('H*trg_downsampling and W*trg_downsampling must be '
+                       'integral (reference ldi.py:113-125)')
+    ht, wt = int(ht), int(wt)
+    flags = _C.LSI_HAS_MASK if mask is not None else 0
+    if cfg.get('deterministic'):
+      flags |= _C.LSI_DETERMINISTIC
+    bg_wt = _C.bg_weight(cfg['bg_layer_disp'], cfg['max_disp'],
+                         cfg['zbuf_scale'])
+    desc = _desc(tex, mask, disp, ht, wt, float(s), float(cfg['max_disp']),
+                 float(cfg['zbuf_scale']), bg_wt, flags, 0)
+    select_path(desc, mat_host, cfg.get('path', 'auto'))
+    img = torch.empty((nl, b, ht, wt, 3), dtype=torch.float32, device=dev)
+    wts = torch.empty((nl, b, ht, wt, 1), dtype=torch.float32, device=dev)
+    img_c = torch.empty((1, b, ht, wt, 3), dtype=torch.float32, device=dev)
+    wts_c = torch.empty((1, b, ht, wt, 1), dtype=torch.float32, device=dev)
+    lib = _C.lib()
+    ws_bytes = int(lib.lsi_splat_workspace_bytes(ctypes.byref(desc)))
+    ws = torch.zeros((max(ws_bytes, 16),), dtype=torch.uint8, device=dev)
+    mat = mat.contiguous()
+    rc = lib.lsi_splat_fwd_both(ctypes.byref(desc), _C.ptr(tex), _C.ptr(disp),
+                                _C.ptr(mask), _C.ptr(mat), _C.ptr(img),
+                                _C.ptr(wts), _C.ptr(img_c), _C.ptr(wts_c),
+                                _C.ptr(ws), ws_bytes, _C.stream_ptr(dev))
+    _C.check(rc, 'lsi_splat_fwd_both')
+    ctx.desc = desc
+    ctx.has_mask = mask is not None
+    ctx.save_for_backward(tex, mask if mask is not None else tex.new_empty(0),
+                          disp, mat, img, wts, img_c, wts_c)
+    return img, wts, img_c, wts_c
+
+  @staticmethod
+  def backward(ctx, g_img, g_wts, g_img_c, g_wts_c):
+    tex, mask, disp, mat, img, wts, img_c, wts_c = ctx.saved_tensors
+    mask = mask if ctx.has_mask else None
+    desc = ctx.desc
+    dev = tex.device
+    nl, b, h, w, _ = tex.shape
+
+    def c(t):
+      return None if t is None else t.contiguous()
+
+    g_img, g_wts, g_img_c, g_wts_c = c(g_img), c(g_wts), c(g_img_c), c(g_wts_c)
+    if g_img is None and g_wts is not None:
+      g_img = torch.zeros_like(img)
+    if g_img_c is None and g_wts_c is not None:
+      g_img_c = torch.zeros_like(img_c)
+    g_tex = torch.empty((nl, b, h, w, 3), dtype=torch.float32, device=dev)
+    g_disp = torch.empty((nl, b, h, w, 1), dtype=torch.float32, device=dev)
+    g_mask = (torch.empty((nl, b, h, w, 1), dtype=torch.float32, device=dev)
+              if mask is not None else None)
+    lib = _C.lib()
+    ws_bytes = int(lib.lsi_splat_bwd_workspace_bytes(ctypes.byref(desc)))
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+    rc = lib.lsi_splat_bwd_both(
+        ctypes.byref(desc), _C.ptr(tex), _C.ptr(disp), _C.ptr(mask),
+        _C.ptr(mat), _C.ptr(img), _C.ptr(wts), _C.ptr(img_c), _C.ptr(wts_c),
+        _C.ptr(g_img), _C.ptr(g_wts), _C.ptr(g_img_c), _C.ptr(g_wts_c),
+        _C.ptr(g_tex), _C.ptr(g_disp), _C.ptr(g_mask), _C.ptr(ws), ws_bytes,
+        _C.stream_ptr(dev))
+    _C.check(rc, 'lsi_splat_bwd_both')
+    return g_tex, g_mask, g_disp, None, None, None
+
+
+def forward_splat_both(ldi_src, src2trg_mat, trg_downsampling=1,
+                       bg_layer_disp=0, max_disp=1, zbuf_scale=10,
+                       mat_host=None, path='auto', deterministic=False):
+  """The two renderings the reference's training step makes of every LDI --
+  per layer (compose_layers=False) and composed (compose_layers=True),
+  reference ldi_enc_dec.py:302-334 -- from ONE sweep over the source pixels
+  (lsi_splat_fwd_both), and one gather pass in the backward.
+
+  Returns (img [L,B,Ht,Wt,3], wts [L,...,1], img_c [1,B,Ht,Wt,3], wts_c).
+  """
+  tex, mask, disp = ldi_src
+  if mat_host is None and path not in ('atomic', 'tile'):
+    mat_host = src2trg_mat.detach().to('cpu', torch.float32)
+  mat = src2trg_mat.detach().to(tex.device, torch.float32)
+  cfg = dict(trg_downsampling=trg_downsampling, bg_layer_disp=bg_layer_disp,
+             max_disp=max_disp, zbuf_scale=zbuf_scale, path=path,
+             deterministic=bool(deterministic))
+  return _ForwardSplatBoth.apply(tex, mask, disp, mat, mat_host, cfg)
+
+
 def forward_splat_matrix(ldi_src, src2trg_mat, compose_layers=True,
                          compute_trg_disp=False, trg_downsampling=1,
                          bg_layer_disp=0, max_disp=1, zbuf_scale=10,

@@ -793,3 +793,64 @@ def test_stream_workgroup_placement_covers_every_band_once(shape, dev, ref_cpu):
     np.testing.assert_allclose(wts.cpu().numpy(), want['wts'], rtol=WTS_RTOL)
     np.testing.assert_allclose(img.cpu().numpy(), want['img'], rtol=0,
                                atol=IMG_ATOL)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', ['fs_kitti_L2_s05.npz', 'fs_general_L3_s05.npz',
+                                  'fs_edge_L2_s05.npz'])
+def test_both_outputs_from_one_sweep(case, dev):
+  """lsi_splat_fwd_both: the per-layer and the composed rendering of one call
+  (STREAM: second LDS tile; other paths: per-layer pass + layer sum) against
+  the reference's goldens for compose_layers=False / True; its backward against
+  the sum of the two separate backwards."""
+  from lsi.geometry import ldi
+  g = golden(case)
+  s, bg, md, zb = _params(g)
+  kw = dict(trg_downsampling=s, bg_layer_disp=bg, max_disp=md, zbuf_scale=zb)
+
+  def leaves():
+    return [torch.tensor(g['tex'], device=dev, requires_grad=True),
+            torch.tensor(g['mask'], device=dev, requires_grad=True),
+            torch.tensor(g['disp'], device=dev, requires_grad=True)]
+
+  la = leaves()
+  img_i, wts_i, img_c, wts_c = ldi.forward_splat_both(la, torch.tensor(g['M']), **kw)
+  np.testing.assert_allclose(img_i.detach().cpu().numpy(), g['indep_img'], rtol=0,
+                             atol=IMG_ATOL)
+  np.testing.assert_allclose(wts_i.detach().cpu().numpy(), g['indep_wts'],
+                             rtol=WTS_RTOL)
+  np.testing.assert_allclose(img_c.detach().cpu().numpy(), g['compose_img'], rtol=0,
+                             atol=IMG_ATOL)
+  np.testing.assert_allclose(wts_c.detach().cpu().numpy(), g['compose_wts'],
+                             rtol=WTS_RTOL)
+  rs = np.random.RandomState(9)
+  ci = torch.tensor(rs.rand(*img_i.shape).astype(np.float32), device=dev)
+  cc = torch.tensor(rs.rand(*img_c.shape).astype(np.float32), device=dev)
+  cw = torch.tensor(rs.rand(*wts_c.shape).astype(np.float32) * 1e-3, device=dev)
+  ((img_i * ci).sum() + (img_c * cc).sum() + (wts_c * cw).sum()).backward()
+
+  lb = leaves()
+  a_i, _ = ldi.forward_splat_matrix(lb, torch.tensor(g['M']), compose_layers=False, **kw)
+  a_c, w_c = ldi.forward_splat_matrix(lb, torch.tensor(g['M']), compose_layers=True, **kw)
+  ((a_i * ci).sum() + (a_c * cc).sum() + (w_c * cw).sum()).backward()
+  for x, y in zip(la, lb):
+    scale = float(y.grad.abs().max()) + 1e-30
+    assert float((x.grad - y.grad).abs().max()) <= 2e-5 * scale
+
+
+@pytest.mark.gpu
+def test_both_outputs_at_config3_shard_size(dev, ref_cpu):
+  """4-layer 256x768 batch 4 (STREAM, second tile in LDS) vs the C oracle."""
+  from lsi.geometry import ldi
+  rs = np.random.RandomState(15)
+  tex, disp, mat = _synth(rs, 4, 4, 256, 768)
+  src = [torch.tensor(tex, device=dev), None, torch.tensor(disp, device=dev)]
+  img_i, wts_i, img_c, wts_c = ldi.forward_splat_both(
+      src, torch.tensor(mat), trg_downsampling=0.5, bg_layer_disp=1e-3,
+      max_disp=0.4, zbuf_scale=50)
+  for compose, (img, wts) in ((False, (img_i, wts_i)), (True, (img_c, wts_c))):
+    want = ref_cpu.forward_splat(tex, None, disp, mat, 0.5, 1e-3, 0.4, 50,
+                                 compose, want_disp=False)
+    np.testing.assert_allclose(img.cpu().numpy(), want['img'], rtol=0,
+                               atol=IMG_ATOL)
+    np.testing.assert_allclose(wts.cpu().numpy(), want['wts'], rtol=WTS_RTOL)
