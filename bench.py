@@ -250,6 +250,63 @@ def time_backward(r, iters=20):
   return e0.elapsed_time(e1) * 1e3 / iters
 
 
+def time_both(r, iters=20):
+  """lsi_splat_fwd_both (per-layer + composed outputs from one sweep) and
+  lsi_splat_bwd_both on the renderer's inputs; microseconds per launch."""
+  lib = _C.lib()
+  dev = r.dev
+  nl, b, h, w, _ = r.tex.shape
+  ht, wt = h // 2, w // 2
+  desc = _C.LsiSplatDesc.from_buffer_copy(r.desc)
+  desc.flags = 0
+  desc.path = r.desc.path
+  img = torch.empty((nl, b, ht, wt, 3), device=dev)
+  wts = torch.empty((nl, b, ht, wt, 1), device=dev)
+  img_c = torch.empty((1, b, ht, wt, 3), device=dev)
+  wts_c = torch.empty((1, b, ht, wt, 1), device=dev)
+  ws_bytes = int(lib.lsi_splat_workspace_bytes(ctypes.byref(desc)))
+  ws = torch.zeros((max(ws_bytes, 16),), dtype=torch.uint8, device=dev)
+  g_i, g_c = torch.rand_like(img), torch.rand_like(img_c)
+  g_tex = torch.empty((nl, b, h, w, 3), device=dev)
+  g_disp = torch.empty((nl, b, h, w, 1), device=dev)
+  bws_bytes = int(lib.lsi_splat_bwd_workspace_bytes(ctypes.byref(desc)))
+  bws = torch.empty((bws_bytes,), dtype=torch.uint8, device=dev)
+  turn = [0]
+
+  def fwd():
+    tex, disp = r.sets[turn[0]]
+    turn[0] = (turn[0] + 1) % len(r.sets)
+    rc = lib.lsi_splat_fwd_both(ctypes.byref(desc), _C.ptr(tex), _C.ptr(disp),
+                                None, _C.ptr(r.mat), _C.ptr(img), _C.ptr(wts),
+                                _C.ptr(img_c), _C.ptr(wts_c), _C.ptr(ws),
+                                ws_bytes, _C.stream_ptr(dev))
+    _C.check(rc, 'lsi_splat_fwd_both')
+
+  def bwd():
+    tex, disp = r.sets[turn[0]]
+    rc = lib.lsi_splat_bwd_both(
+        ctypes.byref(desc), _C.ptr(tex), _C.ptr(disp), None, _C.ptr(r.mat),
+        _C.ptr(img), _C.ptr(wts), _C.ptr(img_c), _C.ptr(wts_c), _C.ptr(g_i), None,
+        _C.ptr(g_c), None, _C.ptr(g_tex), _C.ptr(g_disp), None, _C.ptr(bws),
+        bws_bytes, _C.stream_ptr(dev))
+    _C.check(rc, 'lsi_splat_bwd_both')
+
+  out = []
+  for fn in (fwd, bwd):
+    for _ in range(3):
+      fn()
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+      fn()
+    e1.record()
+    torch.cuda.synchronize()
+    out.append(e0.elapsed_time(e1) * 1e3 / iters)
+  return out
+
+
 def backward_bytes(nl, b, h, w):
   """the backward re-reads the inputs (16 B / source px), reads
   g_img (12 B) and the saved img/wts (16 B) per target px and writes g_tex and
@@ -549,6 +606,20 @@ def main():
           'frac_of_hbm_peak': (alg + balg) / ((kern_s * 1e6 + bwd_us) * 1e-6) /
                               1e9 / HBM_PEAK_GBPS,
       }
+      try:
+        f_us, b_us = time_both(r)
+        # read the inputs once, write L + 1 rendered views; backward as above
+        # plus the composed view's gradient
+        both_alg = (nl * b_local * h * w * 16 +
+                    (nl + 1) * b_local * (h // 2) * (w // 2) * 16)
+        extra['both_outputs'] = {
+            'fwd_us': f_us, 'bwd_us': b_us,
+            'fwd_frac_of_hbm_peak': both_alg / (f_us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+            'note': 'lsi_splat_fwd_both / lsi_splat_bwd_both: the per-layer and '
+                    'the composed view of a training step from one sweep',
+        }
+      except Exception as e:  # pylint: disable=broad-except
+        extra['both_outputs'] = {'error': str(e)}
       del r
       torch.cuda.empty_cache()
       other = {}
