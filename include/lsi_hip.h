@@ -88,7 +88,7 @@ typedef struct LsiSplatDesc {
   int64_t mask_sl, mask_sb, mask_sy, mask_sx;
   float trg_downsampling; /* s                                              */
   float max_disp;
-  float zbuf_scale;
+  float zbuf_scale;       /* |zbuf_scale| <= 160 (else LSI_EINVAL)           */
   float bg_wt;            /* lsi_bg_weight(bg_layer_disp, max_disp, scale)   */
   uint32_t flags;
   int32_t path;

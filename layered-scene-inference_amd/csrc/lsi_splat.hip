@@ -511,6 +511,10 @@ int check_desc(const LsiSplatDesc* d) {
   if ((int64_t)d->H * d->W >= (1 << 24) || (int64_t)d->Ht * d->Wt >= (1 << 24))
     return LSI_EINVAL;  // fp32 index arithmetic exact only below 2^24
   if (!(d->max_disp > 0.0f)) return LSI_EINVAL;
+  // the device exp (lsi_common.h: exp_accurate) is valid for |argument| < ~80,
+  // i.e. |zbuf_scale| / 2: beyond that the weights would overflow / flush
+  // differently from the reference's exp
+  if (!(fabsf(d->zbuf_scale) <= 160.0f)) return LSI_EINVAL;
   return LSI_OK;
 }
 

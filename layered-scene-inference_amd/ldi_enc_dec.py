@@ -60,6 +60,20 @@ def build_parser():
   a('--depth_softmax_temp', type=float, default=1e-6)
   a('--max_disp', type=float, default=0)
   # build-specific switches
+  # synthetic planar worlds (reference ldi_enc_dec.py:52-55, 86-123): procedural
+  # textures replace the SUN / PASCAL images
+  a('--synth_scene', default='pairs', choices=['pairs', 'planes'],
+    help="synthetic inputs: 'pairs' = shifted smooth images generated on the "
+    "device (throughput runs); 'planes' = box room + billboard objects "
+    'rendered through planar_transform + compose (lsi/data/synthetic_planes)')
+  a('--debug_synth_texture', type=_bool, default=False,
+    help='feed the ground-truth fg / bg disparities in place of the predicted '
+    'ones (n_layers = 2, --synth_scene planes): the renderer must then '
+    'reconstruct the other view')
+  a('--synth_ds_factor', type=int, default=1)
+  a('--n_obj_min', type=int, default=1)
+  a('--n_obj_max', type=int, default=4)
+  a('--n_box_planes', type=int, default=5)
   a('--bf16', type=_bool, default=False, help='bf16 autocast for the convs')
   a('--channels_last', type=_bool, default=True)
   a('--cpu', type=_bool, default=False, help='CPU run (no splat losses)')
@@ -153,7 +167,19 @@ class Trainer(train_utils.Trainer):
   """LDI prediction trainer (reference ldi_enc_dec.py:126-410)."""
 
   def define_data_loader(self):
-    self.data_loader = SyntheticPairs(self.opts, self.device, 1234 + self.rank)
+    opts = self.opts
+    if opts.dataset == 'synthetic' and (opts.synth_scene == 'planes' or
+                                        opts.debug_synth_texture):
+      from lsi.data import synthetic_planes  # pylint: disable=g-import-not-at-top
+      if opts.debug_synth_texture and opts.n_layers != 2:
+        raise ValueError('debug_synth_texture feeds (fg, bg) disparities: '
+                         'n_layers must be 2')
+      opts.synth_dl_eval_data = (bool(opts.debug_synth_texture) or
+                                 bool(getattr(opts, 'synth_dl_eval_data', False)))
+      self.data_loader = synthetic_planes.DataLoader(
+          opts, device=self.device, seed=1234 + self.rank)
+    else:
+      self.data_loader = SyntheticPairs(opts, self.device, 1234 + self.rank)
     bs = self.opts.batch_size
     self.pixel_coords = nn_helpers.pixel_coords(bs, self.opts.img_height,
                                                 self.opts.img_width)
@@ -162,7 +188,16 @@ class Trainer(train_utils.Trainer):
     return LdiNet(self.opts)
 
   def feed(self):
-    return self.data_loader.forward(self.opts.batch_size)
+    """One batch: (img_src, img_trg, k_s, k_t, rot, trans); with
+    debug_synth_texture also the ground-truth LDI disparities (reference
+    ldi_enc_dec.py:230-263)."""
+    batch = self.data_loader.forward(self.opts.batch_size)
+    self.gt_disps = None
+    if self.opts.debug_synth_texture:
+      (_, _, _, _, _, _, _, _, d_s_fg, d_s_bg, d_t_fg, d_t_bg, _, _) = batch
+      self.gt_disps = (torch.stack([d_s_fg, d_s_bg], 0),
+                       torch.stack([d_t_fg, d_t_bg], 0))
+    return tuple(batch[:6])
 
   def stage(self, batch):
     """Images to the device; the two src->trg projection matrices are built on
@@ -197,6 +232,10 @@ class Trainer(train_utils.Trainer):
            (opts.bf16 and self.device.type == 'cuda') else _NullCtx())
     with amp:
       ldi_src, ldi_trg = self.train_model(imgs_src, imgs_trg)
+    if opts.debug_synth_texture and getattr(self, 'gt_disps', None) is not None:
+      # ldi_enc_dec.py:223-225: keep the graph, substitute the values
+      ldi_src[2] = 0 * ldi_src[2] + self.gt_disps[0].to(ldi_src[2].device)
+      ldi_trg[2] = 0 * ldi_trg[2] + self.gt_disps[1].to(ldi_trg[2].device)
 
     def ones_like_mask(l):
       return l[1] if l[1] is not None else torch.ones_like(l[2])

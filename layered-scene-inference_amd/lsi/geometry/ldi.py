@@ -9,6 +9,7 @@ An LDI is {textures, masks, disps}:
 output) -- the kernels take element strides, nothing is copied.
 """
 import ctypes
+import threading
 
 import torch
 
@@ -99,20 +100,23 @@ def plan_key(shape, trg_downsampling, max_disp, mat_host):
 
 
 _WS_CACHE = {}
+_WS_LOCK = threading.Lock()
 
 
 def _stream_workspace(desc, dev):
   """Zero-filled once, then kept by the library (lsi_hip.h, LSI_WS_KEEP): one
-  buffer per (device, stream, call geometry); calls on a stream are ordered."""
+  buffer per (device, stream, call geometry); calls on a stream are ordered.
+  Entries are never evicted: a captured HIP graph has the buffer's address
+  baked in and relies on the counters the library left zero (a process sees a
+  handful of geometries; the buffers hold a few counters and boundary rows)."""
   need = int(_C.lib().lsi_splat_workspace_bytes(ctypes.byref(desc)))
   key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, desc.L, desc.B,
          desc.Ht, desc.Wt, desc.flags & ~_C.LSI_WS_KEEP)
-  ws = _WS_CACHE.get(key)
-  if ws is None:
-    if len(_WS_CACHE) >= 16:  # a handful of shapes per process is the norm
-      _WS_CACHE.clear()
-    ws = torch.zeros((need,), dtype=torch.uint8, device=dev)
-    _WS_CACHE[key] = ws
+  with _WS_LOCK:
+    ws = _WS_CACHE.get(key)
+    if ws is None:
+      ws = torch.zeros((need,), dtype=torch.uint8, device=dev)
+      _WS_CACHE[key] = ws
   return ws, ws.numel()
 
 

@@ -72,3 +72,42 @@ def aggregate(metric_dicts):
       a, c = totals.get(k, (0.0, 0.0))
       totals[k] = (a + float(s), c + float(n))
   return {k: a / c for k, (a, c) in totals.items() if c > 0}
+
+
+def layer_prediction_metrics(ldi_src, ldi_trg, imgs_src, imgs_trg, gt, opts):
+  """Per-layer texture / disparity errors of the predicted LDIs against ground
+  truth (reference ldi_pred_eval.py:455-521; synthetic data only).
+
+  ldi_*: [tex L x B x H x W x 3, masks, disps L x B x H x W x 1].
+  gt: dict with src_gt_disp, trg_gt_disp (foreground, B x H x W x 1) and,
+      for the background metrics, src/trg_gt_disp_bg and src/trg_gt_tex_bg.
+  Foreground (layer 0): valid where the gt disparity exceeds bg_layer_disp;
+  background (last layer): valid where the foreground hides the background
+  (gt_disp > gt_disp_bg).  Texture errors are summed over the pixels and divided
+  by 3 (the channels).  Returns name -> (sum, norm)."""
+  n_layers = ldi_src[0].shape[0]
+  out = {}
+  v_s = (gt['src_gt_disp'] > opts.bg_layer_disp).float()
+  v_t = (gt['trg_gt_disp'] > opts.bg_layer_disp).float()
+  fg_tex = ((torch.abs(ldi_src[0][0] - imgs_src) * v_s).sum() / 3 +
+            (torch.abs(ldi_trg[0][0] - imgs_trg) * v_t).sum() / 3)
+  fg_disp = ((torch.abs(ldi_src[2][0] - gt['src_gt_disp']) * v_s).sum() +
+             (torch.abs(ldi_trg[2][0] - gt['trg_gt_disp']) * v_t).sum())
+  n_fg = (v_s + v_t).sum()
+  out['fg_tex_error'] = (fg_tex, n_fg)
+  out['fg_disp_error'] = (fg_disp, n_fg)
+  if 'src_gt_disp_bg' in gt:
+    b_s = (gt['src_gt_disp'] > gt['src_gt_disp_bg']).float()
+    b_t = (gt['trg_gt_disp'] > gt['trg_gt_disp_bg']).float()
+    bg_tex = ((torch.abs(ldi_src[0][n_layers - 1] - gt['src_gt_tex_bg']) *
+               b_s).sum() / 3 +
+              (torch.abs(ldi_trg[0][n_layers - 1] - gt['trg_gt_tex_bg']) *
+               b_t).sum() / 3)
+    bg_disp = ((torch.abs(ldi_src[2][n_layers - 1] - gt['src_gt_disp_bg']) *
+                b_s).sum() +
+               (torch.abs(ldi_trg[2][n_layers - 1] - gt['trg_gt_disp_bg']) *
+                b_t).sum())
+    n_bg = (b_s + b_t).sum()
+    out['bg_tex_error'] = (bg_tex, n_bg)
+    out['bg_disp_error'] = (bg_disp, n_bg)
+  return out

@@ -114,15 +114,48 @@ class Trainer(object):
       self._stream = torch.cuda.Stream(self.device)
     self.resume()
 
+  @staticmethod
+  def latest_checkpoint(checkpoint_dir):
+    """The most recently written of model.latest / model-<step> (what
+    tf.train.latest_checkpoint returns for the reference's Saver), or None."""
+    cands = glob.glob(os.path.join(checkpoint_dir, 'model-*'))
+    latest = os.path.join(checkpoint_dir, 'model.latest')
+    if os.path.exists(latest):
+      cands.append(latest)
+    return max(cands, key=os.path.getmtime) if cands else None
+
+  @staticmethod
+  def optimistic_restore(model, state_dict):
+    """helpers.optimistic_restorer (reference helpers.py:27-62): variables of the
+    saved model that exist in this one with the same shape are restored, the
+    others are skipped.  Returns the names restored."""
+    own = model.state_dict()
+    picked = {k: v for k, v in state_dict.items()
+              if k in own and tuple(own[k].shape) == tuple(v.shape)}
+    model.load_state_dict(picked, strict=False)
+    return sorted(picked)
+
   def resume(self):
-    """Latest checkpoint in checkpoint_dir if any (train_utils.py:190-195).
-    Like the reference, only model variables + global_step are saved: Adam's
-    moments restart."""
-    path = os.path.join(self.opts.checkpoint_dir, 'model.latest')
-    if os.path.exists(path):
+    """Latest checkpoint in checkpoint_dir if any; else, when --pretrain_name
+    is given, a shape-tolerant warm start from
+    checkpoint_dir/../<pretrain_name>/model-<pretrain_iter>
+    (train_utils.py:176-200).  Like the reference, only model variables +
+    global_step are saved: Adam's moments restart."""
+    opts = self.opts
+    path = self.latest_checkpoint(opts.checkpoint_dir)
+    if path is not None:
       state = torch.load(path, map_location=self.device)
       self.model.load_state_dict(state['model'])
       self.global_step = int(state['global_step'])
+      return
+    if getattr(opts, 'pretrain_name', ''):
+      pre = os.path.join(os.path.dirname(os.path.normpath(opts.checkpoint_dir)),
+                         opts.pretrain_name, 'model-%d' % opts.pretrain_iter)
+      if not os.path.exists(pre):
+        raise FileNotFoundError('--pretrain_name given but %s does not exist'
+                                % pre)
+      state = torch.load(pre, map_location=self.device)
+      self.optimistic_restore(self.model, state['model'])
 
   def save(self, name):
     if self.rank != 0:

@@ -146,3 +146,26 @@ def test_ddp_gradient_allreduce_two_gloo_ranks(tmp_path):
   # different data shards, identical parameters after the all-reduced step
   assert out[0][2] != out[1][2]
   assert out[0][0] == out[1][0] and out[0][1] == out[1][1]
+
+
+def test_resume_picks_the_newest_checkpoint_and_pretrain_restore(tmp_path):
+  """train_utils.py:176-200: resume from tf.train.latest_checkpoint (numbered
+  or `latest`), else an optimistic (shape-tolerant) restore from
+  ../<pretrain_name>/model-<pretrain_iter>."""
+  import os
+  import time
+  import torch
+  from lsi.nnutils import train_utils
+  run, pre = tmp_path / 'run', tmp_path / 'base'
+  os.makedirs(str(run)); os.makedirs(str(pre))
+  assert train_utils.Trainer.latest_checkpoint(str(run)) is None
+  torch.save({'model': {}, 'global_step': 50000}, str(run / 'model-50000'))
+  assert train_utils.Trainer.latest_checkpoint(str(run)).endswith('model-50000')
+  time.sleep(0.05)
+  torch.save({'model': {}, 'global_step': 52000}, str(run / 'model.latest'))
+  assert train_utils.Trainer.latest_checkpoint(str(run)).endswith('model.latest')
+  a = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.Linear(3, 2))
+  b = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.Linear(3, 5))
+  restored = train_utils.Trainer.optimistic_restore(b, a.state_dict())
+  assert restored == ['0.bias', '0.weight']            # shapes of layer 1 differ
+  assert torch.equal(b[0].weight, a[0].weight)

@@ -12,8 +12,6 @@ for bf in false true; do
   rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_$bf -o p -- python $R/tools/train_bench.py --bf16 $bf --steps 3 > /dev/null 2> $OUT/pmc_$bf.err
 done
 python3 - <<PY
-# raw traces are large: only the summary travels back
-rm -rf $OUT/kt_false $OUT/kt_true $OUT/pmc_false $OUT/pmc_true
 import csv, glob, json, collections
 out = {}
 for bf in ("false", "true"):
