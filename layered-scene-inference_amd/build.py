@@ -16,6 +16,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, 'csrc')
 SO = os.path.join(PKG, 'liblsi_hip.so')
 SOURCES = ['lsi_splat.hip', 'lsi_splat_stream.hip', 'lsi_splat_tile.hip',
+           'lsi_splat_sweep.hip',
            'lsi_sampling.hip', 'lsi_loss.hip']
 HEADERS = [os.path.join(CSRC, 'lsi_common.h'),
            os.path.join(CSRC, 'lsi_splat_internal.h'),

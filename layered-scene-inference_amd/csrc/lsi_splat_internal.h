@@ -32,3 +32,10 @@ int lsi_stream_launch(const SplatArgs& a, hipStream_t stream);
 // LSI_PATH_TILE launcher and workspace need (lsi_splat_tile.hip).
 size_t lsi_tile_workspace_bytes(const LsiSplatDesc* d);
 int lsi_tile_launch(const SplatArgs& a, hipStream_t stream);
+
+// The any-pose sweep kernel (lsi_splat_sweep.hip), launched by lsi_tile_launch
+// after the disparity ranges (range[(l * B + b) * LSI_RANGE_SLICES + k] =
+// {min, max} of a slice of rows) are on the stream.
+#define LSI_RANGE_SLICES 8
+#define LSI_SWEEP_MAXL 16
+int lsi_sweep_launch(const SplatArgs& a, const float2* range, hipStream_t stream);

@@ -1,0 +1,576 @@
+// LSI_PATH_TILE without the disparity output: the any-pose SWEEP kernel
+// (general 3-D poses, BASELINE config 4).  Reference semantics: ldi.py:97-184
+// (forward_splat) with sampling.py:161-241 (splat) for an arbitrary 4x4 matrix.
+//
+// The gather kernel (lsi_splat_tile.hip) bins records and walks bin lists
+// between chunk barriers; it stays for LSI_WANT_DISP.  Here nothing is binned
+// and nothing waits at a barrier while pixels are in flight:
+//
+// * Workgroup = (tile of TH x TW target cells, batch element[, layer]); the
+//   tile's r/g/b/w sums live in LDS (64 KB at 32 x 128 cells).
+// * Work item = (layer, source row, 64-pixel segment).  A prologue keeps the
+//   items whose target rows can intersect the tile (Y is linear-fractional in
+//   x and d: extremes at the segment's four (x, disparity-range) corners; the
+//   per-layer disparity range comes from disp_range_kernel) in an LDS list.
+//   Short segments follow a tilted / keystoned row closely: ~5 % more pixels
+//   are projected than land in the tile (whole rows: 20 %, and 1.5x imbalance
+//   between workgroups).
+// * The 16 waves draw QUADS of items by ticket (no barriers); 16 lanes own an
+//   item, each lane 4 consecutive pixels (16-byte loads, the next quad's in
+//   flight while this one is processed).  Concurrent waves take quads far
+//   apart in the list, so they rarely meet in the tile.
+// * Every pixel is projected with the exact index arithmetic of the other
+//   paths and each corner is added to its tile cell by a plain LDS
+//   read-modify-write under a per-cell spin lock.  The two left corners
+//   (x0, y0) and (x0, y0+1) are locked by ONE `ds_wrxchg2_rtn_b32` and released
+//   by one `ds_write2_b32`, then the two right ones: lanes of a wave are >= 1
+//   cell apart in x, so lanes do not collide with themselves.  Integer LDS
+//   exchanges retire ~20x faster than `ds_add_f32` (tools/microbench2.hip).
+//   A lane never waits while it holds a lock (try both, add where acquired,
+//   release, retry what failed): no deadlock for any input, any collision
+//   pattern is merely slower.
+// * Tile cells are stored even/odd interleaved within a row: lanes two cells
+//   apart (trg_downsampling 0.5 x 4 pixels) hit consecutive 16-byte slots.
+// * Epilogue per cell: background, normalisation (ldi.py:122-125, 157-182).
+// Summation order within a cell is not run-to-run deterministic (like ATOMIC
+// and the gather kernel).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/lsi_hip.h"
+#include "lsi_common.h"
+#include "lsi_splat_internal.h"
+
+#pragma clang fp contract(off)
+
+#ifndef LSI_STREAM_HOOKS
+#define LSI_STREAM_HOOKS 0
+#endif
+
+using namespace lsi;
+
+namespace {
+
+constexpr int SWEEP_CAP = 4096; // item-list entries in LDS (candidates per chunk)
+#ifndef LSI_SWEEP_T
+#define LSI_SWEEP_T 1024
+#endif
+#ifndef LSI_SWEEP_WGS
+#define LSI_SWEEP_WGS 1
+#endif
+constexpr int SWEEP_T = LSI_SWEEP_T;   // threads per workgroup
+constexpr int SWEEP_NW = SWEEP_T / 64;  // waves
+constexpr int SWEEP_BPW = (SWEEP_CAP / 64 + SWEEP_NW - 1) / SWEEP_NW;  // blocks per wave
+constexpr int SEGW = 64;        // source pixels per item (16 lanes x 4)
+
+struct SweepCfg {
+  int th;          // tile height (cells)
+  int tiles_x;
+  int nq4;         // groups of four 64-pixel segments per source row
+  int all_layers;  // 1: compose, every layer sums into the tile; 0: grid.z = layer
+  float inv_nq4, inv_nlw;
+};
+
+// n / d for 0 <= n < 2^22, d > 0, rcp = fl(1/d)
+__device__ __forceinline__ int div_small(int n, int d, float rcp) {
+  int q = (int)((float)n * rcp);
+  const int r = n - q * d;
+  q += (r >= d) ? 1 : 0;
+  q -= (r < 0) ? 1 : 0;
+  return q;
+}
+
+// Try-lock of the lock words at LDS byte address `addr` and `addr + 4 * OFF1`:
+// writes 1 to both, returns what was there (0 = acquired).
+template <int OFF1>
+__device__ __forceinline__ void try_lock2(unsigned addr, int& o0, int& o1) {
+  unsigned long long r;
+  const int one = 1;
+  asm volatile(
+      "ds_wrxchg2_rtn_b32 %0, %1, %2, %2 offset1:%3\n\ts_waitcnt lgkmcnt(0)"
+      : "=&v"(r)
+      : "v"(addr), "v"(one), "n"(OFF1)
+      : "memory");
+  o0 = (int)(unsigned)r;
+  o1 = (int)(r >> 32);
+}
+__device__ __forceinline__ int try_lock1(unsigned addr) {
+  int r;
+  const int one = 1;
+  asm volatile("ds_wrxchg_rtn_b32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)"
+               : "=&v"(r)
+               : "v"(addr), "v"(one)
+               : "memory");
+  return r;
+}
+template <int OFF1>
+__device__ __forceinline__ void unlock2(unsigned addr) {
+  const int zero = 0;
+  asm volatile("ds_write2_b32 %0, %1, %1 offset1:%2"
+               :
+               : "v"(addr), "v"(zero), "n"(OFF1)
+               : "memory");
+}
+__device__ __forceinline__ void unlock1(unsigned addr) {
+  const int zero = 0;
+  asm volatile("ds_write_b32 %0, %1" : : "v"(addr), "v"(zero) : "memory");
+}
+
+template <int TWL, bool VEC4, bool HAS_MASK>
+__global__ __launch_bounds__(SWEEP_T, LSI_SWEEP_WGS) void splat_sweep_kernel(
+    SplatArgs a, SweepCfg c, const float2* __restrict__ range) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int TW = 1 << TWL;
+  const LsiSplatDesc& d = a.d;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int b = blockIdx.y;
+  const int l_begin = c.all_layers ? 0 : (int)blockIdx.z;
+  const int NLW = c.all_layers ? d.L : 1;  // layers this workgroup sums
+  const int TH = c.th, NC = TH << TWL, NCP = (TH + 2) << TWL;
+  const int tile_y = blockIdx.x / c.tiles_x, tile_x = blockIdx.x - tile_y * c.tiles_x;
+  const int ty0 = tile_y * TH, tx0 = tile_x * TW;
+  const int Ht = d.Ht, Wt = d.Wt, H = d.H, W = d.W;
+
+  // r g b w sums and one lock per cell, rows -1 .. TH (slot row r + 1)
+  float4* tile = reinterpret_cast<float4*>(smem);   // [TH + 2][TW]
+  int* locks = reinterpret_cast<int*>(tile + NCP);  // [TH + 2][TW]
+  int* list = locks + NCP;                          // [SWEEP_CAP] accepted items
+  int* cnt = list + SWEEP_CAP;                      // [64] per-block counts
+  int* ctl = cnt + 64;                              // [1] list fill
+  float2* lrange = reinterpret_cast<float2*>(ctl + 4);  // [LSI_SWEEP_MAXL]
+  const unsigned locks_addr = (unsigned)(uintptr_t)locks;
+
+  float m[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) m[k] = a.M[16 * b + k];
+  const float s = d.trg_downsampling, zscale = d.zbuf_scale;
+  const float inv_md = div_rn(1.0f, d.max_disp);
+  const float ty0f = (float)ty0, tx0f = (float)tx0;
+  // the part of the tile inside the image, and the acceptance window of the
+  // top-left cell (x0, y0) around it
+  const int th_eff = min(TH, Ht - ty0), tw_eff = min(TW, Wt - tx0);
+  const float ay_lo = (float)(ty0 - 1), ay_hi = (float)(ty0 + th_eff - 1);
+  const float ax_lo = (float)(tx0 - 1), ax_hi = (float)(tx0 + tw_eff - 1);
+
+  for (int i = tid; i < NCP; i += SWEEP_T) {
+    tile[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    locks[i] = 0;
+  }
+  if (tid < NLW) {  // the layer's disparity range: fold the row slices
+    float2 dr = make_float2(__builtin_inff(), -__builtin_inff());
+    for (int k = 0; k < LSI_RANGE_SLICES; ++k) {
+      const float2 r = range[((size_t)(l_begin + tid) * d.B + b) * LSI_RANGE_SLICES + k];
+      dr.x = fminf(dr.x, r.x);
+      dr.y = fmaxf(dr.y, r.y);
+    }
+    lrange[tid] = dr;
+  }
+  __syncthreads();
+
+#if LSI_STREAM_HOOKS
+  // reserved & 4: cycles per wave in [0] issue [1] projection + weights
+  // [2] left pair [3] right pair [4] whole loop [5] prologue, written behind
+  // the range slices in the workspace (tools/sweep_probe.py)
+  long long tacc[6] = {0, 0, 0, 0, 0, 0};
+  long long tprev = __builtin_readcyclecounter();
+  const bool prof = (d.reserved & 4) != 0;
+#define SWEEP_STAMP(i) do { if (prof) { const long long tn = __builtin_readcyclecounter(); tacc[i] += tn - tprev; tprev = tn; } } while (0)
+#else
+#define SWEEP_STAMP(i)
+#endif
+  struct Px {
+    float4 dv, ta, tb, tc, mv;  // 4 disparities, 4 x rgb, 4 masks
+    int y, x;  // source row, first pixel of this lane (x < 0: nothing)
+  };
+
+  const int wave = tid >> 6;
+  const int ncand = NLW * H * c.nq4;
+  for (int cand0 = 0; cand0 < ncand; cand0 += SWEEP_CAP) {
+    const int cand1 = min(ncand, cand0 + SWEEP_CAP);
+    if (tid == 0) ctl[0] = 0;  // the ticket counter (barriers below)
+    // ---- work items of this chunk that can reach the tile, in candidate order
+    // (row, layer, group of 4 segments): blocks of 64 candidates, 4 per wave ----
+    unsigned long long tmask[SWEEP_BPW];
+    int tpacked[SWEEP_BPW];
+#pragma unroll
+    for (int k = 0; k < SWEEP_BPW; ++k) {
+      const int blk = wave + SWEEP_NW * k;
+      const int cand = blk < SWEEP_CAP / 64 ? cand0 + blk * 64 + lane : cand1;
+      int segs = 0;  // segments of the group that can reach the tile
+      int packed = 0;
+      if (cand < cand1) {
+        const int yl = c.nq4 == 1 ? cand : div_small(cand, c.nq4, c.inv_nq4);
+        const int q4 = cand - yl * c.nq4;
+        const int y = NLW == 1 ? yl : div_small(yl, NLW, c.inv_nlw);
+        const int li = yl - y * NLW;
+        const float2 dr = lrange[li];
+        const float py = (float)y + 0.5f;
+        const bool unbounded = !(dr.x <= dr.y);  // no finite disparity seen
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int x0s = (4 * q4 + g) * SEGW;
+          if (x0s >= W) continue;
+          const float xa = (float)x0s + 0.5f;
+          const float xb = (float)min(x0s + SEGW, W) - 0.5f;
+          float vmin = __builtin_inff(), vmax = -__builtin_inff();
+          bool wild = unbounded;
+          float nsign = 0.0f;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float px = (q & 1) ? xb : xa;
+            const float dv = (q & 2) ? dr.y : dr.x;
+            const float q1 = mrow(m, 1, px, py, dv);
+            const float n = mrow(m, 2, px, py, dv);
+            const float v = div_rn(q1, safe_den(n)) * s - 0.5f;
+            // Y is linear-fractional in x and d: monotone along both while the
+            // denominator keeps its sign on the segment; else no bound holds
+            if (!finite_f(v) || !finite_f(n) || n == 0.0f) wild = true;
+            if (q == 0) nsign = n;
+            else if ((n > 0.0f) != (nsign > 0.0f)) wild = true;
+            vmin = fminf(vmin, v);
+            vmax = fmaxf(vmax, v);
+          }
+          // one cell of slack on either side for the rounding of the corners
+          if (wild || (floorf(vmax) + 1.0f >= ay_lo && floorf(vmin) - 1.0f <= ay_hi))
+            segs |= 1 << g;
+        }
+        packed = (li << 28) | (q4 << 20) | (segs << 16) | y;
+      }
+      tmask[k] = __ballot(segs != 0);
+      tpacked[k] = packed;
+      if (lane == 0 && blk < SWEEP_CAP / 64) cnt[blk] = __popcll(tmask[k]);
+    }
+    __syncthreads();
+    if (wave == 0) {  // exclusive prefix of the 64 block counts
+      const int mine = cnt[lane];
+      int incl = mine;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(incl, o);
+        if (lane >= o) incl += up;
+      }
+      cnt[lane] = incl - mine;
+      if (lane == 63) ctl[1] = incl;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < SWEEP_BPW; ++k) {
+      if ((tmask[k] >> lane) & 1ull)
+        list[cnt[wave + SWEEP_NW * k] +
+             __builtin_amdgcn_mbcnt_hi((unsigned)(tmask[k] >> 32),
+                                       __builtin_amdgcn_mbcnt_lo((unsigned)tmask[k], 0u))] =
+            tpacked[k];
+    }
+    __syncthreads();
+    // ---- the waves draw items by ticket (the hardware favours the oldest
+    // waves of a SIMD: with a static split the last waves run on long after
+    // the first are done).  Ticket t maps to item (t % 16) * zc + t / 16: the
+    // list is sorted by row, so the 16 most recent tickets are items in 16
+    // bands of source rows several rows apart, and the four lane groups take
+    // the four segments of an item: what is in flight lands in different cells
+    // and lock collisions stay rare (a collision costs a wave a retry round).
+    const int nitem = ctl[1];
+    const int zc = (nitem + 15) >> 4;  // items per band
+    const int nticket = zc << 4;
+    auto next_ticket = [&]() {
+      int t = 0;
+      if (lane == 0) t = atomicAdd(&ctl[0], 1);
+      return __builtin_amdgcn_readfirstlane(t);
+    };
+
+    // Decodes the lane's item of step `st` and starts its loads.  The loads are
+    // unconditional (lanes without work read the item's first pixels) and their
+    // results are not touched until process(): the compiler then waits for
+    // them only there, one step later.
+    auto issue = [&](Px& p, int t) {
+      const int it = (t & 15) * zc + (t >> 4);
+      const unsigned item = (unsigned)list[min(it, nitem - 1)];
+      const int g = lane >> 4;
+      const int l = l_begin + (int)(item >> 28);
+      const int y = (int)(item & 0xffffu);
+      const int x = ((int)((item >> 20) & 0xffu) * 4 + g) * SEGW + (lane & 15) * 4;
+      const bool valid = t < nticket && it < nitem && ((item >> (16 + g)) & 1u) && x < W;
+      const int xs = valid ? x : 0;
+      p.y = y;
+      p.x = valid ? x : -1;
+      const float* dp = a.disp + (long)l * d.disp_sl + (long)b * d.disp_sb +
+                        (long)y * d.disp_sy + (long)xs * d.disp_sx;
+      const float* tp = a.tex + (long)l * d.tex_sl + (long)b * d.tex_sb +
+                        (long)y * d.tex_sy + (long)xs * d.tex_sx;
+      const float* mp = HAS_MASK ? a.mask + (long)l * d.mask_sl + (long)b * d.mask_sb +
+                                       (long)y * d.mask_sy + (long)xs * d.mask_sx
+                                 : nullptr;
+      if (VEC4) {  // unit strides, channels last, 16-byte aligned rows, W % 4 == 0
+        p.dv = *reinterpret_cast<const float4*>(dp);
+        p.ta = *reinterpret_cast<const float4*>(tp);
+        p.tb = *reinterpret_cast<const float4*>(tp + 4);
+        p.tc = *reinterpret_cast<const float4*>(tp + 8);
+        if (HAS_MASK) p.mv = *reinterpret_cast<const float4*>(mp);
+      } else {
+        float dv[4], t[12], mk[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const bool in = xs + j < W;  // past the row end: mask 0, dropped below
+          const int jj = in ? j : 0;
+          dv[j] = dp[(long)jj * d.disp_sx];
+          const float* tq = tp + (long)jj * d.tex_sx;
+          t[3 * j] = tq[0]; t[3 * j + 1] = tq[d.tex_sc]; t[3 * j + 2] = tq[2 * d.tex_sc];
+          mk[j] = HAS_MASK ? mp[(long)jj * d.mask_sx] : 1.0f;
+          if (!in) mk[j] = 0.0f;
+        }
+        p.dv = make_float4(dv[0], dv[1], dv[2], dv[3]);
+        p.ta = make_float4(t[0], t[1], t[2], t[3]);
+        p.tb = make_float4(t[4], t[5], t[6], t[7]);
+        p.tc = make_float4(t[8], t[9], t[10], t[11]);
+        p.mv = make_float4(mk[0], mk[1], mk[2], mk[3]);
+      }
+    };
+
+    // Adds V * wa to the cell at slot `cell` (= (row + 1) * TW + slot, row in
+    // -1 .. TH-1) and V * wb to the cell below it, for the lanes with need ==
+    // true.  Both cells are locked and updated together whatever their
+    // weights (the reference, too, adds all four corners, zero weights
+    // included); rows -1 and TH exist so that no lane needs a special case --
+    // what lands there is never read.
+    auto locked_pair = [&](bool need, int cell, float wa, float wb,
+                           const float4& V) {
+#if LSI_STREAM_HOOKS
+      if (d.reserved & 512) return;  // timing experiment: no accumulation
+#endif
+      const unsigned la = locks_addr + (unsigned)cell * 4u;
+      bool pend = false;
+      if (need) {
+        int oa, ob;
+#if LSI_STREAM_HOOKS
+        if (d.reserved & 1024) { oa = 0; ob = 0; } else  // experiment: no locks
+#endif
+        try_lock2<TW>(la, oa, ob);
+        if ((oa | ob) == 0) {
+          float4 ta = tile[cell], tb = tile[cell + TW];
+          // (explicit FMAs: a sum, not an index or a threshold)
+          ta.x = __fmaf_rn(V.x, wa, ta.x); ta.y = __fmaf_rn(V.y, wa, ta.y);
+          ta.z = __fmaf_rn(V.z, wa, ta.z); ta.w = __fmaf_rn(V.w, wa, ta.w);
+          tb.x = __fmaf_rn(V.x, wb, tb.x); tb.y = __fmaf_rn(V.y, wb, tb.y);
+          tb.z = __fmaf_rn(V.z, wb, tb.z); tb.w = __fmaf_rn(V.w, wb, tb.w);
+          tile[cell] = ta;
+          tile[cell + TW] = tb;
+          asm volatile("" ::: "memory");
+#if LSI_STREAM_HOOKS
+          if (!(d.reserved & 1024))
+#endif
+          unlock2<TW>(la);
+        } else {  // give back the half that was acquired
+          if (oa == 0) unlock1(la);
+          if (ob == 0) unlock1(la + TW * 4u);
+          pend = true;
+        }
+      }
+      // Lost a lock to another lane: one cell at a time, only cells still
+      // needed (two lanes after the same pair cannot keep each other's other
+      // half busy), never waiting while holding a lock.
+      if (__ballot(pend) != 0ull) {
+        bool na = pend, nb = pend;
+        while (__ballot(na || nb) != 0ull) {
+          if (na) {
+            if (try_lock1(la) == 0) {
+              float4 t = tile[cell];
+              t.x = __fmaf_rn(V.x, wa, t.x); t.y = __fmaf_rn(V.y, wa, t.y);
+              t.z = __fmaf_rn(V.z, wa, t.z); t.w = __fmaf_rn(V.w, wa, t.w);
+              tile[cell] = t;
+              asm volatile("" ::: "memory");
+              unlock1(la);
+              na = false;
+            }
+          } else if (nb) {
+            if (try_lock1(la + TW * 4u) == 0) {
+              float4 t = tile[cell + TW];
+              t.x = __fmaf_rn(V.x, wb, t.x); t.y = __fmaf_rn(V.y, wb, t.y);
+              t.z = __fmaf_rn(V.z, wb, t.z); t.w = __fmaf_rn(V.w, wb, t.w);
+              tile[cell + TW] = t;
+              asm volatile("" ::: "memory");
+              unlock1(la + TW * 4u);
+              nb = false;
+            }
+          }
+        }
+      }
+    };
+
+    auto process = [&](const Px& p) {
+      if (__ballot(p.x >= 0) == 0ull) return;
+#if LSI_STREAM_HOOKS
+      if (d.reserved & 2048) return;  // timing experiment: loads only
+#endif
+      const float py = (float)p.y + 0.5f;
+      const float dvs[4] = {p.dv.x, p.dv.y, p.dv.z, p.dv.w};
+      const float t0s[4] = {p.ta.x, p.ta.w, p.tb.z, p.tc.y};
+      const float t1s[4] = {p.ta.y, p.tb.x, p.tb.w, p.tc.z};
+      const float t2s[4] = {p.ta.z, p.tb.y, p.tc.x, p.tc.w};
+      const float mks[4] = {p.mv.x, p.mv.y, p.mv.z, p.mv.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float px = (float)(p.x + j) + 0.5f;
+        const float dv = dvs[j];
+        const float q1 = mrow(m, 1, px, py, dv);
+        const float nden = safe_den(mrow(m, 2, px, py, dv));
+        const float Y = div_rn(q1, nden) * s - 0.5f;
+        const float y0 = floorf(Y);
+        const float q0 = mrow(m, 0, px, py, dv);
+        const float X = div_rn(q0, nden) * s - 0.5f;
+        const float x0 = floorf(X);
+        // (non-finite X / Y fail the comparisons: dropped, like every path)
+        bool ok = p.x >= 0 && y0 >= ay_lo && y0 <= ay_hi && x0 >= ax_lo && x0 <= ax_hi;
+        if (__ballot(ok) == 0ull) continue;
+#if LSI_STREAM_HOOKS
+        if (prof) tacc[5] += 1 + ((long long)__popcll(__ballot(ok)) << 32);  // px-iters, ok lanes
+#endif
+        const float q3 = mrow(m, 3, px, py, dv);
+        const float dd = div_rn(q3, nden);
+        const float pw = (VEC4 && !HAS_MASK)
+                             ? zbuffer_weight(dd * inv_md, zscale)
+                             : zbuffer_weight(dd * inv_md, zscale) * mks[j];
+        ok = ok && pw != 0.0f;  // contributes exactly +0 everywhere
+        // Corner weights (sampling.py:193-222).  The border masks are implied:
+        // a corner outside the image is outside every tile and never read.
+        const float wx0 = (x0 + 1.0f) - X, wx1 = X - x0;
+        const float wy0 = (y0 + 1.0f) - Y, wy1 = Y - y0;
+        const float w00 = clamp_small(wx0 * wy0), w01 = clamp_small(wx1 * wy0);
+        const float w10 = clamp_small(wx0 * wy1), w11 = clamp_small(wx1 * wy1);
+        const float4 V = make_float4(t0s[j] * pw, t1s[j] * pw, t2s[j] * pw, pw);
+        const int iy = ok ? (int)(y0 - ty0f) : 0;  // -1 .. th_eff - 1
+        const int ix = ok ? (int)(x0 - tx0f) : 0;  // -1 .. tw_eff - 1
+        // even cells of a row first, odd cells in its second half
+        const int ixr = ix + 1;
+        const int sl = (ix >> 1) + ((ix & 1) << (TWL - 1));
+        const int sr = (ixr >> 1) + ((ixr & 1) << (TWL - 1));
+        const int rowb = (iy + 1) << TWL;
+        SWEEP_STAMP(1);
+        locked_pair(ok && ix >= 0, rowb + sl, w00, w10, V);
+        SWEEP_STAMP(2);
+        locked_pair(ok && ixr < tw_eff, rowb + sr, w01, w11, V);
+        SWEEP_STAMP(3);
+      }
+    };
+
+    if (nitem > 0) {
+      Px pa, pb;
+      pa.mv = make_float4(1.f, 1.f, 1.f, 1.f);
+      pb.mv = pa.mv;
+      SWEEP_STAMP(5);
+#if LSI_STREAM_HOOKS
+      const long long tloop = tprev;
+#endif
+      int ta = next_ticket();
+      issue(pa, ta);
+      for (;;) {
+        const int tb = next_ticket();
+        issue(pb, tb);
+        SWEEP_STAMP(0);
+        if (ta >= nticket) break;
+        process(pa);
+        ta = next_ticket();
+        issue(pa, ta);
+        SWEEP_STAMP(0);
+        if (tb >= nticket) break;
+        process(pb);
+      }
+#if LSI_STREAM_HOOKS
+      tacc[4] += tprev - tloop;
+#endif
+    }
+    __syncthreads();
+  }
+#if LSI_STREAM_HOOKS
+  if (prof && lane == 0) {
+    long long* o = reinterpret_cast<long long*>(
+                       const_cast<float2*>(range) +
+                       (size_t)d.B * d.L * LSI_RANGE_SLICES) +
+                   (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * SWEEP_NW + wave) * 6;
+    for (int k = 0; k < 6; ++k) o[k] = tacc[k];
+  }
+#endif
+
+  // ---- epilogue: background, normalisation (ldi.py:122-125, 157-182) ---------
+  const float bgs = (float)NLW * d.bg_wt;
+  const size_t P = (size_t)Ht * Wt;
+  const size_t obase = c.all_layers ? (size_t)b * P
+                                    : ((size_t)l_begin * d.B + b) * P;
+  for (int cell = tid; cell < NC; cell += SWEEP_T) {
+    const int cy = cell >> TWL, cx = cell & (TW - 1);
+    const int gy = ty0 + cy, gx = tx0 + cx;
+    if (gy >= Ht || gx >= Wt) continue;
+    const float4 t = tile[((cy + 1) << TWL) + (cx >> 1) + ((cx & 1) << (TWL - 1))];
+    const size_t o = obase + (size_t)gy * Wt + gx;
+    const float w = t.w + bgs;
+    const float wd = safe_den(w);
+    a.out_img[3 * o + 0] = div_rn(t.x + bgs, wd);
+    a.out_img[3 * o + 1] = div_rn(t.y + bgs, wd);
+    a.out_img[3 * o + 2] = div_rn(t.z + bgs, wd);
+    a.out_wts[o] = w;
+  }
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// 16-byte loads of 4 consecutive pixels: channels-last texture, unit pixel
+// strides, every row / layer / batch offset a multiple of 4 floats.
+bool sweep_vec4(const SplatArgs& a) {
+  const LsiSplatDesc& d = a.d;
+  bool ok = d.W % 4 == 0 && d.tex_sc == 1 && d.tex_sx == 3 && d.disp_sx == 1 &&
+            d.tex_sy % 4 == 0 && d.tex_sb % 4 == 0 && d.tex_sl % 4 == 0 &&
+            d.disp_sy % 4 == 0 && d.disp_sb % 4 == 0 && d.disp_sl % 4 == 0 &&
+            aligned16(a.tex) && aligned16(a.disp);
+  if (d.flags & LSI_HAS_MASK)
+    ok = ok && d.mask_sx == 1 && d.mask_sy % 4 == 0 && d.mask_sb % 4 == 0 &&
+         d.mask_sl % 4 == 0 && aligned16(a.mask);
+  return ok;
+}
+
+template <int TWL>
+const void* sweep_fn(bool vec4, bool has_mask) {
+  return vec4 ? (has_mask ? (const void*)splat_sweep_kernel<TWL, true, true>
+                          : (const void*)splat_sweep_kernel<TWL, true, false>)
+              : (has_mask ? (const void*)splat_sweep_kernel<TWL, false, true>
+                          : (const void*)splat_sweep_kernel<TWL, false, false>);
+}
+
+}  // namespace
+
+int lsi_sweep_launch(const SplatArgs& a, const float2* range, hipStream_t stream) {
+  const LsiSplatDesc* d = &a.d;
+  if (d->H > 65535 || d->W > 65535) return LSI_EINVAL;  // item packing
+  SweepCfg c;
+  // a tile of (up to) 4096 cells: 64 KB of sums + 17 KB of locks
+  const int twl = d->Wt <= 32 ? 5 : (d->Wt <= 64 ? 6 : 7);
+  const int TW = 1 << twl;
+  const bool compose = (d->flags & LSI_COMPOSE) != 0;
+  const int nz = compose ? 1 : d->L;
+  c.th = (LSI_SWEEP_T < 1024 ? 2048 : 4096) / TW;
+  if (d->tune_rows > 0 && d->tune_rows < c.th) c.th = d->tune_rows;
+  // shorter tiles when the tall ones would leave CUs idle
+  while (c.th > 8 && (long)((d->Ht + c.th - 1) / c.th) *
+                             ((d->Wt + TW - 1) / TW) * d->B * nz < 256)
+    c.th >>= 1;
+  if (c.th > d->Ht) c.th = (d->Ht + 7) & ~7;
+  c.tiles_x = (d->Wt + TW - 1) / TW;
+  c.nq4 = (d->W + 4 * SEGW - 1) / (4 * SEGW);
+  c.all_layers = compose ? 1 : 0;
+  c.inv_nq4 = 1.0f / (float)c.nq4;
+  c.inv_nlw = 1.0f / (float)(compose ? d->L : 1);
+  const int tiles_y = (d->Ht + c.th - 1) / c.th;
+  const size_t lds = (size_t)(c.th + 2) * TW * 20 + (size_t)SWEEP_CAP * 4 + 64 * 4 + 16 +
+                     LSI_SWEEP_MAXL * 8;
+  const bool vec4 = sweep_vec4(a), has_mask = (d->flags & LSI_HAS_MASK) != 0;
+  const void* fn = twl == 5 ? sweep_fn<5>(vec4, has_mask)
+                            : (twl == 6 ? sweep_fn<6>(vec4, has_mask)
+                                        : sweep_fn<7>(vec4, has_mask));
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)lds) != hipSuccess)
+    return LSI_ELAUNCH;
+  void* kargs[3] = {const_cast<SplatArgs*>(&a), &c, &range};
+  if (hipLaunchKernel(fn, dim3(c.tiles_x * tiles_y, d->B, nz), dim3(SWEEP_T), kargs,
+                      lds, stream) != hipSuccess)
+    return LSI_ELAUNCH;
+  return hipGetLastError() == hipSuccess ? LSI_OK : LSI_ELAUNCH;
+}

@@ -55,24 +55,40 @@ struct TileCfg {
   int cpt;       // cells per thread (1, 2 or 4): thread t owns cells t + k*1024
 };
 
-// Per batch element: min and max of the finite-or-infinite disparities (NaNs
-// are skipped: such pixels are dropped by every path).  grid (B), block 1024.
-__global__ __launch_bounds__(1024) void disp_range_kernel(SplatArgs a,
-                                                          float2* range) {
+// Min and max of the finite-or-infinite disparities of a slice of rows of one
+// (layer, batch element) (NaNs are skipped: such pixels are dropped by every
+// path).  grid (B * L, LSI_RANGE_SLICES), block 256;
+// range[(l * B + b) * LSI_RANGE_SLICES + slice]; consumers fold the slices.
+__global__ __launch_bounds__(256) void disp_range_kernel(SplatArgs a,
+                                                         float2* range, int vec4) {
   const LsiSplatDesc& d = a.d;
-  const int b = blockIdx.x;
+  const int l = blockIdx.x / d.B, b = blockIdx.x - l * d.B, sl = blockIdx.y;
+  const int r0 = (int)((long)d.H * sl / LSI_RANGE_SLICES);
+  const int r1 = (int)((long)d.H * (sl + 1) / LSI_RANGE_SLICES);
   float lo = __builtin_inff(), hi = -__builtin_inff();
-  const int n = d.H * d.W;
-  for (int l = 0; l < d.L; ++l) {
-    const float* base = a.disp + (long)l * d.disp_sl + (long)b * d.disp_sb;
-    for (int i = threadIdx.x; i < n; i += 1024) {
-      const int y = i / d.W, x = i - y * d.W;
-      const float v = base[(long)y * d.disp_sy + (long)x * d.disp_sx];
-      lo = fminf(lo, v);  // fminf / fmaxf return the non-NaN operand
-      hi = fmaxf(hi, v);
+  const float* base = a.disp + (long)l * d.disp_sl + (long)b * d.disp_sb;
+  if (vec4) {  // unit pixel stride, 16-byte aligned rows, W % 4 == 0
+    const int w4 = d.W >> 2, n4 = (r1 - r0) * w4;
+    const float rcp_w4 = 1.0f / (float)w4;
+    for (int i = threadIdx.x; i < n4; i += 256) {  // i < 2^22: H * W < 2^24
+      int y = (int)((float)i * rcp_w4);
+      int x4 = i - y * w4;
+      if (x4 < 0) { --y; x4 += w4; }
+      if (x4 >= w4) { ++y; x4 -= w4; }
+      const float4 v = reinterpret_cast<const float4*>(
+          base + (long)(r0 + y) * d.disp_sy)[x4];
+      lo = fminf(fminf(lo, v.x), fminf(fminf(v.y, v.z), v.w));  // skip NaNs
+      hi = fmaxf(fmaxf(hi, v.x), fmaxf(fmaxf(v.y, v.z), v.w));
     }
+  } else {
+    for (int y = r0; y < r1; ++y)
+      for (int x = threadIdx.x; x < d.W; x += 256) {
+        const float v = base[(long)y * d.disp_sy + (long)x * d.disp_sx];
+        lo = fminf(lo, v);  // fminf / fmaxf return the non-NaN operand
+        hi = fmaxf(hi, v);
+      }
   }
-  __shared__ float slo[16], shi[16];
+  __shared__ float slo[4], shi[4];
   for (int o = 32; o > 0; o >>= 1) {
     lo = fminf(lo, __shfl_xor(lo, o));
     hi = fmaxf(hi, __shfl_xor(hi, o));
@@ -83,8 +99,8 @@ __global__ __launch_bounds__(1024) void disp_range_kernel(SplatArgs a,
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    for (int w = 1; w < 16; ++w) { lo = fminf(lo, slo[w]); hi = fmaxf(hi, shi[w]); }
-    range[b] = make_float2(lo, hi);
+    for (int w = 1; w < 4; ++w) { lo = fminf(lo, slo[w]); hi = fmaxf(hi, shi[w]); }
+    range[((size_t)l * d.B + b) * LSI_RANGE_SLICES + sl] = make_float2(lo, hi);
   }
 }
 
@@ -126,7 +142,13 @@ __global__ __launch_bounds__(1024) void splat_tile_kernel(
 
   // ---- source rows that can reach the tile -------------------------------
   {
-    const float2 dr = range[b];
+    float2 dr = make_float2(__builtin_inff(), -__builtin_inff());
+    for (int l = 0; l < d.L; ++l)  // this kernel bounds all layers together
+      for (int k = 0; k < LSI_RANGE_SLICES; ++k) {
+        const float2 r = range[((size_t)l * d.B + b) * LSI_RANGE_SLICES + k];
+        dr.x = fminf(dr.x, r.x);
+        dr.y = fmaxf(dr.y, r.y);
+      }
     int lo = H, hi = -1;
     for (int y = tid; y < H; y += TT) {
       const float py = (float)y + 0.5f;
@@ -355,7 +377,7 @@ __global__ __launch_bounds__(1024) void splat_tile_kernel(
 #if LSI_STREAM_HOOKS
   if ((d.reserved & 4) && tid == 0) {
     long long* o = reinterpret_cast<long long*>(
-                       const_cast<float2*>(range) + d.B) +
+                       const_cast<float2*>(range) + (size_t)d.B * d.L * LSI_RANGE_SLICES) +
                    ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4;
     o[0] = tacc[0]; o[1] = tacc[1]; o[2] = tacc[2]; o[3] = tacc[3];
   }
@@ -389,10 +411,11 @@ __global__ __launch_bounds__(1024) void splat_tile_kernel(
   }
 }
 
+
 }  // namespace
 
 size_t lsi_tile_workspace_bytes(const LsiSplatDesc* d) {
-  return (size_t)d->B * sizeof(float2);
+  return (size_t)d->B * d->L * LSI_RANGE_SLICES * sizeof(float2);
 }
 
 int lsi_tile_launch(const SplatArgs& a, hipStream_t stream) {
@@ -401,8 +424,18 @@ int lsi_tile_launch(const SplatArgs& a, hipStream_t stream) {
   if (a.ws_bytes < lsi_tile_workspace_bytes(d)) return LSI_EWORKSPACE;
   if ((reinterpret_cast<uintptr_t>(a.canvas) & 7) != 0) return LSI_EINVAL;
   float2* range = reinterpret_cast<float2*>(a.canvas);
-  hipLaunchKernelGGL(disp_range_kernel, dim3(d->B), dim3(1024), 0, stream, a,
-                     range);
+  const int rvec4 = d->W % 4 == 0 && d->disp_sx == 1 && d->disp_sy % 4 == 0 &&
+                    d->disp_sb % 4 == 0 && d->disp_sl % 4 == 0 &&
+                    (reinterpret_cast<uintptr_t>(a.disp) & 15) == 0;
+  hipLaunchKernelGGL(disp_range_kernel, dim3(d->B * d->L, LSI_RANGE_SLICES),
+                     dim3(256), 0, stream, a, range, rvec4);
+  const bool want_disp = (d->flags & LSI_WANT_DISP) != 0;
+  // the sweep kernel renders colour + weight; the disparity output (per-layer
+  // normalisation before the max over layers) stays on the gather kernel
+  // (reserved bit 8: force the gather kernel, for A/B runs)
+  if (!want_disp && !(d->reserved & 256) &&
+      (!(d->flags & LSI_COMPOSE) || d->L <= LSI_SWEEP_MAXL))
+    return lsi_sweep_launch(a, range, stream);
   TileCfg c;
   c.tw_log2 = d->Wt <= 32 ? 5 : (d->Wt <= 64 ? 6 : 7);
   const int TW = 1 << c.tw_log2;
@@ -427,7 +460,6 @@ int lsi_tile_launch(const SplatArgs& a, hipStream_t stream) {
   c.th = c.cpt * TT / TW;
   c.tiles_x = (d->Wt + TW - 1) / TW;
   const int tiles_y = (d->Ht + c.th - 1) / c.th;
-  const bool want_disp = (d->flags & LSI_WANT_DISP) != 0;
   const size_t lds = (size_t)CH * 32 + (want_disp ? (size_t)CH * 4 : 0) +
                      (size_t)CH * 4 + (size_t)2 * (c.th + 1) * (TW + 1) * 4 + 16;
   const void* fn = want_disp ? (const void*)splat_tile_kernel<true>
