@@ -499,6 +499,10 @@ def main():
                   help='LsiSplatDesc.reserved: planner experiments (bits 12+) work '
                   'with any build; the kernel timing hooks (bits 0-9) need '
                   'LSI_HIP_LIB=hooks (build.py --hooks)')
+  ap.add_argument('--shard-of', type=int, default=1,
+                  help='N=1 only: time the per-rank shard of an N-rank run (what '
+                  'one GPU of --gpus N renders); the JSON line is then about that '
+                  'shard, not the workload')
   ap.add_argument('--disp', default='smooth',
                   choices=['smooth', 'rough', 'stress'])
   ap.add_argument('--tex-layout', default='nhwc', choices=['nhwc', 'planar'],
@@ -528,7 +532,7 @@ def main():
       dist.init_process_group('nccl', rank=rank, world_size=world,
                               device_id=torch.device('cuda', local_rank))
   nl, h, w, batch, per_gpu, cams, max_disp, bg = WORKLOADS[args.workload]
-  b_local, scaling = shard_batch(args.workload, world)
+  b_local, scaling = shard_batch(args.workload, max(world, args.shard_of))
 
   if selftest:
     # the rank plumbing without a GPU: shard, barrier, max-over-ranks, one line
@@ -585,7 +589,11 @@ def main():
             'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS,
             'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS,
             'traffic': None,
-            'kernel': 'splat_%s_kernel' % r.path_name,
+            # the any-pose path: disp_range_kernel + splat_sweep_kernel, both
+            # inside the measured launch
+            'kernel': ('splat_sweep_kernel (+ disp_range_kernel)'
+                       if r.path_name == 'tile' else
+                       'splat_%s_kernel' % r.path_name),
             'algorithmic_bytes_per_launch': alg,
             'avg_launch_us': kern_s * 1e6,
         },

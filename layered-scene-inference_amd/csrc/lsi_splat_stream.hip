@@ -477,8 +477,16 @@ __global__ __launch_bounds__(LSI_STREAM_MAXT) void splat_stream_kernel(SplatArgs
   // task = (source row, 256-pixel segment, group of layers); table for tasks
   // [tg0, tg0 + CAP) of ntask, rows from ylo on, layers from lbase on: one
   // task per participating thread (threads first, first + stride, ...)
+  auto pad5 = [](int n) { return (n + 4) / 5 * 5; };  // rows of the task order
   auto fill_tasks = [&](int tg0, int first, int stride, int ylo, int ntask,
-                        int lbase, int lend) {
+                        int lbase, int lend, int nreal) {
+    // Consecutive tickets go to source rows a fifth of the band apart: row
+    // index yi of the (padded) task order is source row (yi % 5) * q + yi / 5,
+    // q = rows / 5 rounded up.  The tasks in flight at any time then merge
+    // into different tile rows (less waiting at the row locks); the at most 4
+    // padding rows are empty tasks.
+    const int nrows_pad = (int)(((float)ntask + 0.5f) * inv_per_row);
+    const int q5 = (int)(((float)nrows_pad + 0.5f) * 0.2f);
     for (int t = first; t < CAP; t += stride) {
       const int tg = tg0 + t;
       TaskA ta; ta.row0 = -1000000; ta.wy0 = 0.f; ta.wy1 = 0.f; ta.win = 0;
@@ -489,16 +497,22 @@ __global__ __launch_bounds__(LSI_STREAM_MAXT) void splat_stream_kernel(SplatArgs
         // tg / per_row etc. without integer divisions (tg < 2^20: exact)
         const int yi = (int)(((float)tg + 0.5f) * inv_per_row);
         const int rem = tg - yi * per_row;
+#ifdef LSI_NO_INTERLEAVE
+        const int yr = yi;
+#else
+        const int y5 = (int)(((float)yi + 0.5f) * 0.2f);
+        const int yr = (yi - 5 * y5) * q5 + y5;
+#endif
         const int sg = (int)(((float)rem + 0.5f) * inv_ngrp);
         const int grp = rem - sg * NGRP;
-        const int y = ylo + yi;
+        const int y = ylo + yr;
         const int xs = sg * SEG;
         tc.l0 = min(lbase + grp * LPG, lend);
         tc.l1 = min(tc.l0 + LPG, lend);
         const float py = (float)y + 0.5f;
         float nden;
         const float Y = row_Y(y, nden);
-        if (finite_f(Y) && fabsf(Y) < 1.0e7f && tc.l1 > tc.l0) {
+        if (finite_f(Y) && fabsf(Y) < 1.0e7f && tc.l1 > tc.l0 && yr < nreal) {
           const Axis ay = splat_axis(Y, ymax);
           ta.row0 = (int)floorf(Y) - row0;
           ta.wy0 = ay.w0;
@@ -598,7 +612,8 @@ __global__ __launch_bounds__(LSI_STREAM_MAXT) void splat_stream_kernel(SplatArgs
     if (lane == 0) { ctl[0] = y_lo; ctl[1] = y_hi; ctl[3] = ranged; }
     if (ranged)
       fill_tasks(0, lane, 64, y_lo,
-                 ((y_hi >= y_lo) ? (y_hi - y_lo + 1) : 0) * per_row, 0, Lp);
+                 pad5((y_hi >= y_lo) ? (y_hi - y_lo + 1) : 0) * per_row, 0, Lp,
+                 y_hi - y_lo + 1);
   }
   LSI_TSTAMP();
   __syncthreads();
@@ -619,15 +634,15 @@ __global__ __launch_bounds__(LSI_STREAM_MAXT) void splat_stream_kernel(SplatArgs
     if (hi >= 0) { atomicMin(&ctl[0], lo); atomicMax(&ctl[1], hi); }
     __syncthreads();
     const int ylo = ctl[0], yhi = ctl[1];
-    fill_tasks(0, tid, T, ylo, ((yhi >= ylo) ? (yhi - ylo + 1) : 0) * per_row,
-               0, Lp);
+    fill_tasks(0, tid, T, ylo, pad5((yhi >= ylo) ? (yhi - ylo + 1) : 0) * per_row,
+               0, Lp, yhi - ylo + 1);
     __syncthreads();
   }
   const int y_lo = ctl[0], y_hi = ctl[1];
   LSI_TSTAMP();
   const int nsrc = (y_hi >= y_lo) ? (y_hi - y_lo + 1) : 0;
   const size_t P = (size_t)Ht * Wt;
-  const int ntask = nsrc * per_row;
+  const int ntask = pad5(nsrc) * per_row;
 
   struct PxData { float4 d4, t0, t1, t2, m4; };
 
@@ -637,7 +652,7 @@ __global__ __launch_bounds__(LSI_STREAM_MAXT) void splat_stream_kernel(SplatArgs
       // chunk 0 of pass 0 is in the table from the prologue
       if (chunk0 > 0 || pass > 0) {
         // (the previous chunk's closing barrier protects the table)
-        fill_tasks(chunk0, tid, T, y_lo, ntask, l_begin, l_begin + Lp);
+        fill_tasks(chunk0, tid, T, y_lo, ntask, l_begin, l_begin + Lp, nsrc);
         if (tid == 0) { ctl[2] = 0; ctl[6] = 0; }
         __syncthreads();
       }
@@ -1569,7 +1584,8 @@ static int stream_plan(const LsiSplatDesc* d, int wmax, bool both,
           continue;
         const int lpg = (layers + ngrp - 1) / ngrp;
         if ((layers + lpg - 1) / lpg != ngrp) continue;  // same split, fewer groups
-        const int ntask = srows * nseg * ngrp;
+        // (the kernel pads the rows of its task order to a multiple of 5)
+        const int ntask = (srows + 4) / 5 * 5 * nseg * ngrp;
         const int cap_override = (d->reserved >> 20) & 0xff;  // experiments
         const int cap = cap_override ? cap_override * 16 : stream_cap(ntask);
         for (int c = MAXNW; c >= 4; --c) {

@@ -1,7 +1,7 @@
 """Per-workgroup phase timestamps of the stream kernel (debug flag 4).
 Needs the instrumented library: python layered-scene-inference_amd/build.py --hooks
 
-  python tools/phase_probe.py <workload> [flags] [band_rows] [threads]
+  python tools/phase_probe.py <workload> [flags] [band_rows] [threads] [shard_of]
 Stamps (tid 0): 0 start, 1 tile/windows cleared, 2 wave 0 has the row range and
 the task table, 3 task loop starts, 4 wave 0 leaves the loop, 5 closing barrier
 passed, 6 tile rows written (epilogue), 7 end.  12+w: wave w leaves the loop.
@@ -18,6 +18,7 @@ flags = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 rows = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 threads = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 nl, h, w, batch, per_gpu, cams, max_disp, bg = bench.WORKLOADS[wl]
+batch //= int(sys.argv[5]) if len(sys.argv) > 5 else 1
 dev = torch.device('cuda:0')
 tex, disp, mat = bench.make_inputs(nl, batch, h, w, cams, max_disp, 1000, dev)
 r = bench.Renderer(tex, disp, mat, max_disp, bg, 'stream', rows, threads)
