@@ -1,44 +1,39 @@
 #!/bin/bash
 # Round profile collection (run on the GPU box through gpurun):
 #   tools/collect_profiles.sh <round-tag>
-# 1. the default bench line (with cpu_baseline), 2. rocprofv3 --kernel-trace
-# --stats of the same command, 3. FETCH_SIZE and WRITE_SIZE in separate PMC
-# passes (never combined with other trace domains), 4. other workloads.
+# 1. the default bench line (cfg3; with cpu_baseline, the extras and
+#    roofline.traffic from bench.py's own two --pmc passes), 2. rocprofv3
+#    --kernel-trace --stats of the same command, 3. the other workloads and the
+#    per-rank shards of an N-GPU run, 4. SQ counters (PMC passes only, never
+#    combined with other trace domains) of the stream and sweep kernels.
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r01}
+TAG=${1:-r02}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
-python $R/bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
-for wl in cfg3 cfg4 cfg5; do
-  python $R/bench.py --workload $wl --no-cpu-baseline > $OUT/bench_$wl.json 2>> $OUT/bench_default.err
+timeout 900 python $R/bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
+for wl in cfg2 cfg4 cfg5; do
+  timeout 300 python $R/bench.py --workload $wl --no-cpu-baseline --no-extra --traffic off > $OUT/bench_$wl.json 2>> $OUT/bench_default.err
 done
-python $R/bench.py --launch eager --no-cpu-baseline > $OUT/bench_default_eager.json 2>> $OUT/bench_default.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python $R/bench.py --no-cpu-baseline > $OUT/kt_bench.json 2> $OUT/kt.err
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o f -- python $R/bench.py --no-cpu-baseline --steps 20 --warmup 5 --launch eager > /dev/null 2> $OUT/fetch.err
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o w -- python $R/bench.py --no-cpu-baseline --steps 20 --warmup 5 --launch eager > /dev/null 2> $OUT/write.err
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch3 -o f -- python $R/bench.py --workload cfg3 --no-cpu-baseline --steps 20 --warmup 5 --launch eager > /dev/null 2>> $OUT/fetch.err
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write3 -o w -- python $R/bench.py --workload cfg3 --no-cpu-baseline --steps 20 --warmup 5 --launch eager > /dev/null 2>> $OUT/write.err
+for n in 2 4 8; do
+  timeout 300 python $R/bench.py --shard-of $n --no-cpu-baseline --no-extra --traffic off > $OUT/bench_cfg3_shard_of_$n.json 2>> $OUT/bench_default.err
+done
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python $R/bench.py --no-cpu-baseline --no-extra --traffic off > $OUT/kt_bench.json 2> $OUT/kt.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt4 -o kt -- python $R/bench.py --workload cfg4 --no-cpu-baseline --no-extra --traffic off > $OUT/kt4_bench.json 2>> $OUT/kt.err
 python3 - <<PY
-import csv, glob, json, collections, re
+import csv, glob, json
 out = {}
-def kstats(path):
-    rows = list(csv.DictReader(open(path)))
-    return [r for r in rows if 'splat' in r['Name']]
-for f in glob.glob("$OUT/kt/*kernel_stats.csv"):
-    out['kernel_stats'] = kstats(f)
-def pmc(dirname, counter):
-    res = collections.defaultdict(list)
-    for f in glob.glob("$OUT/%s/*counter_collection.csv" % dirname):
-        for row in csv.DictReader(open(f)):
-            if 'splat' in row['Kernel_Name'] and row['Counter_Name'] == counter:
-                name = re.search(r'splat_\w+(<[^>]*>)?', row['Kernel_Name']).group(0)
-                res[name].append(float(row['Counter_Value']))
-    return {k: {'n': len(v), 'mean': sum(v)/len(v), 'min': min(v), 'max': max(v)} for k, v in res.items()}
-out['FETCH_SIZE_cfg2'] = pmc('fetch', 'FETCH_SIZE'); out['WRITE_SIZE_cfg2'] = pmc('write', 'WRITE_SIZE')
-out['FETCH_SIZE_cfg3'] = pmc('fetch3', 'FETCH_SIZE'); out['WRITE_SIZE_cfg3'] = pmc('write3', 'WRITE_SIZE')
-json.dump(out, open("$OUT/summary.json", "w"), indent=1)
-print(json.dumps(out, indent=1)[:3000])
+for tag, d in (('default_cfg3', 'kt'), ('cfg4', 'kt4')):
+    for f in glob.glob("$OUT/%s/**/*kernel_stats.csv" % d, recursive=True):
+        rows = list(csv.DictReader(open(f)))
+        out['kernel_stats_' + tag] = [r for r in rows if 'splat' in r['Name'] or 'disp_range' in r['Name']]
+json.dump(out, open("$OUT/rocprof_summary.json", "w"), indent=1)
+print(json.dumps(out, indent=1)[:2500])
 PY
+bash $R/tools/pmc_quick.sh splat_stream_kernel --workload cfg3 > $OUT/pmc_sq_stream_cfg3.txt 2>&1
+bash $R/tools/pmc_quick.sh splat_sweep_kernel --workload cfg4 > $OUT/pmc_sq_sweep_cfg4.txt 2>&1
+cat $OUT/pmc_sq_stream_cfg3.txt $OUT/pmc_sq_sweep_cfg4.txt
+rm -rf $OUT/kt/*/ $OUT/kt4/*/ 2>/dev/null
+find $OUT -name "*.csv" -size +2M -delete
 cat $OUT/bench_default.json
 lscpu | grep -E "Model name|^CPU\(s\)|Socket" > $OUT/host.txt; cat $OUT/host.txt
