@@ -295,6 +295,28 @@ __device__ __forceinline__ float4 ld4_stream(const float* p) {
 // configuration) with halo / exchange bands: the code and scalar registers of
 // the other modes are gone.  MODE 0: everything, decided at run time.
 // FULL: W is a multiple of the 256-pixel segment: every lane always has pixels.
+// Try-lock / unlock of one LDS lock word (byte address): writes 1, returns what
+// was there (0 = acquired).  Integer LDS exchanges are cheap; `ds_add_f32` is not.
+__device__ __forceinline__ void cell_try2(unsigned a0, unsigned a1, int& o0, int& o1) {
+  const int one = 1;
+  asm volatile(
+      "ds_wrxchg_rtn_b32 %0, %2, %4\n\tds_wrxchg_rtn_b32 %1, %3, %4\n\ts_waitcnt lgkmcnt(0)"
+      : "=&v"(o0), "=&v"(o1)
+      : "v"(a0), "v"(a1), "v"(one)
+      : "memory");
+}
+__device__ __forceinline__ int cell_try1(unsigned a0) {
+  int o;
+  const int one = 1;
+  asm volatile("ds_wrxchg_rtn_b32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)"
+               : "=&v"(o) : "v"(a0), "v"(one) : "memory");
+  return o;
+}
+__device__ __forceinline__ void cell_unlock(unsigned a0) {
+  const int zero = 0;
+  asm volatile("ds_write_b32 %0, %1" : : "v"(a0), "v"(zero) : "memory");
+}
+
 template <int LAYOUT, bool SIMPLE, int MODE, bool FULL>  // LAYOUT 0: channels-last, 1: planar
 __global__ __launch_bounds__(LSI_STREAM_MAXT) void splat_stream_kernel(SplatArgs a,
                                                            StreamCfg cfg) {
@@ -336,7 +358,11 @@ __global__ __launch_bounds__(LSI_STREAM_MAXT) void splat_stream_kernel(SplatArgs
   const int nbands = gridDim.x;
   const int row0 = band * R;
   constexpr bool LEAN = MODE != 0;
-  const int xchg = MODE == 1 ? 0 : (MODE == 2 ? 1 : cfg.exchange);
+  // MODE 3 / 4 = MODE 1 / 2 with one lock per tile CELL instead of one per tile
+  // row for the merge (short bands: few tile rows, every merge would queue at
+  // the same two row locks)
+  constexpr bool CELL = MODE >= 3;
+  const int xchg = (MODE == 1 || MODE == 3) ? 0 : ((MODE == 2 || MODE == 4) ? 1 : cfg.exchange);
   const int rows = min(xchg ? R + 1 : R, Ht - row0);  // tile rows
   const int k_lo = xchg ? (band == 0 ? -1 : row0) : row0 - 1;
   const int k_hi = xchg ? min(row0 + R, Ht) - 1 : row0 + rows - 1;
@@ -369,6 +395,11 @@ __global__ __launch_bounds__(LSI_STREAM_MAXT) void splat_stream_kernel(SplatArgs
   int* const qc = reinterpret_cast<int*>(
                       reinterpret_cast<float4*>(ctl + ((8 + R + 2 + 3) & ~3)) +
                       NW * Q) + wave * Q;                              // [NW][Q]
+  // CELL: one lock word per tile cell, behind the queues
+  int* const clk = reinterpret_cast<int*>(
+                       reinterpret_cast<float4*>(ctl + ((8 + R + 2 + 3) & ~3)) +
+                       NW * Q) + NW * Q;              // [(R + exchange) * Wt]
+  const unsigned clk_addr = (unsigned)(uintptr_t)clk;
   // Window cell c lives at slot (c >> 1) + (c & 1) * WHS: lanes are two cells
   // apart, so their 16-byte cells are adjacent slots (no bank conflicts), and
   // the odd half starts 8 slots off a 256-byte boundary so that a run of
@@ -460,6 +491,8 @@ __global__ __launch_bounds__(LSI_STREAM_MAXT) void splat_stream_kernel(SplatArgs
     for (int i = tid; i < rows * Wt; i += T)
       ctile4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   if (tid < 8 + R + 2) ctl[tid] = 0;  // tickets, turn, locks
+  if (CELL)
+    for (int i = tid; i < rows * Wt; i += T) clk[i] = 0;
   LSI_TSTAMP();
   const int nseg = (W + SEG - 1) / SEG;
   const int NGRP = compose ? cfg.ngrp : 1;  // layer groups per (row, segment)
@@ -759,7 +792,32 @@ __global__ __launch_bounds__(LSI_STREAM_MAXT) void splat_stream_kernel(SplatArgs
       int qn = 0;  // wave-uniform fill
       int q_row0 = 0;  // tile row of the current task (locks for a flush)
       bool q_use_a = false, q_use_b = false;
-      auto apply_queue = [&]() {  // caller holds the rows
+      // one value into one tile cell under that cell's lock (CELL; lanes may
+      // name the same cell: the losers of a round try again)
+      auto cell_add = [&](bool pred, int tcell, float4 v) {
+        const unsigned la = clk_addr + (unsigned)tcell * 4u;
+        while (__ballot(pred) != 0ull) {
+          if (pred && cell_try1(la) == 0) {
+            float4* e = tile4 + tcell;
+            float4 t = *e;
+            t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+            *e = t;
+            LSI_COMPILER_FENCE();
+            cell_unlock(la);
+            pred = false;
+          }
+        }
+      };
+      auto apply_queue = [&]() {  // caller holds the rows (or: CELL)
+        if (CELL && !ordered) {
+          for (int i0 = 0; i0 < qn; i0 += 64) {
+            const int i = i0 + lane;
+            const bool p = i < qn;
+            cell_add(p, p ? qc[i] : 0, p ? qv[i] : make_float4(0.f, 0.f, 0.f, 0.f));
+          }
+          qn = 0;
+          return;
+        }
         for (int i = lane; i < qn; i += 64) {
           const float4 v = qv[i];
           float* e = extras + (long)qc[i] * 4;
@@ -773,6 +831,10 @@ __global__ __launch_bounds__(LSI_STREAM_MAXT) void splat_stream_kernel(SplatArgs
       int cur_slot = 0;
       // queue full (rare): these lanes' corners go to the tile at once
       auto direct = [&](bool pred, int tcell, float4 val) {
+        if (CELL && !ordered) {
+          cell_add(pred, pred ? tcell : 0, val);
+          return;
+        }
         if (ordered) {
           wait_turn(cur_slot);  // (the turn is passed on after the merge)
         } else {
@@ -1262,12 +1324,51 @@ __global__ __launch_bounds__(LSI_STREAM_MAXT) void splat_stream_kernel(SplatArgs
           const bool use_a = q_use_a, use_b = q_use_b;
           if (ordered) {
             wait_turn(slot);
-          } else {  // ascending order: no deadlock
+          } else if (!CELL) {  // ascending order: no deadlock
             if (use_a) lock_row(t_row0);
             if (use_b) lock_row(t_row0 + 1);
           }
           if (qn != 0) apply_queue();
           float4* trow = tile4 + (long)t_row0 * Wt + t_wlo;
+          if (CELL && !ordered) {
+            // every lane locks its own pair of cells (one exchange each, both
+            // in flight), adds, releases; a lane that lost one to another
+            // wave's merge gives nothing up it still needs and tries again
+            const unsigned lrow = clk_addr + (unsigned)(t_row0 * Wt + t_wlo) * 4u;
+            for (int c = lane; c < t_wwin; c += 64) {
+              float4* wc = rb + (c >> 1) + (c & 1) * WHS;
+              const float4 v = *wc;
+              *wc = make_float4(0.f, 0.f, 0.f, 0.f);  // ready for the next task
+              const bool inside = (unsigned)(t_wlo + c) < (unsigned)Wt;
+              bool na = use_a && inside, nb = use_b && inside;
+              const unsigned la = lrow + (unsigned)c * 4u, lb = la + (unsigned)Wt * 4u;
+              while (__ballot(na || nb) != 0ull) {
+                if (na && nb) {
+                  int oa, ob;
+                  cell_try2(la, lb, oa, ob);
+                  if (oa == 0) { trow[c] = f4_fma(trow[c], v, wy0); }
+                  if (ob == 0) { trow[Wt + c] = f4_fma(trow[Wt + c], v, wy1); }
+                  LSI_COMPILER_FENCE();
+                  if (oa == 0) { cell_unlock(la); na = false; }
+                  if (ob == 0) { cell_unlock(lb); nb = false; }
+                } else if (na) {
+                  if (cell_try1(la) == 0) {
+                    trow[c] = f4_fma(trow[c], v, wy0);
+                    LSI_COMPILER_FENCE();
+                    cell_unlock(la);
+                    na = false;
+                  }
+                } else if (nb) {
+                  if (cell_try1(lb) == 0) {
+                    trow[Wt + c] = f4_fma(trow[Wt + c], v, wy1);
+                    LSI_COMPILER_FENCE();
+                    cell_unlock(lb);
+                    nb = false;
+                  }
+                }
+              }
+            }
+          } else {
 #ifndef LSI_MERGE_BATCHED
           for (int c = lane; c < t_wwin; c += 64) {
             float4* wc = rb + (c >> 1) + (c & 1) * WHS;
@@ -1304,9 +1405,10 @@ __global__ __launch_bounds__(LSI_STREAM_MAXT) void splat_stream_kernel(SplatArgs
             if (use_b && ib) trow[Wt + cb] = f4_fma(b1, xb, wy1);
           }
 #endif
+          }
           if (ordered) {
             pass_turn(slot);
-          } else {
+          } else if (!CELL) {
             if (use_b) unlock_row(t_row0 + 1);
             if (use_a) unlock_row(t_row0);
           }
@@ -1459,8 +1561,8 @@ int stream_cap(int ntask) {
 }
 
 size_t stream_lds_bytes(const LsiSplatDesc* d, int tile_rows, int nw, int wmax,
-                        int cap, int qcap) {  // (tile_rows: both tiles counted)
-  return (size_t)nw * (2 * (((wmax / 2 + 15) & ~15) + 8)) * 16 +
+                        int cap, int qcap, int cell = 0) {  // (tile_rows: both tiles counted)
+  return (cell ? (size_t)tile_rows * d->Wt * 4 : 0) + (size_t)nw * (2 * (((wmax / 2 + 15) & ~15) + 8)) * 16 +
          (size_t)nw * wmax +
          (size_t)tile_rows * d->Wt * 16 +
          (size_t)cap * (sizeof(TaskA) + sizeof(TaskB) + sizeof(TaskC)) +
@@ -1550,7 +1652,7 @@ size_t lsi_stream_workspace_bytes(const LsiSplatDesc* d) {
 // with no barrier -- bounded either by the waves' own latency chains or by the
 // CU's instruction issue shared with the co-resident workgroups -- then the
 // last waves finish alone (tail), then the epilogue.
-struct StreamPlan { int R, nw, xch, ngrp, lpg, cap, qcap; size_t lds; double est; };
+struct StreamPlan { int R, nw, xch, ngrp, lpg, cap, qcap, cell; size_t lds; double est; };
 
 static int stream_plan(const LsiSplatDesc* d, int wmax, bool both,
                        StreamPlan* out) {
@@ -1567,6 +1669,7 @@ static int stream_plan(const LsiSplatDesc* d, int wmax, bool both,
   const bool compose = (d->flags & LSI_COMPOSE) != 0;
   const int layers = compose ? d->L : 1;
   const int npass = compose ? 1 : d->L;
+  const bool lean = compose && !(d->flags & LSI_HAS_MASK);
   const int force_mode = (d->reserved >> 16) & 3;  // experiments: 1 halo, 2 exchange
   StreamPlan best; best.est = -1.0; best.nw = 0;
   for (int xch = 0; xch <= (both ? 0 : 1); ++xch) {
@@ -1588,15 +1691,26 @@ static int stream_plan(const LsiSplatDesc* d, int wmax, bool both,
         const int ntask = (srows + 4) / 5 * 5 * nseg * ngrp;
         const int cap_override = (d->reserved >> 20) & 0xff;  // experiments
         const int cap = cap_override ? cap_override * 16 : stream_cap(ntask);
+        // merge exclusion: one lock per tile row, or (lean variants, short
+        // bands) one per tile cell -- experiments: reserved bits 18-19 force
+        // 1 = row locks, 2 = cell locks
+        const int force_cell = (d->reserved >> 18) & 3;
+        for (int cell = 0; cell <= 1; ++cell) {
+        // (measured: cell locks win while a band has few tasks -- cfg2 25.9 ->
+        // 19.8 us, a 4-view shard of cfg3 29.6 -> 27.0 us -- and lose once the
+        // row interleave alone keeps the row locks free: cfg5 105 -> 121 us)
+        const bool cell_ok = lean && !both && R + xch <= 8 && ntask <= 40;
+        if (cell != (cell_ok ? 1 : 0) && !(force_cell == 1 && cell == 0)) continue;
+        if (force_cell == 1 && cell == 1) continue;
         for (int c = MAXNW; c >= 4; --c) {
           if (d->tune_threads > 0 && c != (d->tune_threads + 63) / 64) continue;
           int q = 64;
           const int trows = (R + xch) * (both ? 2 : 1);
           while (q >= 16 &&
-                 stream_lds_bytes(d, trows, c, wmax, cap, q) > lds_cap)
+                 stream_lds_bytes(d, trows, c, wmax, cap, q, cell) > lds_cap)
             q /= 2;
           if (q < 16) continue;
-          const size_t lds = stream_lds_bytes(d, trows, c, wmax, cap, q);
+          const size_t lds = stream_lds_bytes(d, trows, c, wmax, cap, q, cell);
           long k = (long)(160 * 1024 / lds);   // co-resident workgroups per CU
           if (k > MAXNW / c) k = MAXNW / c;    // (128 VGPRs: 16 waves per CU)
           if (k < 1) k = 1;
@@ -1610,15 +1724,21 @@ static int stream_plan(const LsiSplatDesc* d, int wmax, bool both,
           const double per_item = fmax(t_lat, (double)(c * kk) * t_issue);
           // waves take tasks in rounds: the last round is rarely full
           const double task_rounds = ceil((double)ntask / c);
-          const double loop = task_rounds * (lpg * per_item + 1600.0);
+          // a merge holds its two row locks for ~900 cycles: with few tile
+          // rows the merges of a band queue up behind each other
+          const double merge_serial =
+              cell ? 0.0 : (double)ntask * 900.0 / fmax(1.0, (R + xch) / 2.0);
+          const double loop =
+              fmax(task_rounds * (lpg * per_item + 1600.0), merge_serial);
           const double epi = (double)(R + xch) * d->Wt / (c * 64.0) * 70.0 +
                              2500.0 + 16000.0 * xch;
           const double est = (double)rounds * (fixed + npass * (loop + epi));
           if (best.est < 0.0 || est < best.est) {
             best.est = est; best.R = R; best.nw = c; best.xch = xch;
             best.ngrp = ngrp; best.lpg = lpg; best.cap = cap; best.qcap = q;
-            best.lds = lds;
+            best.lds = lds; best.cell = cell;
           }
+        }
         }
       }
     }
@@ -1628,9 +1748,9 @@ static int stream_plan(const LsiSplatDesc* d, int wmax, bool both,
   static const bool verbose = getenv("LSI_STREAM_VERBOSE") != nullptr;
   if (verbose)
     fprintf(stderr, "lsi stream plan: R=%d waves=%d %s layer-groups=%d x %d "
-            "table=%d queue=%d est=%.0f cycles lds=%zu\n", best.R, best.nw,
+            "table=%d queue=%d %s-locks est=%.0f cycles lds=%zu\n", best.R, best.nw,
             best.xch ? "exchange" : "halo", best.ngrp, best.lpg, best.cap,
-            best.qcap, best.est, best.lds);
+            best.qcap, best.cell ? "cell" : "row", best.est, best.lds);
   return LSI_OK;
 }
 
@@ -1701,13 +1821,15 @@ int lsi_stream_launch(const SplatArgs& a, hipStream_t stream) {
   dim3 grid((d->Ht + R - 1) / R, d->B);
   const bool simple = (d->tune_window & LSI_STREAM_SIMPLE_BIT) != 0;
   const bool lean = (d->flags & LSI_COMPOSE) && !(d->flags & LSI_HAS_MASK);
-  const int mode = lean ? (cfg.exchange ? 2 : 1) : 0;
+  const int mode = lean ? (cfg.exchange ? 2 : 1) + (plan.cell ? 2 : 0) : 0;
   const void* fn;
 #define LSI_PICK2(L_, S_, M_)                                              \
   (full ? (const void*)splat_stream_kernel<L_, S_, M_, true>                \
         : (const void*)splat_stream_kernel<L_, S_, M_, false>)
 #define LSI_PICK(L_, S_) \
-  (mode == 1 ? LSI_PICK2(L_, S_, 1) : mode == 2 ? LSI_PICK2(L_, S_, 2) : LSI_PICK2(L_, S_, 0))
+  (mode == 1 ? LSI_PICK2(L_, S_, 1) : mode == 2 ? LSI_PICK2(L_, S_, 2) :   \
+   mode == 3 ? LSI_PICK2(L_, S_, 3) : mode == 4 ? LSI_PICK2(L_, S_, 4) :   \
+   LSI_PICK2(L_, S_, 0))
   const bool full = d->W % SEG == 0;
   if (layout == 0)
     fn = simple ? LSI_PICK(0, true) : LSI_PICK(0, false);
