@@ -15,30 +15,45 @@
 // routing the rare affected corners through an exact slow path.
 //
 // Structure.  Workgroup = (band of target rows, batch element b), NW <= 16 waves.
-//   task  = (source row y, 256-pixel segment j), all layers of the pass.
-//     prologue wave 0 finds the band's source rows (analytic inverse of Y(y),
-//             verified with the exact fp32 Y) and fills the task table while
-//             the other waves clear the band's tile.
-//     x-pass  waves draw tasks from a ticket counter.  Lanes load 4 consecutive
-//             pixels (dwordx4), project them, and add V*wx0 / V*wx1
-//             (V = (r,g,b,1)*pixel weight) into the task's PRIVATE window of
-//             float4 cells in LDS by plain RMW.  Lanes are 4 pixels apart, so
-//             their cells are distinct whenever floor(X) is strictly
-//             increasing across the wave (checked); otherwise the lanes are
-//             ranked per cell with an integer LDS atomic and the RMW is issued
-//             rank by rank.
-//     barrier
-//     merge   every 64-cell unit of the band's LDS tile is owned by one wave,
-//             which adds window[cell] * wy of each task that touches its row
-//             (deterministic summation order).
-//     barrier (only if another step follows)
-//   Corners that the factorisation cannot represent exactly (clamped products,
-//   cells outside the window because the disparity leaves [0, max_disp]) are
-//   added to the tile with fp32 LDS atomics -- exact for any input, slow only
-//   when such corners are common.
-//   epilogue: (tile + background) normalised, each output written once.  With
-//   source-row bands (cfg.exchange) the first and last tile rows are shared
-//   with the neighbouring bands and combined through the workspace.
+//   task  = (source row y, 256-pixel segment j, group of layers).
+//   prologue  wave 0 finds the band's source rows (analytic inverse of Y(y),
+//             verified with the exact fp32 Y) and fills the task table (row
+//             geometry, clamp thresholds, window origin and size per task)
+//             while the other waves clear the band's tile.  One barrier.
+//   task loop NO barrier inside.  Waves draw tasks from a ticket counter; the
+//             task order puts consecutive tickets on source rows a fifth of
+//             the band apart, so the tasks in flight merge into different
+//             tile rows.  Per task and layer an ITEM = 4 consecutive pixels
+//             per lane (dwordx4 loads).  Two register sets take turns: each is
+//             refilled right after the projection has consumed it, so two
+//             items of loads are in flight per wave (the loaded HBM latency is
+//             about two item periods).  The pixels are projected as packed
+//             pairs and V * wx (V = (r,g,b,1) * pixel weight) is added into
+//             the wave's PRIVATE window of float4 cells in LDS by plain
+//             read-modify-write -- route A: the lane's 4 pixels are summed
+//             into the 4 cells they can reach in registers first (4 RMWs per
+//             lane instead of 8; needs floor(X) strictly increasing across
+//             the wave: one DPP compare + ballot); route B: per pixel; route C:
+//             any order of cells, the lanes of a cell elected one at a time
+//             through a byte table.  Cells live even/odd interleaved so that
+//             lanes two cells apart hit consecutive 16-byte slots.
+//   merge     after a task's last layer the wave adds window * (wy0, wy1) into
+//             the task's two tile rows and clears the window: under the two
+//             ROW locks (long bands), under per-CELL try-locks taken with one
+//             integer LDS exchange per lane (short bands, where every merge
+//             would queue at the same two row locks: kernel modes 3 / 4), or,
+//             with LSI_DETERMINISTIC, strictly in ticket order.
+//   Corners the factorisation cannot represent exactly (a side whose product
+//   with only the LARGER row weight survives the clamp; cells outside the
+//   window because the disparity leaves [0, max_disp]) go to a small per-wave
+//   queue of (tile cell, value) and are added to the tile at the merge --
+//   exact for any input, slow only when such corners are common.  Windows
+//   extend beyond the image: cells left of column 0 / right of column Wt-1 are
+//   dummies the merge drops, which is the reference's border rule.
+//   epilogue  one barrier, then (tile + background) normalised, each output
+//   written once.  With source-row bands (cfg.exchange) the first and last
+//   tile rows are shared with the neighbouring bands and combined through the
+//   workspace by whichever band finishes second (no spinning).
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>

@@ -8,17 +8,21 @@
 //
 // * Workgroup = (tile of TH x TW target cells, batch element[, layer]); the
 //   tile's r/g/b/w sums live in LDS (64 KB at 32 x 128 cells).
-// * Work item = (layer, source row, 64-pixel segment).  A prologue keeps the
-//   items whose target rows can intersect the tile (Y is linear-fractional in
-//   x and d: extremes at the segment's four (x, disparity-range) corners; the
-//   per-layer disparity range comes from disp_range_kernel) in an LDS list.
-//   Short segments follow a tilted / keystoned row closely: ~5 % more pixels
-//   are projected than land in the tile (whole rows: 20 %, and 1.5x imbalance
-//   between workgroups).
-// * The 16 waves draw QUADS of items by ticket (no barriers); 16 lanes own an
-//   item, each lane 4 consecutive pixels (16-byte loads, the next quad's in
-//   flight while this one is processed).  Concurrent waves take quads far
-//   apart in the list, so they rarely meet in the tile.
+// * Work item = (source row, layer, group of four 64-pixel segments) with a
+//   4-bit mask of the segments whose target rows can intersect the tile (Y is
+//   linear-fractional in x and d: extremes at a segment's four (x,
+//   disparity-range) corners; the per-layer disparity range comes from
+//   disp_range_kernel).  A prologue writes the items that have any such
+//   segment to an LDS list in (row, layer) order.  Short segments follow a
+//   tilted / keystoned row closely: ~5 % more pixels are projected than land
+//   in the tile (whole rows: 20 %).
+// * The 16 waves draw items by ticket (no barriers; the hardware favours the
+//   oldest waves of a SIMD, so a static split leaves the last waves running
+//   long after the first).  16 lanes own a segment, each lane 4 consecutive
+//   pixels (16-byte loads, unconditional, the next item's in flight while this
+//   one is processed).  Ticket t maps to item (t % 16) * n/16 + t / 16: the 16
+//   most recent tickets are in 16 bands of source rows several rows apart, so
+//   concurrent waves rarely meet in the tile.
 // * Every pixel is projected with the exact index arithmetic of the other
 //   paths and each corner is added to its tile cell by a plain LDS
 //   read-modify-write under a per-cell spin lock.  The two left corners
