@@ -380,31 +380,52 @@ __global__ __launch_bounds__(256) void splat_bwd_pre_kernel(
   G[i] = make_float4(g0 * inv, g1 * inv, g2 * inv, gw);
 }
 
-__global__ __launch_bounds__(256) void splat_bwd_kernel(
-    SplatArgs a, const float4* __restrict__ G, float* __restrict__ g_tex,
-    float* __restrict__ g_disp, float* __restrict__ g_mask) {
-  const LsiSplatDesc& d = a.d;
-  const int b = blockIdx.y, l = blockIdx.z;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= d.H * d.W) return;
-  const int y = i / d.W, x = i - y * d.W;
-  const float* __restrict__ m = a.M + 16 * b;
-  const float dv = a.disp[l * d.disp_sl + b * d.disp_sb + y * d.disp_sy +
-                          x * d.disp_sx];
-  const bool has_mask = d.flags & LSI_HAS_MASK;
-  const float mk = has_mask ? a.mask[l * d.mask_sl + b * d.mask_sb +
-                                     y * d.mask_sy + x * d.mask_sx]
-                            : 1.0f;
-  Proj p;
-  project_px(m, (float)x + 0.5f, (float)y + 0.5f, dv, mk, d.trg_downsampling,
-             d.max_disp, d.zbuf_scale, d.Ht, d.Wt, p);
-  const float* tp =
-      a.tex + l * d.tex_sl + b * d.tex_sb + y * d.tex_sy + x * d.tex_sx;
-  const float t0 = tp[0], t1 = tp[d.tex_sc], t2 = tp[2 * d.tex_sc];
-  const size_t P = (size_t)d.Ht * d.Wt;
-  const int lo = (d.flags & LSI_COMPOSE) ? 0 : l;
-  const float4* Gb = G + ((size_t)lo * d.B + b) * P;
+// grid (ceil(W / 256), ceil(H / BWD_ROWS), L * B): no integer division per thread.  SIMPLE_M
+// (decided per batch element from M itself, uniform per block): normaliser == 1
+// and target disparity == source disparity, i.e. M rows 2, 3 = (0,0,1,0),
+// (0,0,0,1) -- every rectified pair.  Then u = q0 * s exactly (x / 1 == x), so
+// the corner cells are the forward's bit for bit, and the projection and its
+// gradient need no division at all.
+struct BwdPx { float gt0, gt1, gt2, gm, gd; };
 
+template <bool SIMPLE_M>
+__device__ __forceinline__ BwdPx splat_bwd_core(
+    const LsiSplatDesc& d, const float* __restrict__ m, int y, int x, float dv,
+    float mk, float t0, float t1, float t2, const float4* __restrict__ Gb) {
+  const float s = d.trg_downsampling;
+  const float inv_md = div_rn(1.0f, d.max_disp);
+  Proj p;
+  if (SIMPLE_M) {
+    const float px = (float)x + 0.5f, py = (float)y + 0.5f;
+    p.q0 = mrow(m, 0, px, py, dv);
+    p.q1 = mrow(m, 1, px, py, dv);
+    p.q3 = dv;
+    p.nden = 1.0f;
+    p.dd = dv;
+    p.zw = zbuffer_weight(dv * inv_md, d.zbuf_scale);
+    p.pw = p.zw * mk;
+    const float X = p.q0 * s - 0.5f, Y = p.q1 * s - 0.5f;
+    p.ok = finite_f(X) && finite_f(Y);
+    p.ax = splat_axis(X, (float)d.Wt - 1.0f);
+    p.ay = splat_axis(Y, (float)d.Ht - 1.0f);
+    const float wt = (float)d.Wt;
+    p.w[0] = clamp_small(p.ax.w0 * p.ay.w0);
+    p.w[1] = clamp_small(p.ax.w1 * p.ay.w0);
+    p.w[2] = clamp_small(p.ax.w0 * p.ay.w1);
+    p.w[3] = clamp_small(p.ax.w1 * p.ay.w1);
+    if (p.ok) {
+      p.idx[0] = (int)(p.ax.c0s + p.ay.c0s * wt);
+      p.idx[1] = (int)(p.ax.c1s + p.ay.c0s * wt);
+      p.idx[2] = (int)(p.ax.c0s + p.ay.c1s * wt);
+      p.idx[3] = (int)(p.ax.c1s + p.ay.c1s * wt);
+    } else {
+      p.idx[0] = p.idx[1] = p.idx[2] = p.idx[3] = 0;
+      p.w[0] = p.w[1] = p.w[2] = p.w[3] = 0.0f;
+    }
+  } else {
+    project_px(m, (float)x + 0.5f, (float)y + 0.5f, dv, mk, s, d.max_disp,
+               d.zbuf_scale, d.Ht, d.Wt, p);
+  }
   float gt0 = 0.f, gt1 = 0.f, gt2 = 0.f, gpw = 0.f;
   float gwk[4];
 #pragma unroll
@@ -419,11 +440,11 @@ __global__ __launch_bounds__(256) void splat_bwd_kernel(
     gpw += p.w[k] * S;
     gwk[k] = p.pw * S;
   }
-  const size_t o = ((size_t)l * d.B + b) * ((size_t)d.H * d.W) + i;
-  g_tex[3 * o + 0] = gt0 * p.pw;
-  g_tex[3 * o + 1] = gt1 * p.pw;
-  g_tex[3 * o + 2] = gt2 * p.pw;
-  if (g_mask) g_mask[o] = gpw * p.zw;
+  BwdPx r;
+  r.gt0 = gt0 * p.pw;
+  r.gt1 = gt1 * p.pw;
+  r.gt2 = gt2 * p.pw;
+  r.gm = gpw * p.zw;
 
   // corner weights -> X, Y.  w_tl = wx0*wy0 etc.; d wx0/dX = -v0, d wx1/dX = +v1
   const float gX = -p.ax.v0 * (gwk[0] * p.ay.w0 + gwk[2] * p.ay.w1) +
@@ -431,17 +452,110 @@ __global__ __launch_bounds__(256) void splat_bwd_kernel(
   const float gY = -p.ay.v0 * (gwk[0] * p.ax.w0 + gwk[1] * p.ax.w1) +
                    p.ay.v1 * (gwk[2] * p.ax.w0 + gwk[3] * p.ax.w1);
   // pw = zw * mask ; zw = exp((clip(xn,0,1)-.5)*scale)*[xn>0], xn = D/max_disp
-  const float xn = p.dd / d.max_disp;
+  const float xn = SIMPLE_M ? p.dd * inv_md : p.dd / d.max_disp;
   const float inr = (xn >= 0.0f && xn <= 1.0f) ? 1.0f : 0.0f;
-  const float gD = gpw * mk * p.zw * d.zbuf_scale * inr / d.max_disp;
+  const float gD = SIMPLE_M
+                       ? gpw * mk * p.zw * d.zbuf_scale * inr * inv_md
+                       : gpw * mk * p.zw * d.zbuf_scale * inr / d.max_disp;
   // u = q0/n' * s, v = q1/n' * s, D = q3/n'
-  const float inv_n = 1.0f / p.nden;
-  const float s = d.trg_downsampling;
-  const float gq0 = gX * s * inv_n, gq1 = gY * s * inv_n, gq3 = gD * inv_n;
-  const float gn = -(gq0 * p.q0 + gq1 * p.q1 + gq3 * p.q3) * inv_n;
-  float gd = gq0 * m[3] + gq1 * m[7] + gn * m[11] + gq3 * m[15];
+  float gd;
+  if (SIMPLE_M) {  // n' == 1, M[2][3] == 0, M[3][3] == 1
+    gd = (gX * s) * m[3] + (gY * s) * m[7] + gD;
+  } else {
+    const float inv_n = 1.0f / p.nden;
+    const float gq0 = gX * s * inv_n, gq1 = gY * s * inv_n, gq3 = gD * inv_n;
+    const float gn = -(gq0 * p.q0 + gq1 * p.q1 + gq3 * p.q3) * inv_n;
+    gd = gq0 * m[3] + gq1 * m[7] + gn * m[11] + gq3 * m[15];
+  }
   if (!p.ok) gd = 0.0f;
-  g_disp[o] = gd;
+  r.gd = gd;
+  return r;
+}
+
+// One thread = one column x of BWD_ROWS consecutive source rows.  A wave with a
+// single pixel per lane is a chain of dependent memory round trips (arguments,
+// inputs, the four gathers, stores) with nothing to overlap them; here the next
+// row's inputs are in flight while the current row gathers and computes, and
+// the per-wave setup is paid once per BWD_ROWS rows (one pixel per wave-lane:
+// 294 us at config 3; this loop: see DESIGN.md 4.5).
+constexpr int BWD_ROWS = 8;
+
+struct BwdIn { float dv, mk, t0, t1, t2; };
+
+template <bool SIMPLE_M>
+__device__ __forceinline__ void splat_bwd_rows(
+    const SplatArgs& a, const float* __restrict__ m, int b, int l, int y0, int x,
+    const float4* __restrict__ G, float* __restrict__ g_tex,
+    float* __restrict__ g_disp, float* __restrict__ g_mask) {
+  const LsiSplatDesc& d = a.d;
+  const bool has_mask = d.flags & LSI_HAS_MASK;
+  const float* dbase = a.disp + l * d.disp_sl + b * d.disp_sb + x * d.disp_sx;
+  const float* tbase = a.tex + l * d.tex_sl + b * d.tex_sb + x * d.tex_sx;
+  const float* mbase =
+      has_mask ? a.mask + l * d.mask_sl + b * d.mask_sb + x * d.mask_sx : nullptr;
+  auto load = [&](int y) {  // (rows past the end re-read the last row: no branch)
+    const int yc = min(y, d.H - 1);
+    BwdIn in;
+    in.dv = dbase[yc * d.disp_sy];
+    const float* tp = tbase + yc * d.tex_sy;
+    in.t0 = tp[0]; in.t1 = tp[d.tex_sc]; in.t2 = tp[2 * d.tex_sc];
+    in.mk = has_mask ? mbase[yc * d.mask_sy] : 1.0f;
+    return in;
+  };
+  const size_t P = (size_t)d.Ht * d.Wt;
+  const int lo = (d.flags & LSI_COMPOSE) ? 0 : l;
+  const float4* Gb = G + ((size_t)lo * d.B + b) * P;
+  const size_t obase = ((size_t)l * d.B + b) * ((size_t)d.H * d.W) + x;
+  BwdIn cur = load(y0);
+#pragma unroll
+  for (int r = 0; r < BWD_ROWS; ++r) {
+    const int y = y0 + r;
+    const BwdIn nxt = load(y + 1);
+    if (y < d.H) {
+      const BwdPx g = splat_bwd_core<SIMPLE_M>(d, m, y, x, cur.dv, cur.mk, cur.t0,
+                                               cur.t1, cur.t2, Gb);
+      const size_t o = obase + (size_t)y * d.W;
+      g_tex[3 * o + 0] = g.gt0;
+      g_tex[3 * o + 1] = g.gt1;
+      g_tex[3 * o + 2] = g.gt2;
+      if (g_mask) g_mask[o] = g.gm;
+      g_disp[o] = g.gd;
+    }
+    cur = nxt;
+  }
+}
+
+__global__ __launch_bounds__(256) void splat_bwd_kernel(
+    SplatArgs a, float inv_b, const float4* __restrict__ G,
+    float* __restrict__ g_tex, float* __restrict__ g_disp,
+    float* __restrict__ g_mask) {
+  const LsiSplatDesc& d = a.d;
+  const int y0 = blockIdx.y * BWD_ROWS;
+  // blockIdx.z = l * B + b
+  int l = (int)((float)blockIdx.z * inv_b);
+  int b = (int)blockIdx.z - l * d.B;
+  if (b < 0) { --l; b += d.B; }
+  if (b >= d.B) { ++l; b -= d.B; }
+  const int x = blockIdx.x * 256 + threadIdx.x;
+  if (x >= d.W) return;
+  const float* __restrict__ m = a.M + 16 * b;
+  const bool simple_m = m[8] == 0.0f && m[9] == 0.0f && m[10] == 1.0f &&
+                        m[11] == 0.0f && m[12] == 0.0f && m[13] == 0.0f &&
+                        m[14] == 0.0f && m[15] == 1.0f;
+  if (simple_m)
+    splat_bwd_rows<true>(a, m, b, l, y0, x, G, g_tex, g_disp, g_mask);
+  else
+    splat_bwd_rows<false>(a, m, b, l, y0, x, G, g_tex, g_disp, g_mask);
+}
+
+static void launch_bwd(const SplatArgs& a, const float4* G, float* g_tex,
+                       float* g_disp, float* g_mask, hipStream_t stream) {
+  const LsiSplatDesc* d = &a.d;
+  hipLaunchKernelGGL(splat_bwd_kernel,
+                     dim3((d->W + 255) / 256, (d->H + BWD_ROWS - 1) / BWD_ROWS,
+                          d->L * d->B),
+                     dim3(256), 0, stream, a, 1.0f / (float)d->B, G, g_tex, g_disp,
+                     g_mask);
 }
 
 // Pre-pass of lsi_splat_bwd_both: layer l's canvas receives the gradient of
@@ -710,10 +824,9 @@ int lsi_splat_bwd(const LsiSplatDesc* d, const float* tex, const float* disp,
   a.ws_bytes = 0;
   a.nch = 4; a.ncanv = 1; a.shared = 0; a.band_rows = 0;
   a.out_img_c = a.out_wts_c = nullptr;
-  const int npx = d->H * d->W;
-  hipLaunchKernelGGL(splat_bwd_kernel, dim3((npx + 255) / 256, d->B, d->L),
-                     dim3(256), 0, stream, a, (const float4*)workspace, g_tex,
-                     g_disp_in, (d->flags & LSI_HAS_MASK) ? g_mask : nullptr);
+  if ((long)d->B * d->L > 65535 || d->H > 65535) return LSI_EINVAL;  // grid.y / z
+  launch_bwd(a, (const float4*)workspace, g_tex, g_disp_in,
+             (d->flags & LSI_HAS_MASK) ? g_mask : nullptr, stream);
   return hipGetLastError() == hipSuccess ? LSI_OK : LSI_ELAUNCH;
 }
 
@@ -780,10 +893,9 @@ int lsi_splat_bwd_both(const LsiSplatDesc* d, const float* tex,
   a.ws_bytes = 0;
   a.nch = 4; a.ncanv = 1; a.shared = 0; a.band_rows = 0;
   a.out_img_c = a.out_wts_c = nullptr;
-  const int npx = d->H * d->W;
-  hipLaunchKernelGGL(splat_bwd_kernel, dim3((npx + 255) / 256, d->B, d->L),
-                     dim3(256), 0, stream, a, (const float4*)workspace, g_tex,
-                     g_disp_in, (d->flags & LSI_HAS_MASK) ? g_mask : nullptr);
+  if ((long)d->B * d->L > 65535 || d->H > 65535) return LSI_EINVAL;  // grid.y / z
+  launch_bwd(a, (const float4*)workspace, g_tex, g_disp_in,
+             (d->flags & LSI_HAS_MASK) ? g_mask : nullptr, stream);
   return hipGetLastError() == hipSuccess ? LSI_OK : LSI_ELAUNCH;
 }
 
