@@ -3,7 +3,7 @@
 // sampling.py:171-254 and helpers.py:82-85,116-137,180-193 fused in.
 //
 // Two of the four kernel families behind lsi_splat_fwd (include/lsi_hip.h; the
-// others: lsi_splat_stream.hip, lsi_splat_tile.hip):
+// others: lsi_splat_stream.hip, lsi_splat_tile.hip + lsi_splat_sweep.hip):
 //
 //  LSI_PATH_ATOMIC   any projection matrix.  One thread per source pixel,
 //                    fp32 global atomics (global_atomic_add_f32) into

@@ -70,15 +70,23 @@ __global__ __launch_bounds__(256) void disp_range_kernel(SplatArgs a,
   if (vec4) {  // unit pixel stride, 16-byte aligned rows, W % 4 == 0
     const int w4 = d.W >> 2, n4 = (r1 - r0) * w4;
     const float rcp_w4 = 1.0f / (float)w4;
-    for (int i = threadIdx.x; i < n4; i += 256) {  // i < 2^22: H * W < 2^24
+    auto at = [&](int i) {  // i < 2^22 (H * W < 2^24): exact in fp32
       int y = (int)((float)i * rcp_w4);
       int x4 = i - y * w4;
       if (x4 < 0) { --y; x4 += w4; }
       if (x4 >= w4) { ++y; x4 -= w4; }
-      const float4 v = reinterpret_cast<const float4*>(
-          base + (long)(r0 + y) * d.disp_sy)[x4];
-      lo = fminf(fminf(lo, v.x), fminf(fminf(v.y, v.z), v.w));  // skip NaNs
-      hi = fmaxf(fmaxf(hi, v.x), fmaxf(fmaxf(v.y, v.z), v.w));
+      return reinterpret_cast<const float4*>(base + (long)(r0 + y) * d.disp_sy)[x4];
+    };
+    // four independent 16-byte loads in flight per thread
+    for (int i = threadIdx.x; i < n4; i += 1024) {
+      float4 v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = at(min(i + 256 * k, n4 - 1));
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        lo = fminf(fminf(lo, v[k].x), fminf(fminf(v[k].y, v[k].z), v[k].w));  // skip NaNs
+        hi = fmaxf(fmaxf(hi, v[k].x), fmaxf(fmaxf(v[k].y, v[k].z), v[k].w));
+      }
     }
   } else {
     for (int y = r0; y < r1; ++y)
