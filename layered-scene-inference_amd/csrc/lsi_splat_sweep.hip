@@ -69,7 +69,10 @@ constexpr int SWEEP_BPW = (SWEEP_CAP / 64 + SWEEP_NW - 1) / SWEEP_NW;  // blocks
 constexpr int SEGW = 64;        // source pixels per item (16 lanes x 4)
 
 struct SweepCfg {
-  int th;          // tile height (cells)
+  int th;          // nominal tile height (cells): equal-height tiles
+  int thmax;       // tile rows allocated in LDS (adaptive tiles may be taller)
+  int nty;         // tiles per column of tiles
+  int adaptive;    // 1: tile rows cut by source-row count (see the kernel)
   int tiles_x;
   int nq4;         // groups of four 64-pixel segments per source row
   int all_layers;  // 1: compose, every layer sums into the tile; 0: grid.z = layer
@@ -131,14 +134,15 @@ __global__ __launch_bounds__(SWEEP_T, LSI_SWEEP_WGS) void splat_sweep_kernel(
   const int b = blockIdx.y;
   const int l_begin = c.all_layers ? 0 : (int)blockIdx.z;
   const int NLW = c.all_layers ? d.L : 1;  // layers this workgroup sums
-  const int TH = c.th, NC = TH << TWL, NCP = (TH + 2) << TWL;
+  // c.thmax rows of cells are allocated; the tile's own height is decided below
+  const int NCP = (c.thmax + 2) << TWL;
   const int tile_y = blockIdx.x / c.tiles_x, tile_x = blockIdx.x - tile_y * c.tiles_x;
-  const int ty0 = tile_y * TH, tx0 = tile_x * TW;
+  const int tx0 = tile_x * TW;
   const int Ht = d.Ht, Wt = d.Wt, H = d.H, W = d.W;
 
-  // r g b w sums and one lock per cell, rows -1 .. TH (slot row r + 1)
-  float4* tile = reinterpret_cast<float4*>(smem);   // [TH + 2][TW]
-  int* locks = reinterpret_cast<int*>(tile + NCP);  // [TH + 2][TW]
+  // r g b w sums and one lock per cell, rows -1 .. thmax (slot row r + 1)
+  float4* tile = reinterpret_cast<float4*>(smem);   // [thmax + 2][TW]
+  int* locks = reinterpret_cast<int*>(tile + NCP);  // [thmax + 2][TW]
   int* list = locks + NCP;                          // [SWEEP_CAP] accepted items
   int* cnt = list + SWEEP_CAP;                      // [64] per-block counts
   int* ctl = cnt + 64;                              // [1] list fill
@@ -150,11 +154,8 @@ __global__ __launch_bounds__(SWEEP_T, LSI_SWEEP_WGS) void splat_sweep_kernel(
   for (int k = 0; k < 16; ++k) m[k] = a.M[16 * b + k];
   const float s = d.trg_downsampling, zscale = d.zbuf_scale;
   const float inv_md = div_rn(1.0f, d.max_disp);
-  const float ty0f = (float)ty0, tx0f = (float)tx0;
-  // the part of the tile inside the image, and the acceptance window of the
-  // top-left cell (x0, y0) around it
-  const int th_eff = min(TH, Ht - ty0), tw_eff = min(TW, Wt - tx0);
-  const float ay_lo = (float)(ty0 - 1), ay_hi = (float)(ty0 + th_eff - 1);
+  const float tx0f = (float)tx0;
+  const int tw_eff = min(TW, Wt - tx0);
   const float ax_lo = (float)(tx0 - 1), ax_hi = (float)(tx0 + tw_eff - 1);
 
   for (int i = tid; i < NCP; i += SWEEP_T) {
@@ -171,6 +172,95 @@ __global__ __launch_bounds__(SWEEP_T, LSI_SWEEP_WGS) void splat_sweep_kernel(
     lrange[tid] = dr;
   }
   __syncthreads();
+
+  // ---- the tile's target rows [ty0, ty0 + th_eff).  Equal-height tiles get
+  // unequal numbers of source pixels under a keystone (config 4: the heaviest
+  // tile 1.37x the mean, and the heaviest tile is the kernel's time), so the
+  // nty tiles of a column split the rows by SOURCE rows instead: a histogram of
+  // where the centre pixel of every source row lands (mid disparity), cut into
+  // nty equal parts, each tile at most c.thmax rows (config 4: 135 -> 122 us).  Every workgroup of the
+  // batch element computes the same cuts from the same data.
+  int ty0 = tile_y * c.th, ty1 = min(ty0 + c.th, Ht);
+  if (c.adaptive) {
+    int* hist = list;                 // [Ht] (Ht <= SWEEP_CAP), then its prefix
+    int* cut = cnt;                   // [nty + 1] (nty <= 63)
+    for (int i = tid; i < Ht; i += SWEEP_T) hist[i] = 0;
+    if (tid == 0) ctl[2] = 0;
+    __syncthreads();
+    float dlo = __builtin_inff(), dhi = -__builtin_inff();
+    for (int k = 0; k < NLW; ++k) {
+      dlo = fminf(dlo, lrange[k].x);
+      dhi = fmaxf(dhi, lrange[k].y);
+    }
+    const float dm = 0.5f * (dlo + dhi);
+    if (finite_f(dm)) {
+      // 8 sample columns per source row; a sample counts where it lands if it
+      // lands inside the target image (what falls outside costs almost nothing)
+      for (int i = tid; i < H * 8; i += SWEEP_T) {
+        const int y = i >> 3, k = i & 7;
+        const float py = (float)y + 0.5f;
+        const float pxc = ((float)k + 0.5f) * (float)W * 0.125f;
+        const float n = safe_den(mrow(m, 2, pxc, py, dm));
+        const float t = floorf(div_rn(mrow(m, 1, pxc, py, dm), n) * s - 0.5f);
+        const float u = floorf(div_rn(mrow(m, 0, pxc, py, dm), n) * s - 0.5f);
+        if (t >= 0.0f && t < (float)Ht && u >= -1.0f && u < (float)Wt)
+          atomicAdd(&hist[(int)t], 1);
+      }
+    }
+    __syncthreads();
+    if (tid < 64) {  // wave 0: inclusive prefix, lane = a run of rows
+      const int per = (Ht + 63) >> 6;
+      const int r0 = min(lane * per, Ht), r1 = min(r0 + per, Ht);
+      int sum = 0;
+      for (int r = r0; r < r1; ++r) sum += hist[r];
+      int incl = sum;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(incl, o);
+        if (lane >= o) incl += up;
+      }
+      int run = incl - sum;
+      for (int r = r0; r < r1; ++r) { run += hist[r]; hist[r] = run; }
+      if (lane == 63) ctl[2] = incl;
+    }
+    __syncthreads();
+    const int total = ctl[2];
+    if (tid <= c.nty) {
+      // first row whose prefix reaches k * total / nty (binary search), then
+      // clamped so that every tile has 1 .. thmax rows and the rest still fits
+      int want = 0;
+      if (tid > 0 && tid < c.nty && total > 0) {
+        const long target = ((long)total * tid + c.nty - 1) / c.nty;
+        int lo = 0, hi = Ht - 1;
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (hist[mid] >= target) hi = mid; else lo = mid + 1;
+        }
+        want = lo + 1;
+      } else if (tid > 0) {
+        want = tid < c.nty ? min(tid * c.th, Ht) : Ht;
+      }
+      cut[tid] = want;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      for (int k = 1; k < c.nty; ++k) {
+        const int lo = max(cut[k - 1] + 1, Ht - (c.nty - k) * c.thmax);
+        const int hi = min(cut[k - 1] + c.thmax, Ht - (c.nty - k));
+        cut[k] = total > 0 ? min(max(cut[k], lo), hi)
+                           : min(k * c.th, Ht);
+      }
+      cut[c.nty] = Ht;
+    }
+    __syncthreads();
+    ty0 = cut[tile_y];
+    ty1 = cut[tile_y + 1];
+    __syncthreads();  // (list / cnt are reused below)
+  }
+  const int th_eff = ty1 - ty0;
+  const float ty0f = (float)ty0;
+  // acceptance window of the top-left cell (x0, y0) around the tile
+  const float ay_lo = (float)(ty0 - 1), ay_hi = (float)(ty0 + th_eff - 1);
 
 #if LSI_STREAM_HOOKS
   // reserved & 4: cycles per wave in [0] issue [1] projection + weights
@@ -500,10 +590,10 @@ __global__ __launch_bounds__(SWEEP_T, LSI_SWEEP_WGS) void splat_sweep_kernel(
   const size_t P = (size_t)Ht * Wt;
   const size_t obase = c.all_layers ? (size_t)b * P
                                     : ((size_t)l_begin * d.B + b) * P;
-  for (int cell = tid; cell < NC; cell += SWEEP_T) {
+  for (int cell = tid; cell < (th_eff << TWL); cell += SWEEP_T) {
     const int cy = cell >> TWL, cx = cell & (TW - 1);
     const int gy = ty0 + cy, gx = tx0 + cx;
-    if (gy >= Ht || gx >= Wt) continue;
+    if (gx >= Wt) continue;
     const float4 t = tile[((cy + 1) << TWL) + (cx >> 1) + ((cx & 1) << (TWL - 1))];
     const size_t o = obase + (size_t)gy * Wt + gx;
     const float w = t.w + bgs;
@@ -563,7 +653,13 @@ int lsi_sweep_launch(const SplatArgs& a, const float2* range, hipStream_t stream
   c.inv_nq4 = 1.0f / (float)c.nq4;
   c.inv_nlw = 1.0f / (float)(compose ? d->L : 1);
   const int tiles_y = (d->Ht + c.th - 1) / c.th;
-  const size_t lds = (size_t)(c.th + 2) * TW * 20 + (size_t)SWEEP_CAP * 4 + 64 * 4 + 16 +
+  c.nty = tiles_y;
+  // adaptive tile rows: up to 1.5x the nominal height (48 rows of 128 cells:
+  // 128 KB of sums and locks)
+  c.adaptive = (tiles_y >= 2 && tiles_y <= 63 && d->Ht <= SWEEP_CAP &&
+                !(d->reserved & 4096)) ? 1 : 0;
+  c.thmax = c.adaptive ? c.th + c.th / 2 : c.th;
+  const size_t lds = (size_t)(c.thmax + 2) * TW * 20 + (size_t)SWEEP_CAP * 4 + 64 * 4 + 16 +
                      LSI_SWEEP_MAXL * 8;
   const bool vec4 = sweep_vec4(a), has_mask = (d->flags & LSI_HAS_MASK) != 0;
   const void* fn = twl == 5 ? sweep_fn<5>(vec4, has_mask)
