@@ -380,7 +380,7 @@ __global__ __launch_bounds__(256) void splat_bwd_pre_kernel(
   G[i] = make_float4(g0 * inv, g1 * inv, g2 * inv, gw);
 }
 
-// grid (ceil(W / 256), ceil(H / BWD_ROWS), L * B): no integer division per thread.  SIMPLE_M
+// grid (ceil(W / 256), ceil(H / BWD_ROWS), B * L): no integer division per thread.  SIMPLE_M
 // (decided per batch element from M itself, uniform per block): normaliser == 1
 // and target disparity == source disparity, i.e. M rows 2, 3 = (0,0,1,0),
 // (0,0,0,1) -- every rectified pair.  Then u = q0 * s exactly (x / 1 == x), so
@@ -498,7 +498,12 @@ __device__ __forceinline__ void splat_bwd_rows(
     BwdIn in;
     in.dv = dbase[yc * d.disp_sy];
     const float* tp = tbase + yc * d.tex_sy;
-    in.t0 = tp[0]; in.t1 = tp[d.tex_sc]; in.t2 = tp[2 * d.tex_sc];
+    if (d.tex_sc == 1) {  // channels last: one 12-byte load per lane
+      const float3 t3 = *reinterpret_cast<const float3*>(tp);
+      in.t0 = t3.x; in.t1 = t3.y; in.t2 = t3.z;
+    } else {
+      in.t0 = tp[0]; in.t1 = tp[d.tex_sc]; in.t2 = tp[2 * d.tex_sc];
+    }
     in.mk = has_mask ? mbase[yc * d.mask_sy] : 1.0f;
     return in;
   };
@@ -515,9 +520,8 @@ __device__ __forceinline__ void splat_bwd_rows(
       const BwdPx g = splat_bwd_core<SIMPLE_M>(d, m, y, x, cur.dv, cur.mk, cur.t0,
                                                cur.t1, cur.t2, Gb);
       const size_t o = obase + (size_t)y * d.W;
-      g_tex[3 * o + 0] = g.gt0;
-      g_tex[3 * o + 1] = g.gt1;
-      g_tex[3 * o + 2] = g.gt2;
+      // one 12-byte store per lane: a wave writes 768 contiguous bytes
+      *reinterpret_cast<float3*>(g_tex + 3 * o) = make_float3(g.gt0, g.gt1, g.gt2);
       if (g_mask) g_mask[o] = g.gm;
       g_disp[o] = g.gd;
     }
@@ -526,16 +530,17 @@ __device__ __forceinline__ void splat_bwd_rows(
 }
 
 __global__ __launch_bounds__(256) void splat_bwd_kernel(
-    SplatArgs a, float inv_b, const float4* __restrict__ G,
+    SplatArgs a, float inv_l, const float4* __restrict__ G,
     float* __restrict__ g_tex, float* __restrict__ g_disp,
     float* __restrict__ g_mask) {
   const LsiSplatDesc& d = a.d;
   const int y0 = blockIdx.y * BWD_ROWS;
-  // blockIdx.z = l * B + b
-  int l = (int)((float)blockIdx.z * inv_b);
-  int b = (int)blockIdx.z - l * d.B;
-  if (b < 0) { --l; b += d.B; }
-  if (b >= d.B) { ++l; b -= d.B; }
+  // blockIdx.z = b * L + l: the layers of a batch element run back to back and
+  // find its gradient canvas in the L2
+  int b = (int)((float)blockIdx.z * inv_l);
+  int l = (int)blockIdx.z - b * d.L;
+  if (l < 0) { --b; l += d.L; }
+  if (l >= d.L) { ++b; l -= d.L; }
   const int x = blockIdx.x * 256 + threadIdx.x;
   if (x >= d.W) return;
   const float* __restrict__ m = a.M + 16 * b;
@@ -554,7 +559,7 @@ static void launch_bwd(const SplatArgs& a, const float4* G, float* g_tex,
   hipLaunchKernelGGL(splat_bwd_kernel,
                      dim3((d->W + 255) / 256, (d->H + BWD_ROWS - 1) / BWD_ROWS,
                           d->L * d->B),
-                     dim3(256), 0, stream, a, 1.0f / (float)d->B, G, g_tex, g_disp,
+                     dim3(256), 0, stream, a, 1.0f / (float)d->L, G, g_tex, g_disp,
                      g_mask);
 }
 
