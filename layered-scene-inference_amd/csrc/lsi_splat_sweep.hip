@@ -1,9 +1,9 @@
-// LSI_PATH_TILE without the disparity output: the any-pose SWEEP kernel
+// LSI_PATH_TILE: the any-pose SWEEP kernel
 // (general 3-D poses, BASELINE config 4).  Reference semantics: ldi.py:97-184
 // (forward_splat) with sampling.py:161-241 (splat) for an arbitrary 4x4 matrix.
 //
 // The gather kernel (lsi_splat_tile.hip) bins records and walks bin lists
-// between chunk barriers; it stays for LSI_WANT_DISP.  Here nothing is binned
+// between chunk barriers; it stays for > 16 composed layers.  Here nothing is binned
 // and nothing waits at a barrier while pixels are in flight:
 //
 // * Workgroup = (tile of TH x TW target cells, batch element[, layer]); the
@@ -124,7 +124,7 @@ __device__ __forceinline__ void unlock1(unsigned addr) {
   asm volatile("ds_write_b32 %0, %1" : : "v"(addr), "v"(zero) : "memory");
 }
 
-template <int TWL, bool VEC4, bool HAS_MASK>
+template <int TWL, bool VEC4, bool HAS_MASK, bool WANT_DISP>
 __global__ __launch_bounds__(SWEEP_T, LSI_SWEEP_WGS) void splat_sweep_kernel(
     SplatArgs a, SweepCfg c, const float2* __restrict__ range) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -147,6 +147,8 @@ __global__ __launch_bounds__(SWEEP_T, LSI_SWEEP_WGS) void splat_sweep_kernel(
   int* cnt = list + SWEEP_CAP;                      // [64] per-block counts
   int* ctl = cnt + 64;                              // [1] list fill
   float2* lrange = reinterpret_cast<float2*>(ctl + 4);  // [LSI_SWEEP_MAXL]
+  // WANT_DISP: sum of (target disparity * weight) per cell, next to the tile
+  float* dsum = reinterpret_cast<float*>(lrange + LSI_SWEEP_MAXL);  // [thmax + 2][TW]
   const unsigned locks_addr = (unsigned)(uintptr_t)locks;
 
   float m[16];
@@ -161,6 +163,7 @@ __global__ __launch_bounds__(SWEEP_T, LSI_SWEEP_WGS) void splat_sweep_kernel(
   for (int i = tid; i < NCP; i += SWEEP_T) {
     tile[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     locks[i] = 0;
+    if (WANT_DISP) dsum[i] = 0.0f;
   }
   if (tid < NLW) {  // the layer's disparity range: fold the row slices
     float2 dr = make_float2(__builtin_inff(), -__builtin_inff());
@@ -279,7 +282,19 @@ __global__ __launch_bounds__(SWEEP_T, LSI_SWEEP_WGS) void splat_sweep_kernel(
   };
 
   const int wave = tid >> 6;
-  const int ncand = NLW * H * c.nq4;
+  // Composition with the disparity output needs every layer's own normalised
+  // disparity (ldi.py:157-182): the layers are then swept one after the other
+  // and folded into per-thread totals (a thread owns cells tid + k * 1024).
+  constexpr bool LAYER_PASSES = WANT_DISP;
+  const int npass = (LAYER_PASSES && c.all_layers) ? d.L : 1;
+  const int PLW = (LAYER_PASSES && c.all_layers) ? 1 : NLW;  // layers per pass
+  float4 Tsum[4];
+  float Tdmax[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { Tsum[k] = make_float4(0.f, 0.f, 0.f, 0.f); Tdmax[k] = 0.0f; }
+  for (int lp = 0; lp < npass; ++lp) {
+  const int lofs = npass > 1 ? lp : 0;  // first layer of this pass (in lrange)
+  const int ncand = PLW * H * c.nq4;
   for (int cand0 = 0; cand0 < ncand; cand0 += SWEEP_CAP) {
     const int cand1 = min(ncand, cand0 + SWEEP_CAP);
     if (tid == 0) ctl[0] = 0;  // the ticket counter (barriers below)
@@ -296,8 +311,8 @@ __global__ __launch_bounds__(SWEEP_T, LSI_SWEEP_WGS) void splat_sweep_kernel(
       if (cand < cand1) {
         const int yl = c.nq4 == 1 ? cand : div_small(cand, c.nq4, c.inv_nq4);
         const int q4 = cand - yl * c.nq4;
-        const int y = NLW == 1 ? yl : div_small(yl, NLW, c.inv_nlw);
-        const int li = yl - y * NLW;
+        const int y = PLW == 1 ? yl : div_small(yl, PLW, c.inv_nlw);
+        const int li = lofs + yl - y * PLW;
         const float2 dr = lrange[li];
         const float py = (float)y + 0.5f;
         const bool unbounded = !(dr.x <= dr.y);  // no finite disparity seen
@@ -428,7 +443,7 @@ __global__ __launch_bounds__(SWEEP_T, LSI_SWEEP_WGS) void splat_sweep_kernel(
     // included); rows -1 and TH exist so that no lane needs a special case --
     // what lands there is never read.
     auto locked_pair = [&](bool need, int cell, float wa, float wb,
-                           const float4& V) {
+                           const float4& V, float vd) {
 #if LSI_STREAM_HOOKS
       if (d.reserved & 512) return;  // timing experiment: no accumulation
 #endif
@@ -449,6 +464,10 @@ __global__ __launch_bounds__(SWEEP_T, LSI_SWEEP_WGS) void splat_sweep_kernel(
           tb.z = __fmaf_rn(V.z, wb, tb.z); tb.w = __fmaf_rn(V.w, wb, tb.w);
           tile[cell] = ta;
           tile[cell + TW] = tb;
+          if (WANT_DISP) {
+            dsum[cell] = __fmaf_rn(vd, wa, dsum[cell]);
+            dsum[cell + TW] = __fmaf_rn(vd, wb, dsum[cell + TW]);
+          }
           asm volatile("" ::: "memory");
 #if LSI_STREAM_HOOKS
           if (!(d.reserved & 1024))
@@ -472,6 +491,7 @@ __global__ __launch_bounds__(SWEEP_T, LSI_SWEEP_WGS) void splat_sweep_kernel(
               t.x = __fmaf_rn(V.x, wa, t.x); t.y = __fmaf_rn(V.y, wa, t.y);
               t.z = __fmaf_rn(V.z, wa, t.z); t.w = __fmaf_rn(V.w, wa, t.w);
               tile[cell] = t;
+              if (WANT_DISP) dsum[cell] = __fmaf_rn(vd, wa, dsum[cell]);
               asm volatile("" ::: "memory");
               unlock1(la);
               na = false;
@@ -482,6 +502,7 @@ __global__ __launch_bounds__(SWEEP_T, LSI_SWEEP_WGS) void splat_sweep_kernel(
               t.x = __fmaf_rn(V.x, wb, t.x); t.y = __fmaf_rn(V.y, wb, t.y);
               t.z = __fmaf_rn(V.z, wb, t.z); t.w = __fmaf_rn(V.w, wb, t.w);
               tile[cell + TW] = t;
+              if (WANT_DISP) dsum[cell + TW] = __fmaf_rn(vd, wb, dsum[cell + TW]);
               asm volatile("" ::: "memory");
               unlock1(la + TW * 4u);
               nb = false;
@@ -540,9 +561,9 @@ __global__ __launch_bounds__(SWEEP_T, LSI_SWEEP_WGS) void splat_sweep_kernel(
         const int sr = (ixr >> 1) + ((ixr & 1) << (TWL - 1));
         const int rowb = (iy + 1) << TWL;
         SWEEP_STAMP(1);
-        locked_pair(ok && ix >= 0, rowb + sl, w00, w10, V);
+        locked_pair(ok && ix >= 0, rowb + sl, w00, w10, V, dd * pw);
         SWEEP_STAMP(2);
-        locked_pair(ok && ixr < tw_eff, rowb + sr, w01, w11, V);
+        locked_pair(ok && ixr < tw_eff, rowb + sr, w01, w11, V, dd * pw);
         SWEEP_STAMP(3);
       }
     };
@@ -575,6 +596,39 @@ __global__ __launch_bounds__(SWEEP_T, LSI_SWEEP_WGS) void splat_sweep_kernel(
     }
     __syncthreads();
   }
+  if (npass > 1) {
+    // layer lp is complete in the tile: fold it into the totals of the cells
+    // this thread owns (as the reference: per-layer canvases bg + sums, the
+    // layer's disparity normalised by its own weight, then sum / max over
+    // the layers), and clear the tile for the next layer
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int cell = tid + k * SWEEP_T;
+      if (cell >= (th_eff << TWL)) continue;
+      const int cy = cell >> TWL, cx = cell & (TW - 1);
+      const int slot = ((cy + 1) << TWL) + (cx >> 1) + ((cx & 1) << (TWL - 1));
+      const float4 t = tile[slot];
+      const float bg = d.bg_wt;
+      const float l0 = bg + t.x, l1 = bg + t.y, l2 = bg + t.z, lw = bg + t.w;
+      const float dl = div_rn(dsum[slot], safe_den(lw));
+      if (lp == 0) {
+        Tsum[k] = make_float4(l0, l1, l2, lw);
+        Tdmax[k] = dl;
+      } else {
+        Tsum[k].x += l0; Tsum[k].y += l1; Tsum[k].z += l2; Tsum[k].w += lw;
+        Tdmax[k] = fmaxf(Tdmax[k], dl);
+      }
+    }
+    __syncthreads();
+    if (lp + 1 < npass) {
+      for (int i = tid; i < NCP; i += SWEEP_T) {
+        tile[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        dsum[i] = 0.0f;
+      }
+      __syncthreads();
+    }
+  }
+  }  // layer passes
 #if LSI_STREAM_HOOKS
   if (prof && lane == 0) {
     long long* o = reinterpret_cast<long long*>(
@@ -586,15 +640,34 @@ __global__ __launch_bounds__(SWEEP_T, LSI_SWEEP_WGS) void splat_sweep_kernel(
 #endif
 
   // ---- epilogue: background, normalisation (ldi.py:122-125, 157-182) ---------
-  const float bgs = (float)NLW * d.bg_wt;
   const size_t P = (size_t)Ht * Wt;
   const size_t obase = c.all_layers ? (size_t)b * P
                                     : ((size_t)l_begin * d.B + b) * P;
+  if (npass > 1) {  // composed totals of the layer passes, from registers
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int cell = tid + k * SWEEP_T;
+      if (cell >= (th_eff << TWL)) continue;
+      const int cy = cell >> TWL, cx = cell & (TW - 1);
+      const int gy = ty0 + cy, gx = tx0 + cx;
+      if (gx >= Wt) continue;
+      const size_t o = obase + (size_t)gy * Wt + gx;
+      const float wd = safe_den(Tsum[k].w);
+      a.out_img[3 * o + 0] = div_rn(Tsum[k].x, wd);
+      a.out_img[3 * o + 1] = div_rn(Tsum[k].y, wd);
+      a.out_img[3 * o + 2] = div_rn(Tsum[k].z, wd);
+      a.out_wts[o] = Tsum[k].w;
+      a.out_disp[o] = Tdmax[k];
+    }
+    return;
+  }
+  const float bgs = (float)NLW * d.bg_wt;
   for (int cell = tid; cell < (th_eff << TWL); cell += SWEEP_T) {
     const int cy = cell >> TWL, cx = cell & (TW - 1);
     const int gy = ty0 + cy, gx = tx0 + cx;
     if (gx >= Wt) continue;
-    const float4 t = tile[((cy + 1) << TWL) + (cx >> 1) + ((cx & 1) << (TWL - 1))];
+    const int slot = ((cy + 1) << TWL) + (cx >> 1) + ((cx & 1) << (TWL - 1));
+    const float4 t = tile[slot];
     const size_t o = obase + (size_t)gy * Wt + gx;
     const float w = t.w + bgs;
     const float wd = safe_den(w);
@@ -602,6 +675,9 @@ __global__ __launch_bounds__(SWEEP_T, LSI_SWEEP_WGS) void splat_sweep_kernel(
     a.out_img[3 * o + 1] = div_rn(t.y + bgs, wd);
     a.out_img[3 * o + 2] = div_rn(t.z + bgs, wd);
     a.out_wts[o] = w;
+    // (one layer per workgroup here: compose with one layer, or per-layer
+    // outputs -- the layer's disparity normalised by its own weight)
+    if (WANT_DISP) a.out_disp[o] = div_rn(dsum[slot], wd);
   }
 }
 
@@ -621,12 +697,17 @@ bool sweep_vec4(const SplatArgs& a) {
   return ok;
 }
 
+template <int TWL, bool WD>
+const void* sweep_fn2(bool vec4, bool has_mask) {
+  return vec4 ? (has_mask ? (const void*)splat_sweep_kernel<TWL, true, true, WD>
+                          : (const void*)splat_sweep_kernel<TWL, true, false, WD>)
+              : (has_mask ? (const void*)splat_sweep_kernel<TWL, false, true, WD>
+                          : (const void*)splat_sweep_kernel<TWL, false, false, WD>);
+}
 template <int TWL>
-const void* sweep_fn(bool vec4, bool has_mask) {
-  return vec4 ? (has_mask ? (const void*)splat_sweep_kernel<TWL, true, true>
-                          : (const void*)splat_sweep_kernel<TWL, true, false>)
-              : (has_mask ? (const void*)splat_sweep_kernel<TWL, false, true>
-                          : (const void*)splat_sweep_kernel<TWL, false, false>);
+const void* sweep_fn(bool vec4, bool has_mask, bool want_disp) {
+  return want_disp ? sweep_fn2<TWL, true>(vec4, has_mask)
+                   : sweep_fn2<TWL, false>(vec4, has_mask);
 }
 
 }  // namespace
@@ -656,15 +737,19 @@ int lsi_sweep_launch(const SplatArgs& a, const float2* range, hipStream_t stream
   c.nty = tiles_y;
   // adaptive tile rows: up to 1.5x the nominal height (48 rows of 128 cells:
   // 128 KB of sums and locks)
+  const bool want_disp = (d->flags & LSI_WANT_DISP) != 0;
+  if (want_disp && !a.out_disp) return LSI_ENULL;
+  // (with the disparity output: 4 more bytes per cell, and the composed
+  // totals live in registers, 4 cells per thread: nominal tiles only)
   c.adaptive = (tiles_y >= 2 && tiles_y <= 63 && d->Ht <= SWEEP_CAP &&
-                !(d->reserved & 4096)) ? 1 : 0;
+                !want_disp && !(d->reserved & 4096)) ? 1 : 0;
   c.thmax = c.adaptive ? c.th + c.th / 2 : c.th;
-  const size_t lds = (size_t)(c.thmax + 2) * TW * 20 + (size_t)SWEEP_CAP * 4 + 64 * 4 + 16 +
+  const size_t lds = (size_t)(c.thmax + 2) * TW * (want_disp ? 24 : 20) + (size_t)SWEEP_CAP * 4 + 64 * 4 + 16 +
                      LSI_SWEEP_MAXL * 8;
   const bool vec4 = sweep_vec4(a), has_mask = (d->flags & LSI_HAS_MASK) != 0;
-  const void* fn = twl == 5 ? sweep_fn<5>(vec4, has_mask)
-                            : (twl == 6 ? sweep_fn<6>(vec4, has_mask)
-                                        : sweep_fn<7>(vec4, has_mask));
+  const void* fn = twl == 5 ? sweep_fn<5>(vec4, has_mask, want_disp)
+                            : (twl == 6 ? sweep_fn<6>(vec4, has_mask, want_disp)
+                                        : sweep_fn<7>(vec4, has_mask, want_disp));
   if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)lds) != hipSuccess)
     return LSI_ELAUNCH;

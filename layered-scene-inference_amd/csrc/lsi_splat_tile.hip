@@ -438,10 +438,9 @@ int lsi_tile_launch(const SplatArgs& a, hipStream_t stream) {
   hipLaunchKernelGGL(disp_range_kernel, dim3(d->B * d->L, LSI_RANGE_SLICES),
                      dim3(256), 0, stream, a, range, rvec4);
   const bool want_disp = (d->flags & LSI_WANT_DISP) != 0;
-  // the sweep kernel renders colour + weight; the disparity output (per-layer
-  // normalisation before the max over layers) stays on the gather kernel
-  // (reserved bit 8: force the gather kernel, for A/B runs)
-  if (!want_disp && !(d->reserved & 256) &&
+  // the sweep kernel; the gather kernel below remains for more than
+  // LSI_SWEEP_MAXL composed layers (reserved bit 8 forces it, for A/B runs)
+  if (!(d->reserved & 256) &&
       (!(d->flags & LSI_COMPOSE) || d->L <= LSI_SWEEP_MAXL))
     return lsi_sweep_launch(a, range, stream);
   TileCfg c;

@@ -184,6 +184,20 @@ def test_general_pose_against_c_oracle(dev, ref_cpu):
                              atol=1e-7)
   with pytest.raises(RuntimeError, match='precondition'):
     ldi.forward_splat_matrix(ldi_src, torch.tensor(mat), path='rowband')
+  # the gather kernel (what more than 16 composed layers fall back to; forced
+  # here with the experiment bit) and the sweep kernel, per-layer outputs
+  for compose in (True, False):
+    want = ref_cpu.forward_splat(tex, mask, disp, mat, 0.5, 0.2, 1.0, 50, compose)
+    for experiment in (0, 256):
+      img, wts, dsp = ldi.forward_splat_matrix(
+          ldi_src, torch.tensor(mat), compose_layers=compose,
+          compute_trg_disp=True, trg_downsampling=0.5, bg_layer_disp=0.2,
+          max_disp=1.0, zbuf_scale=50, path='tile', experiment=experiment)
+      np.testing.assert_allclose(img.cpu().numpy(), want['img'], rtol=0,
+                                 atol=IMG_ATOL)
+      np.testing.assert_allclose(wts.cpu().numpy(), want['wts'], rtol=WTS_RTOL)
+      np.testing.assert_allclose(dsp.cpu().numpy(), want['disp'], rtol=DSP_RTOL,
+                                 atol=1e-7)
 
 
 @pytest.mark.parametrize('path', ['atomic', 'rowband', 'stream', 'tile'])
