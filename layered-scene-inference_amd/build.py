@@ -55,15 +55,18 @@ def build(force=False, verbose=False, hooks=False):
   so = SO_HOOKS if hooks else SO
   ext = '.hooks.o' if hooks else '.o'
   flags = HIPCC_FLAGS + (['-DLSI_STREAM_HOOKS=1'] if hooks else [])
-  objs = []
+  objs, jobs = [], []
   for src in srcs:
     obj = src[:-4] + ext
     if force or _stale(obj, [src] + HEADERS):
       cmd = [hipcc()] + flags + ['-c', src, '-o', obj]
       if verbose:
         print(' '.join(cmd))
-      subprocess.check_call(cmd)
+      jobs.append((cmd, subprocess.Popen(cmd)))  # the sources compile side by side
     objs.append(obj)
+  for cmd, proc in jobs:
+    if proc.wait() != 0:
+      raise subprocess.CalledProcessError(proc.returncode, cmd)
   if force or _stale(so, objs):
     cmd = [hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', so] + objs
     if verbose:
