@@ -1717,6 +1717,8 @@ static int stream_plan(const LsiSplatDesc* d, int wmax, bool both,
         const bool cell_ok = lean && !both && R + xch <= 8 && ntask <= 40;
         if (cell != (cell_ok ? 1 : 0) && !(force_cell == 1 && cell == 0)) continue;
         if (force_cell == 1 && cell == 1) continue;
+        StreamPlan local; local.nw = 0; local.est = -1.0;
+        double local_pref = 0.0;
         for (int c = MAXNW; c >= 4; --c) {
           if (d->tune_threads > 0 && c != (d->tune_threads + 63) / 64) continue;
           int q = 64;
@@ -1748,12 +1750,21 @@ static int stream_plan(const LsiSplatDesc* d, int wmax, bool both,
           const double epi = (double)(R + xch) * d->Wt / (c * 64.0) * 70.0 +
                              2500.0 + 16000.0 * xch;
           const double est = (double)rounds * (fixed + npass * (loop + epi));
-          if (best.est < 0.0 || est < best.est) {
-            best.est = est; best.R = R; best.nw = c; best.xch = xch;
-            best.ngrp = ngrp; best.lpg = lpg; best.cap = cap; best.qcap = q;
-            best.lds = lds; best.cell = cell;
+          // Among the wave counts of ONE configuration, prefer waves spread
+          // evenly over the four SIMDs (and, with them, the larger per-wave
+          // queue): measured ~3 % at cfg3 (12 waves x 64 entries 95.7 us, 15 x
+          // 16 98.8 us; long bands only: short ones are bound by their fixed
+          // phases).  Configurations compete on the plain estimate.
+          const double pref = est * ((c % 4 != 0 && !cell) ? 1.05 : 1.0);
+          if (local.nw == 0 || pref < local_pref) {
+            local_pref = pref;
+            local.est = est; local.R = R; local.nw = c; local.xch = xch;
+            local.ngrp = ngrp; local.lpg = lpg; local.cap = cap; local.qcap = q;
+            local.lds = lds; local.cell = cell;
           }
         }
+        // (ties go to the later candidate: longer bands, less halo)
+        if (local.nw != 0 && (best.est < 0.0 || local.est <= best.est)) best = local;
         }
       }
     }
