@@ -22,6 +22,7 @@ Parameters the reference creates but never trains when n_layerwise_steps=3
 (`with_fc`, `nl_diff_enc_dec`), so that DDP's reducer never waits for them.
 """
 import math
+import os
 
 import torch
 from torch import nn
@@ -35,6 +36,10 @@ def _same_pad(n, k, stride):
   total = max((ceil(n/stride) - 1)*stride + k - n, 0), the extra pixel after."""
   total = max((-(-n // stride) - 1) * stride + k - n, 0)
   return total // 2, total - total // 2
+
+
+# bf16 batch norm on large maps under autocast (LSI_BF16_BN=0 restores fp32)
+BF16_BATCH_NORM = os.environ.get('LSI_BF16_BN', '1') != '0'
 
 
 class SlimBatchNorm(nn.Module):
@@ -52,8 +57,16 @@ class SlimBatchNorm(nn.Module):
     self.is_training = True
 
   def forward(self, x):
-    # statistics in fp32 also under bf16 autocast (the reference is fp32, and
-    # MIOpen's bf16 batch norm crashed on small bottleneck maps)
+    # Under bf16 autocast the large maps stay in bf16 (MIOpen computes the
+    # statistics in fp32 internally; gamma / beta are fp32): no cast to fp32 and
+    # back around every batch norm, which was a tenth of the bf16 step
+    # (profiles/r02/train_step_summary.json).  Small maps go through fp32: the
+    # reference is fp32, and MIOpen's bf16 batch norm crashed on the small
+    # bottleneck maps.
+    if (x.dtype == torch.bfloat16 and self.is_training and BF16_BATCH_NORM and
+        x.numel() // x.shape[1] >= 4096):
+      return F.batch_norm(x, None, None, self.gamma, self.beta, True, 0.0,
+                          self.eps)
     x = x.float()
     if self.is_training:
       if x.numel() // x.shape[1] > 64:
