@@ -38,6 +38,9 @@ def _same_pad(n, k, stride):
   return total // 2, total - total // 2
 
 
+# symmetric SAME padding inside the convolution (see SlimConv2d);
+# LSI_IMPLICIT_PAD=0 pads explicitly
+IMPLICIT_PAD = os.environ.get('LSI_IMPLICIT_PAD', '1') != '0'
 # bf16 batch norm on large maps under autocast (LSI_BF16_BN=0 restores fp32)
 BF16_BATCH_NORM = os.environ.get('LSI_BF16_BN', '1') != '0'
 
@@ -100,12 +103,19 @@ class SlimConv2d(nn.Module):
   def forward(self, x):
     ph = _same_pad(x.shape[2], self.k, self.stride)
     pw = _same_pad(x.shape[3], self.k, self.stride)
-    # explicit padding also for the symmetric (stride-1) case: with implicit
-    # padding MIOpen (ROCm 7.2) fell back to naive kernels for several bf16
-    # layer shapes (66 ms vs 39 ms per step, tools/train_bench.py)
-    if ph[0] or ph[1] or pw[0] or pw[1]:
-      x = F.pad(x, (pw[0], pw[1], ph[0], ph[1]))
-    x = self.conv(x)
+    # Symmetric SAME padding (the stride-1 layers) goes into the convolution:
+    # no padded copy of the activation (118 -> 127 samples/s fp32, 182 -> 192
+    # bf16, tools/train_bench.py).  (In round 1 MIOpen fell back to naive
+    # kernels for several bf16 shapes with implicit padding; with channels-last
+    # activations and bf16 batch norm it no longer does.)  Asymmetric padding
+    # (the stride-2 layers: TF pads one more pixel after) stays explicit.
+    if IMPLICIT_PAD and ph[0] == ph[1] and pw[0] == pw[1]:
+      x = F.conv2d(x, self.conv.weight, self.conv.bias, self.stride,
+                   (ph[0], pw[0]))
+    else:
+      if ph[0] or ph[1] or pw[0] or pw[1]:
+        x = F.pad(x, (pw[0], pw[1], ph[0], ph[1]))
+      x = self.conv(x)
     if self.bn is not None:
       x = self.bn(x)
     if self.activation == 'relu':
