@@ -432,9 +432,13 @@ def build_renderer(workload, b_local, seed, dev, args):
                   args.threads, extra)
 
 
+SETTLE_S = 0.2  # untimed replays before the timed region (clock ramp)
+
+
 def timed_region(r, steps, warmup, launch_mode, dist, dev):
-  """W untimed steps, then exactly K steps between barrier + synchronize on
-  both sides; HIP events on the launch stream bracket the same K launches."""
+  """W untimed steps (plus SETTLE_S seconds of untimed replays: clock ramp),
+  then exactly K steps between barrier + synchronize on both sides; HIP events
+  on the launch stream bracket the same K launches."""
   stream = torch.cuda.Stream(device=dev)
   with torch.cuda.stream(stream):
     for _ in range(max(warmup, 1)):
@@ -452,6 +456,18 @@ def timed_region(r, steps, warmup, launch_mode, dist, dev):
       except Exception as e:  # pylint: disable=broad-except
         sys.stderr.write('graph capture failed (%s); eager launches\n' % e)
         graph, launch_mode = None, 'eager'
+    # Settle: a GPU that has just left idle runs its first milliseconds at
+    # lower clocks (cfg3: 112 us per step with --steps 20 --warmup 5, 98 us
+    # once warm).  Untimed replays of the same work for SETTLE_S seconds, so
+    # that short runs measure the same steady state as long ones.
+    t_settle = time.perf_counter() + SETTLE_S
+    while time.perf_counter() < t_settle:
+      if graph is not None:
+        graph.replay()
+      else:
+        for _ in range(steps):
+          r.launch()
+      stream.synchronize()
     ev0 = torch.cuda.Event(enable_timing=True)
     ev1 = torch.cuda.Event(enable_timing=True)
     if dist is not None:
@@ -582,6 +598,7 @@ def main():
                         (args.workload, nl, h, w, b_local, b_local * world,
                          cams, args.disp),
             'kernel_path': r.path_name, 'launch': launch_mode,
+            'untimed_settle_s': SETTLE_S,
             'input_sets_rotated': len(r.sets),
             'parallelism': 'batch-sharded replicas x%d (no collective)' % world,
         },
