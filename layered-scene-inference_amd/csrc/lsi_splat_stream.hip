@@ -332,8 +332,12 @@ __device__ __forceinline__ void cell_unlock(unsigned a0) {
   asm volatile("ds_write_b32 %0, %1" : : "v"(a0), "v"(zero) : "memory");
 }
 
-template <int LAYOUT, bool SIMPLE, int MODE, bool FULL>  // LAYOUT 0: channels-last, 1: planar
-__global__ __launch_bounds__(LSI_STREAM_MAXT) void splat_stream_kernel(SplatArgs a,
+// MAXT: the launch bound.  1024 threads = 16 waves of at most 128 VGPRs; the
+// 768-thread instances (lean row-lock modes, what long bands use) may take 168
+// VGPRs: no spills in the pixel loop, ~4 % faster at cfg3 / cfg5 when the
+// planner asks for at most 12 waves anyway.
+template <int LAYOUT, bool SIMPLE, int MODE, bool FULL, int MAXT = LSI_STREAM_MAXT>  // LAYOUT 0: channels-last, 1: planar
+__global__ __launch_bounds__(MAXT) void splat_stream_kernel(SplatArgs a,
                                                            StreamCfg cfg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const LsiSplatDesc& d = a.d;
@@ -1849,18 +1853,24 @@ int lsi_stream_launch(const SplatArgs& a, hipStream_t stream) {
   const bool lean = (d->flags & LSI_COMPOSE) && !(d->flags & LSI_HAS_MASK);
   const int mode = lean ? (cfg.exchange ? 2 : 1) + (plan.cell ? 2 : 0) : 0;
   const void* fn;
-#define LSI_PICK2(L_, S_, M_)                                              \
-  (full ? (const void*)splat_stream_kernel<L_, S_, M_, true>                \
-        : (const void*)splat_stream_kernel<L_, S_, M_, false>)
+#define LSI_PICK3(L_, S_, M_, F_)                                              \
+  ((M_ == 1 || M_ == 2) && narrow                                               \
+       ? (const void*)splat_stream_kernel<L_, S_, M_, F_,                       \
+                                          (M_ == 1 || M_ == 2) ? 768 : LSI_STREAM_MAXT> \
+       : (const void*)splat_stream_kernel<L_, S_, M_, F_>)
+#define LSI_PICK2(L_, S_, M_) \
+  (full ? LSI_PICK3(L_, S_, M_, true) : LSI_PICK3(L_, S_, M_, false))
 #define LSI_PICK(L_, S_) \
   (mode == 1 ? LSI_PICK2(L_, S_, 1) : mode == 2 ? LSI_PICK2(L_, S_, 2) :   \
    mode == 3 ? LSI_PICK2(L_, S_, 3) : mode == 4 ? LSI_PICK2(L_, S_, 4) :   \
    LSI_PICK2(L_, S_, 0))
   const bool full = d->W % SEG == 0;
+  const bool narrow = threads <= 768;  // the 168-VGPR instances
   if (layout == 0)
     fn = simple ? LSI_PICK(0, true) : LSI_PICK(0, false);
   else
     fn = simple ? LSI_PICK(1, true) : LSI_PICK(1, false);
+#undef LSI_PICK3
 #undef LSI_PICK2
 #undef LSI_PICK
   if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
