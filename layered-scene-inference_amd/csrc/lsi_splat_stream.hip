@@ -333,7 +333,7 @@ __device__ __forceinline__ void cell_unlock(unsigned a0) {
 }
 
 // MAXT: the launch bound.  1024 threads = 16 waves of at most 128 VGPRs; the
-// 768-thread instances (lean row-lock modes, what long bands use) may take 168
+// 768-thread instances (the row-lock modes and the general kernel) may take 168
 // VGPRs: no spills in the pixel loop, ~4 % faster at cfg3 / cfg5 when the
 // planner asks for at most 12 waves anyway.
 template <int LAYOUT, bool SIMPLE, int MODE, bool FULL, int MAXT = LSI_STREAM_MAXT>  // LAYOUT 0: channels-last, 1: planar
@@ -1723,7 +1723,10 @@ static int stream_plan(const LsiSplatDesc* d, int wmax, bool both,
         if (force_cell == 1 && cell == 1) continue;
         StreamPlan local; local.nw = 0; local.est = -1.0;
         double local_pref = 0.0;
-        for (int c = MAXNW; c >= 4; --c) {
+        // (the general kernel -- masks, per-layer outputs, both outputs --
+        // spills 33-53 VGPRs under the 128-register bound of 16 waves: its
+        // plans stay within the 12 waves of the 168-register instances)
+        for (int c = lean ? MAXNW : (MAXNW < 12 ? MAXNW : 12); c >= 4; --c) {
           if (d->tune_threads > 0 && c != (d->tune_threads + 63) / 64) continue;
           int q = 64;
           const int trows = (R + xch) * (both ? 2 : 1);
@@ -1854,9 +1857,9 @@ int lsi_stream_launch(const SplatArgs& a, hipStream_t stream) {
   const int mode = lean ? (cfg.exchange ? 2 : 1) + (plan.cell ? 2 : 0) : 0;
   const void* fn;
 #define LSI_PICK3(L_, S_, M_, F_)                                              \
-  ((M_ == 1 || M_ == 2) && narrow                                               \
+  ((M_ <= 2) && narrow                                                          \
        ? (const void*)splat_stream_kernel<L_, S_, M_, F_,                       \
-                                          (M_ == 1 || M_ == 2) ? 768 : LSI_STREAM_MAXT> \
+                                          (M_ <= 2) ? 768 : LSI_STREAM_MAXT>    \
        : (const void*)splat_stream_kernel<L_, S_, M_, F_>)
 #define LSI_PICK2(L_, S_, M_) \
   (full ? LSI_PICK3(L_, S_, M_, true) : LSI_PICK3(L_, S_, M_, false))
