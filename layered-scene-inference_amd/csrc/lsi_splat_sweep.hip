@@ -721,7 +721,10 @@ int lsi_sweep_launch(const SplatArgs& a, const float2* range, hipStream_t stream
   const int TW = 1 << twl;
   const bool compose = (d->flags & LSI_COMPOSE) != 0;
   const int nz = compose ? 1 : d->L;
-  c.th = (LSI_SWEEP_T < 1024 ? 2048 : 4096) / TW;
+#ifndef LSI_SWEEP_CELLS
+#define LSI_SWEEP_CELLS (LSI_SWEEP_T < 1024 ? 2048 : 4096)
+#endif
+  c.th = LSI_SWEEP_CELLS / TW;
   if (d->tune_rows > 0 && d->tune_rows < c.th) c.th = d->tune_rows;
   // shorter tiles when the tall ones would leave CUs idle
   while (c.th > 8 && (long)((d->Ht + c.th - 1) / c.th) *
