@@ -20,7 +20,8 @@ threads = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 nl, h, w, batch, per_gpu, cams, max_disp, bg = bench.WORKLOADS[wl]
 batch //= int(sys.argv[5]) if len(sys.argv) > 5 else 1
 dev = torch.device('cuda:0')
-tex, disp, mat = bench.make_inputs(nl, batch, h, w, cams, max_disp, 1000, dev)
+tex, disp, mat = bench.make_inputs(nl, batch, h, w, cams, max_disp, 1000, dev,
+                                   disp_kind=os.environ.get('LSI_PROBE_DISP', 'smooth'))
 r = bench.Renderer(tex, disp, mat, max_disp, bg, 'stream', rows, threads)
 r.desc.reserved = 4 | flags
 base = (int(_C.lib().lsi_splat_workspace_bytes(ctypes.byref(r.desc))) + 255) // 256 * 256
