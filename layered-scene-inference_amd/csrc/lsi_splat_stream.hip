@@ -1221,16 +1221,22 @@ __global__ __launch_bounds__(MAXT) void splat_stream_kernel(SplatArgs a,
             LSI_COMPILER_FENCE();
           } else {
           int clv[4];
-          unsigned long long regular = ~0ull;
+          unsigned long long regular = ~0ull, inwin = ~0ull;
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             // left-cell offset in the window (+-Inf saturates; NaN gives
             // offset 0 but both its side weights are then clamped to 0)
             clv[i] = (int)(x0v[i] - wlo_f);
-            regular &= __ballot((unsigned)clv[i] <= wspan);
+            inwin &= __ballot((unsigned)clv[i] <= wspan);
             regular &= __ballot(x0v[i] > lane_below(x0v[i])) | edge_mask;
           }
-          if (((~regular & inr_mask) == 0ull) && fast_ok) {
+          regular &= inwin;
+          // route B': every pixel inside the window but floor(X) not
+          // increasing across the wave (folded disparity fields): the per-pixel
+          // code of route B with the lanes of a cell elected one at a time
+          const bool fold = ((~inwin & inr_mask) == 0ull) && fast_ok &&
+                            ((~regular & inr_mask) != 0ull);
+          if ((((~regular & inr_mask) == 0ull) && fast_ok) || fold) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
               float w0 = w0v[i], w1 = w1v[i];
@@ -1254,12 +1260,30 @@ __global__ __launch_bounds__(MAXT) void splat_stream_kernel(SplatArgs a,
               }
               float4* cell = rb + (clv[i] >> 1) + (clv[i] & 1) * WHS;
               float4* cell1 = rb + ((clv[i] + 1) >> 1) + ((clv[i] + 1) & 1) * WHS;
-              if (FULL || inrange) {
-                *cell = f4_fma(*cell, V, w0);
+              if (!fold) {
+                if (FULL || inrange) {
+                  *cell = f4_fma(*cell, V, w0);
+                  LSI_COMPILER_FENCE();
+                  *cell1 = f4_fma(*cell1, V, w1);
+                }
                 LSI_COMPILER_FENCE();
-                *cell1 = f4_fma(*cell1, V, w1);
+              } else {
+                bool pending = FULL || inrange;
+                for (;;) {
+                  if (__ballot(pending) == 0ull) break;
+                  if (pending) sc[clv[i]] = (unsigned char)lane;
+                  LSI_COMPILER_FENCE();
+                  const bool won = pending && sc[clv[i]] == (unsigned char)lane;
+                  LSI_COMPILER_FENCE();
+                  if (won) {
+                    *cell = f4_fma(*cell, V, w0);
+                    LSI_COMPILER_FENCE();
+                    *cell1 = f4_fma(*cell1, V, w1);
+                  }
+                  LSI_COMPILER_FENCE();
+                  pending = pending && !won;
+                }
               }
-              LSI_COMPILER_FENCE();
             }
           } else {
             // ---- general route, pixel by pixel ------------------------------
