@@ -33,9 +33,11 @@
 //             read-modify-write -- route A: the lane's 4 pixels are summed
 //             into the 4 cells they can reach in registers first (4 RMWs per
 //             lane instead of 8; needs floor(X) strictly increasing across
-//             the wave: one DPP compare + ballot); route B: per pixel; route C:
-//             any order of cells, the lanes of a cell elected one at a time
-//             through a byte table.  Cells live even/odd interleaved so that
+//             the wave: one DPP compare + ballot); route B: per pixel; route
+//             B': per pixel, cells shared between lanes (folded disparity
+//             fields), the lanes of a cell elected one at a time through a
+//             byte table; route C: the general one, also for pixels outside
+//             the window.  Cells live even/odd interleaved so that
 //             lanes two cells apart hit consecutive 16-byte slots.
 //   merge     after a task's last layer the wave adds window * (wy0, wy1) into
 //             the task's two tile rows and clears the window: under the two
