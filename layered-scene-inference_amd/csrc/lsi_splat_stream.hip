@@ -14,7 +14,7 @@
 // 1e-3 clamp on the product (sampling.py:218-222), which is honoured exactly by
 // routing the rare affected corners through an exact slow path.
 //
-// Structure.  Workgroup = (band of target rows, batch element b), NW <= 16 waves.
+// Structure.  Workgroup = (band of target rows, batch element b), NW <= 12 waves.
 //   task  = (source row y, 256-pixel segment j, group of layers).
 //   prologue  wave 0 finds the band's source rows (analytic inverse of Y(y),
 //             verified with the exact fp32 Y) and fills the task table (row
@@ -77,8 +77,12 @@ using namespace lsi;
 namespace {
 
 constexpr int SEG = 256;   // source pixels per task (64 lanes x 4)
+// Threads per workgroup at most: 768 = 12 waves of up to 168 VGPRs.  With 1024
+// (16 waves, 128 VGPRs) the pixel loop spills 8-15 registers (33-53 in the
+// general mode) and every workload measured slower: cfg3 93 vs 88 us, a 4-view
+// shard of cfg3 37 vs 33 us, fwd_both 280 vs 224 us.
 #ifndef LSI_STREAM_MAXT
-#define LSI_STREAM_MAXT 1024
+#define LSI_STREAM_MAXT 768
 #endif
 constexpr int MAXNW = LSI_STREAM_MAXT / 64;
 // lsi_stream_ok's return value: window cells, plus this bit when every batch
@@ -334,10 +338,6 @@ __device__ __forceinline__ void cell_unlock(unsigned a0) {
   asm volatile("ds_write_b32 %0, %1" : : "v"(a0), "v"(zero) : "memory");
 }
 
-// MAXT: the launch bound.  1024 threads = 16 waves of at most 128 VGPRs; the
-// 768-thread instances (the row-lock modes and the general kernel) may take 168
-// VGPRs: no spills in the pixel loop, ~4 % faster at cfg3 / cfg5 when the
-// planner asks for at most 12 waves anyway.
 template <int LAYOUT, bool SIMPLE, int MODE, bool FULL, int MAXT = LSI_STREAM_MAXT>  // LAYOUT 0: channels-last, 1: planar
 __global__ __launch_bounds__(MAXT) void splat_stream_kernel(SplatArgs a,
                                                            StreamCfg cfg) {
@@ -1749,10 +1749,7 @@ static int stream_plan(const LsiSplatDesc* d, int wmax, bool both,
         if (force_cell == 1 && cell == 1) continue;
         StreamPlan local; local.nw = 0; local.est = -1.0;
         double local_pref = 0.0;
-        // (the general kernel -- masks, per-layer outputs, both outputs --
-        // spills 33-53 VGPRs under the 128-register bound of 16 waves: its
-        // plans stay within the 12 waves of the 168-register instances)
-        for (int c = lean ? MAXNW : (MAXNW < 12 ? MAXNW : 12); c >= 4; --c) {
+        for (int c = MAXNW; c >= 4; --c) {
           if (d->tune_threads > 0 && c != (d->tune_threads + 63) / 64) continue;
           int q = 64;
           const int trows = (R + xch) * (both ? 2 : 1);
@@ -1762,7 +1759,7 @@ static int stream_plan(const LsiSplatDesc* d, int wmax, bool both,
           if (q < 16) continue;
           const size_t lds = stream_lds_bytes(d, trows, c, wmax, cap, q, cell);
           long k = (long)(160 * 1024 / lds);   // co-resident workgroups per CU
-          if (k > MAXNW / c) k = MAXNW / c;    // (128 VGPRs: 16 waves per CU)
+          if (k > MAXNW / c) k = MAXNW / c;    // (168 VGPRs: 12 waves per CU)
           if (k < 1) k = 1;
           const long kk = (nwg + 255) / 256 < k ? (nwg + 255) / 256 : k;
           const long rounds = (nwg + 256 * kk - 1) / (256 * kk);
@@ -1882,11 +1879,7 @@ int lsi_stream_launch(const SplatArgs& a, hipStream_t stream) {
   const bool lean = (d->flags & LSI_COMPOSE) && !(d->flags & LSI_HAS_MASK);
   const int mode = lean ? (cfg.exchange ? 2 : 1) + (plan.cell ? 2 : 0) : 0;
   const void* fn;
-#define LSI_PICK3(L_, S_, M_, F_)                                              \
-  ((M_ <= 2) && narrow                                                          \
-       ? (const void*)splat_stream_kernel<L_, S_, M_, F_,                       \
-                                          (M_ <= 2) ? 768 : LSI_STREAM_MAXT>    \
-       : (const void*)splat_stream_kernel<L_, S_, M_, F_>)
+#define LSI_PICK3(L_, S_, M_, F_) ((const void*)splat_stream_kernel<L_, S_, M_, F_>)
 #define LSI_PICK2(L_, S_, M_) \
   (full ? LSI_PICK3(L_, S_, M_, true) : LSI_PICK3(L_, S_, M_, false))
 #define LSI_PICK(L_, S_) \
@@ -1894,7 +1887,6 @@ int lsi_stream_launch(const SplatArgs& a, hipStream_t stream) {
    mode == 3 ? LSI_PICK2(L_, S_, 3) : mode == 4 ? LSI_PICK2(L_, S_, 4) :   \
    LSI_PICK2(L_, S_, 0))
   const bool full = d->W % SEG == 0;
-  const bool narrow = threads <= 768;  // the 168-VGPR instances
   if (layout == 0)
     fn = simple ? LSI_PICK(0, true) : LSI_PICK(0, false);
   else
