@@ -537,11 +537,13 @@ def test_stream_path_rejects_what_it_cannot_render(dev):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('locks', [1, 2])         # 1: row locks, 2: cell locks
 @pytest.mark.parametrize('mode', [1, 2])          # 1: halo bands, 2: exchange
 @pytest.mark.parametrize('band_rows', [1, 4, 16])
-def test_stream_bands_that_do_not_divide_the_image(band_rows, mode, dev):
+def test_stream_bands_that_do_not_divide_the_image(band_rows, mode, locks, dev):
   """66 target rows in bands of 4 or 16: the last band is partial, in both band
-  decompositions (forced through the experiments field)."""
+  decompositions and with both merge exclusions (row locks / per-cell locks
+  where the planner allows them), forced through the experiments field."""
   from lsi.geometry import ldi, projection
   gen = torch.Generator(device='cpu').manual_seed(29)
   nl, b, h, w = 2, 2, 132, 260
@@ -560,7 +562,7 @@ def test_stream_bands_that_do_not_divide_the_image(band_rows, mode, dev):
     for _ in range(2):
       img, wts = ldi.forward_splat_matrix(
           [tex, None, disp], mat, compose_layers=compose, path='stream',
-          band_rows=band_rows, experiment=mode << 16, **kw)
+          band_rows=band_rows, experiment=(mode << 16) | (locks << 18), **kw)
       torch.testing.assert_close(img, ref_img, rtol=0, atol=IMG_ATOL)
       torch.testing.assert_close(wts, ref_wts, rtol=WTS_RTOL, atol=0)
 
