@@ -15,7 +15,8 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, 'csrc')
 SO = os.path.join(PKG, 'liblsi_hip.so')
-SOURCES = ['lsi_splat.hip', 'lsi_splat_stream.hip', 'lsi_splat_tile.hip',
+SOURCES = ['lsi_splat.hip', 'lsi_splat_stream.hip', 'lsi_splat_stream2.hip',
+           'lsi_splat_tile.hip',
            'lsi_splat_sweep.hip',
            'lsi_sampling.hip', 'lsi_loss.hip']
 HEADERS = [os.path.join(CSRC, 'lsi_common.h'),

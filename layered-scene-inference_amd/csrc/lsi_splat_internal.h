@@ -28,6 +28,10 @@ struct SplatArgs {
 // LSI_PATH_STREAM launcher and workspace need (lsi_splat_stream.hip).
 size_t lsi_stream_workspace_bytes(const LsiSplatDesc* d);
 int lsi_stream_launch(const SplatArgs& a, hipStream_t stream);
+// The compact STREAM instance (lsi_splat_stream2.hip): compose mode, no mask,
+// unit normaliser, channels-last textures, rows of whole 256-pixel segments.
+bool lsi_stream2_applies(const SplatArgs& a, bool simple, int layout);
+int lsi_stream2_launch(const SplatArgs& a, int wmax, hipStream_t stream);
 
 // LSI_PATH_TILE launcher and workspace need (lsi_splat_tile.hip).
 size_t lsi_tile_workspace_bytes(const LsiSplatDesc* d);

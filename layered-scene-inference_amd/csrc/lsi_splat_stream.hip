@@ -1820,6 +1820,8 @@ int lsi_stream_launch(const SplatArgs& a, hipStream_t stream) {
     return LSI_EINVAL;
   if ((d->tune_window & ~LSI_STREAM_SIMPLE_BIT) <= 0)
     return LSI_EINVAL;  // from lsi_stream_ok
+  if (lsi_stream2_applies(a, (d->tune_window & LSI_STREAM_SIMPLE_BIT) != 0, layout))
+    return lsi_stream2_launch(a, d->tune_window & ~LSI_STREAM_SIMPLE_BIT, stream);
   const int NB = (d->Wt + 63) / 64;
   StreamCfg cfg;
   cfg.wmax = d->tune_window & ~LSI_STREAM_SIMPLE_BIT;

@@ -1,0 +1,1218 @@
+// LSI_PATH_STREAM, compact instance: the configuration every documented
+// command of the reference runs (ldi.py:71-182 with compose_layers=True, no
+// mask input, rectified stereo with unit normaliser, channels-last textures,
+// rows that are whole 256-pixel segments).  Same algorithm and the same exact
+// arithmetic as splat_stream_kernel (lsi_splat_stream.hip, which keeps every
+// other case); what differs is everything around the pixel arithmetic:
+//   * no prologue before the first loads: every wave finds the band's source
+//     rows itself, takes its first task by wave index and has NSETS items of
+//     loads in flight BEFORE the tile is cleared and the task table is filled
+//     (small launches are bound by this start-up, not by bandwidth);
+//   * the zbuffer weight is one fused multiply-add + exp2 (pre-scaled
+//     constants), side weights come from one subtraction, the epilogue uses a
+//     reciprocal: none of them feeds an index or a threshold decision;
+//   * queue overflow (rare) is one out-of-line function instead of code
+//     inlined at every push site: the kernel is ~10 KB of instructions instead
+//     of ~55 KB (first execution of a code region is an instruction-cache miss
+//     per workgroup);
+//   * window slots and tile addresses of the merge are per-lane constants.
+// Exactness contract: identical to lsi_splat_stream.hip (see its header and
+// lsi_common.h): projected cells and every clamp decision bit-exact.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "../../include/lsi_hip.h"
+#include "lsi_common.h"
+#include "lsi_splat_internal.h"
+
+#pragma clang fp contract(off)
+
+using namespace lsi;
+
+namespace {
+
+constexpr int SEG = 256;  // source pixels per task (64 lanes x 4)
+
+struct __attribute__((aligned(16))) Task {
+  int row0;        // target row of the task's top contribution, band-relative
+  float wy0, wy1;  // row weights incl. border masks; both 0: nothing to do
+  int win;         // window: (first cell + 32768) | number of cells << 16
+};
+struct __attribute__((aligned(8))) TaskX {
+  int yx;      // source row | segment << 16
+  float tmin;  // clamp threshold of the smaller row weight
+};
+// Ticket -> (row-segment unit, layers).  The first `nfull` tickets are whole
+// units (all L layers: one merge per unit); the remaining `nsplit` units are
+// handed out `lsub` layers per ticket (unit-minor order: concurrent tickets
+// belong to different units), so that the waves of a short band all have work
+// (a unit is L items on one wave, and a short band has fewer than two units
+// per wave).
+struct Unit { int u, l0, nl; };
+
+struct S2Args {
+  const float* tex;
+  const float* disp;
+  const float* M;
+  float* out_img;
+  float* out_wts;
+  int B, H, Ht, Wt, L, nseg;
+  int tex_sl, tex_sb, tex_sy, disp_sl, disp_sb, disp_sy;  // element strides
+  float s, max_disp, zA, zB, lbg;  // exp2(fma(clip(d), zA, zB)); L * bg weight
+  int R, wmax, qcap, cap, ilv;     // band rows, window cells, queue, table, row interleave
+  int nsplit, lsub;                // units handed out lsub layers per ticket
+  float inv_gx, inv_nseg;
+  long long* stamps;  // S2X_STAMPS build: [workgroup][wave][8] wall-clock ticks
+};
+
+#define S2_FENCE() asm volatile("" ::: "memory")
+#define S2_RFL(x) __builtin_amdgcn_readfirstlane(x)
+
+__device__ __forceinline__ int s2_div_small(int n, int d, float rcp) {
+  int q = (int)((float)n * rcp);
+  const int r = n - q * d;
+  q += (r >= d) ? 1 : 0;
+  q -= (r < 0) ? 1 : 0;
+  return q;
+}
+
+// Ticket order of a band with `nsrc` source rows (see Unit above, and the row
+// interleave: consecutive tickets go to source rows a fifth of the band apart,
+// so that the units in flight merge into different tile rows; short bands keep
+// the natural order).
+struct BandOrder {
+  int nsrc, nrow_pad, q5, nunit, nsplit, nfull, lsub, ntask;
+  float inv_nsplit;
+};
+__device__ __forceinline__ BandOrder s2_band_order(const S2Args& a, int nsrc) {
+  BandOrder o;
+  o.nsrc = nsrc;
+  o.nrow_pad = a.ilv ? (nsrc + 4) / 5 * 5 : nsrc;
+  o.q5 = o.nrow_pad / 5;
+  o.nunit = o.nrow_pad * a.nseg;
+  o.nsplit = min(a.nsplit, o.nunit);
+  o.nfull = o.nunit - o.nsplit;
+  o.lsub = max(a.lsub, 1);
+  o.ntask = o.nfull + o.nsplit * ((a.L + o.lsub - 1) / o.lsub);
+  o.inv_nsplit = __builtin_amdgcn_rcpf((float)max(o.nsplit, 1));
+  return o;
+}
+__device__ __forceinline__ Unit s2_unit_of(const S2Args& a, const BandOrder& o, int tg) {
+  Unit un;
+  if (tg < o.nfull) { un.u = tg; un.l0 = 0; un.nl = a.L; return un; }
+  const int j = tg - o.nfull;
+  const int part = s2_div_small(j, o.nsplit, o.inv_nsplit);
+  un.u = o.nfull + (j - part * o.nsplit);
+  un.l0 = part * o.lsub;
+  un.nl = min(o.lsub, a.L - un.l0);
+  return un;
+}
+// unit -> row of the band (may be a padding row >= nsrc) and segment
+__device__ __forceinline__ int s2_unit_row(const S2Args& a, const BandOrder& o, int u,
+                                           int& sg) {
+  const int yi = (int)(((float)u + 0.5f) * a.inv_nseg);
+  sg = u - yi * a.nseg;
+  if (!a.ilv) return yi;
+  const int y5 = (int)(((float)yi + 0.5f) * 0.2f);
+  return (yi - 5 * y5) * o.q5 + y5;
+}
+// The unit a wave takes without a ticket (ticket == its wave index), as
+// (row of the band, segment, first layer, layers); nl == 0: none.
+struct Aim { int yr, sg, l0, nl; };
+__device__ __forceinline__ Aim s2_own_unit(const S2Args& a, const BandOrder& o, int wave) {
+  Aim r; r.yr = 0; r.sg = 0; r.l0 = 0; r.nl = 0;
+  if (wave >= min(a.cap, o.ntask)) return r;
+  const Unit un = s2_unit_of(a, o, wave);
+  int sg;
+  const int yr = s2_unit_row(a, o, un.u, sg);
+  if (yr >= o.nsrc) return r;
+  r.yr = yr; r.sg = sg; r.l0 = un.l0; r.nl = un.nl;
+  return r;
+}
+
+__device__ __forceinline__ float s2_next_up(float t) {
+  return __int_as_float(__float_as_int(t) + 1);
+}
+__device__ __forceinline__ float s2_next_down(float t) {
+  return __int_as_float(__float_as_int(t) - 1);
+}
+// Smallest side weight w with fl(w * wy) > 1e-3f (sampling.py:218-222); see
+// clamp_threshold in lsi_splat_stream.hip.
+__device__ __forceinline__ float s2_clamp_threshold(float wy) {
+  if (!(wy > 0.0f)) return __builtin_inff();
+  float t = div_rn(1.0e-3f, wy);
+  if (!(t < 4.0f)) return __builtin_inff();
+  for (int k = 0; k < 8; ++k) {
+    const float p = s2_next_down(t);
+    if (p * wy > 1.0e-3f) t = p; else break;
+  }
+  for (int k = 0; k < 8; ++k) {
+    if (!(t * wy > 1.0e-3f)) t = s2_next_up(t); else break;
+  }
+  return t;
+}
+__device__ __forceinline__ float s2_lane_below(float v) {
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x138, 0xf,
+                                                 0xf, true));
+}
+__device__ __forceinline__ float4 s2_fma4(float4 t, float4 v, float w) {
+  t.x = __fmaf_rn(v.x, w, t.x); t.y = __fmaf_rn(v.y, w, t.y);
+  t.z = __fmaf_rn(v.z, w, t.z); t.w = __fmaf_rn(v.w, w, t.w);
+  return t;
+}
+__device__ __forceinline__ int s2_try1(unsigned a0) {
+  int o;
+  const int one = 1;
+  asm volatile("ds_wrxchg_rtn_b32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)"
+               : "=&v"(o) : "v"(a0), "v"(one) : "memory");
+  return o;
+}
+__device__ __forceinline__ void s2_try2(unsigned a0, unsigned a1, int& o0, int& o1) {
+  const int one = 1;
+  asm volatile(
+      "ds_wrxchg_rtn_b32 %0, %2, %4\n\tds_wrxchg_rtn_b32 %1, %3, %4\n\ts_waitcnt lgkmcnt(0)"
+      : "=&v"(o0), "=&v"(o1)
+      : "v"(a0), "v"(a1), "v"(one)
+      : "memory");
+}
+__device__ __forceinline__ void s2_unlock(unsigned a0) {
+  const int zero = 0;
+  asm volatile("ds_write_b32 %0, %1" : : "v"(a0), "v"(zero) : "memory");
+}
+
+// Row locks (workgroup scope).
+__device__ __forceinline__ void s2_lock_row(int* locks, int r, int lane) {
+  if (lane == 0) {
+    for (;;) {
+      int expect = 0;
+      if (__hip_atomic_compare_exchange_strong(&locks[r], &expect, 1,
+                                               __ATOMIC_ACQUIRE, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_WORKGROUP))
+        break;
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+__device__ __forceinline__ void s2_unlock_row(int* locks, int r, int lane) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if (lane == 0)
+    __hip_atomic_store(&locks[r], 0, __ATOMIC_RELEASE,
+                       __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// The wave's queue of (tile cell, value) records -> tile.  CELL: under the
+// cells' try-locks; else the caller holds the rows' locks.
+template <bool CELL>
+__device__ __forceinline__ void s2_apply_queue(float4* tile4, unsigned clk_addr,
+                                               const float4* qv, const int* qc,
+                                               int qn, int lane) {
+  if (CELL) {
+    for (int i0 = 0; i0 < qn; i0 += 64) {
+      const int i = i0 + lane;
+      bool pred = i < qn;
+      const int tcell = pred ? qc[i] : 0;
+      const float4 v = pred ? qv[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      const unsigned la = clk_addr + (unsigned)tcell * 4u;
+      while (__ballot(pred) != 0ull) {
+        if (pred && s2_try1(la) == 0) {
+          float4* e = tile4 + tcell;
+          float4 t = *e;
+          t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+          *e = t;
+          S2_FENCE();
+          s2_unlock(la);
+          pred = false;
+        }
+      }
+    }
+    return;
+  }
+  float* extras = reinterpret_cast<float*>(tile4);
+  for (int i = lane; i < qn; i += 64) {
+    const float4 v = qv[i];
+    float* e = extras + (long)qc[i] * 4;
+    atomic_add_f32(e + 0, v.x);  // two records may name the same cell
+    atomic_add_f32(e + 1, v.y);
+    atomic_add_f32(e + 2, v.z);
+    atomic_add_f32(e + 3, v.w);
+  }
+}
+
+// Queue full in the middle of a task (rare): empty it into the tile now.  Out
+// of line -- one copy instead of one per push site.  rowA / rowB: the tile
+// rows the records can name (-1: none).  Everything is handed over as LDS byte
+// offsets and used through address-space-3 pointers: generic pointers would
+// turn the accesses into FLAT instructions, and flat fp32 atomics on the LDS
+// aperture fault.
+typedef __attribute__((address_space(3))) float LdsF;
+typedef __attribute__((address_space(3))) int LdsI;
+template <bool CELL>
+__device__ __noinline__ void s2_flush_queue(unsigned tile_off, unsigned locks_off,
+                                            unsigned clk_off, unsigned qv_off,
+                                            unsigned qc_off, int qn, int lane,
+                                            int rowA, int rowB) {
+  LdsF* const tile = reinterpret_cast<LdsF*>(tile_off);
+  LdsI* const locks = reinterpret_cast<LdsI*>(locks_off);
+  LdsF* const qv = reinterpret_cast<LdsF*>(qv_off);
+  LdsI* const qc = reinterpret_cast<LdsI*>(qc_off);
+  if (CELL) {
+    for (int i0 = 0; i0 < qn; i0 += 64) {
+      const int i = i0 + lane;
+      bool pred = i < qn;
+      const int tcell = pred ? qc[i] : 0;
+      float v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = pred ? qv[4 * i + k] : 0.0f;
+      const unsigned la = clk_off + (unsigned)tcell * 4u;
+      while (__ballot(pred) != 0ull) {
+        if (pred && s2_try1(la) == 0) {
+          LdsF* e = tile + 4 * tcell;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) e[k] = e[k] + v[k];
+          S2_FENCE();
+          s2_unlock(la);
+          pred = false;
+        }
+      }
+    }
+    return;
+  }
+  auto lock = [&](int r) {
+    if (lane == 0) {
+      for (;;) {
+        int expect = 0;
+        if (__hip_atomic_compare_exchange_strong(&locks[r], &expect, 1,
+                                                 __ATOMIC_ACQUIRE, __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_WORKGROUP))
+          break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  };
+  auto unlock = [&](int r) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0)
+      __hip_atomic_store(&locks[r], 0, __ATOMIC_RELEASE,
+                         __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+  if (rowA >= 0) lock(rowA);
+  if (rowB >= 0) lock(rowB);
+  for (int i = lane; i < qn; i += 64) {
+    LdsF* e = tile + 4 * qc[i];
+    // (two records may name the same cell)
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      __hip_atomic_fetch_add(e + k, qv[4 * i + k], __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  if (rowB >= 0) unlock(rowB);
+  if (rowA >= 0) unlock(rowA);
+}
+
+struct Px { float4 d4, t0, t1, t2; };
+
+template <int NSETS, bool CELL, int MAXT>
+__global__ __launch_bounds__(MAXT) void splat_stream2_kernel(S2Args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = S2_RFL(tid >> 6);
+  const int T = blockDim.x, NW = T >> 6;
+  const int R = a.R, WMAX = a.wmax;
+  const int Wt = a.Wt, Ht = a.Ht, H = a.H;
+  // XCD-aware placement: workgroup i runs on XCD i % 8; every XCD gets a
+  // contiguous run of bands (neighbouring bands share halo rows: same L2)
+  int b, band;
+  {
+    const unsigned nwg = gridDim.x * gridDim.y;
+    const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
+    const unsigned xcd = lin & 7u, q = nwg >> 3, r8 = nwg & 7u;
+    const unsigned base =
+        xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q;
+    const unsigned id = base + (lin >> 3);
+    b = s2_div_small((int)id, (int)gridDim.x, a.inv_gx);
+    band = (int)id - b * (int)gridDim.x;
+  }
+  // band = target rows [row0, row0 + rows); it reads every source row that
+  // touches them: floor(Y) in [row0 - 1, row0 + rows - 1]
+  const int row0 = band * R;
+  const int rows = min(R, Ht - row0);
+  const int k_lo = row0 - 1, k_hi = row0 + rows - 1;
+
+  // ---- LDS carve ---------------------------------------------------------
+  const int WHS = ((WMAX / 2 + 15) & ~15) + 8;  // slots per window half
+  const int WCELLS = 2 * WHS;
+  float4* const rb_all = reinterpret_cast<float4*>(smem_raw);    // [NW][WCELLS]
+  float4* const tile4 = rb_all + NW * WCELLS;                     // [R][Wt]
+  Task* const task = reinterpret_cast<Task*>(tile4 + R * Wt);     // [cap]
+  TaskX* const taskx = reinterpret_cast<TaskX*>(task + a.cap);    // [cap]
+  int* const ctl = reinterpret_cast<int*>(taskx + a.cap);         // [4]: ticket
+  int* const locks = ctl + 4;                                     // [R]
+  const int Q = a.qcap;
+  float4* const qv_all = reinterpret_cast<float4*>(ctl + ((4 + R + 3) & ~3));
+  int* const qc_all = reinterpret_cast<int*>(qv_all + NW * Q);
+  unsigned char* const sc_all = reinterpret_cast<unsigned char*>(qc_all + NW * Q);
+  int* const clk = reinterpret_cast<int*>(sc_all + ((NW * WMAX + 15) & ~15));  // CELL: [R*Wt]
+  const unsigned clk_addr = (unsigned)(uintptr_t)clk;
+  float4* const rb = rb_all + wave * WCELLS;
+  float4* const qv = qv_all + wave * Q;
+  int* const qc = qc_all + wave * Q;
+  unsigned char* const sc = sc_all + wave * WMAX;
+
+#ifdef S2X_STAMPS
+  long long* const stamp = a.stamps
+      ? a.stamps + (((size_t)b * gridDim.x + band) * 16 + wave) * 8 : nullptr;
+#define S2_STAMP(k) do { if (stamp && lane == 0) stamp[k] = (long long)wall_clock64(); } while (0)
+#else
+#define S2_STAMP(k)
+#endif
+  S2_STAMP(0);
+  // rows 0 and 1 of M, one float per lane, asked for before anything else.
+  // A vector load: its counter retires in order, so the first texture loads
+  // below are issued behind it without waiting for it (scalar loads return out
+  // of order: waiting for any kernel argument would wait for M as well).
+  const float m_lane = a.M[16 * b + (lane & 7)];
+  // ---- loader state ---------------------------------------------------------
+  const float* const g_tex = a.tex + (long)b * a.tex_sb + 12 * lane;
+  const float* const g_disp = a.disp + (long)b * a.disp_sb + 4 * lane;
+  const int tex_sl = a.tex_sl, disp_sl = a.disp_sl;
+  const float* p_disp = g_disp;
+  const float* p_tex = g_tex;
+  int ld_left = 0, ld_done = 0, ld_slot = 0, ld_first = 0;
+  auto aim = [&](int y, int sg, int l0) {
+    p_disp = g_disp + (long)l0 * disp_sl + (long)y * a.disp_sy + sg * SEG;
+    p_tex = g_tex + (long)l0 * tex_sl + (long)y * a.tex_sy + 3 * sg * SEG;
+  };
+  auto load_layer = [&](Px& o) {
+    o.d4 = *reinterpret_cast<const float4*>(p_disp);
+    o.t0 = *reinterpret_cast<const float4*>(p_tex);
+    o.t1 = *reinterpret_cast<const float4*>(p_tex + 4);
+    o.t2 = *reinterpret_cast<const float4*>(p_tex + 8);
+    p_disp += disp_sl;
+    p_tex += tex_sl;
+  };
+  // ---- the wave's own first unit, aimed BEFORE the projection matrix is here --
+  // M is one dependent scalar load from HBM away (~2 us cold).  For a
+  // rectified pair with equal intrinsics Y(y) = (y + .5) s - .5: the wave aims
+  // its first unit with that guess and has its loads in flight while M
+  // arrives; a wrong guess (checked below against the exact row range) costs
+  // one re-issue.
+  Px set[NSETS];
+  int tag[NSETS];
+  int g_y = 0;
+  Aim g_aim;
+  {
+    const float inv_s = __builtin_amdgcn_rcpf(a.s);
+    const int ylo_g = (int)fminf(fmaxf(ceilf(((float)k_lo + 0.5f) * inv_s - 0.5f), 0.0f), (float)H);
+    const int yhi_g = (int)fminf(fmaxf(ceilf(((float)k_hi + 1.5f) * inv_s - 0.5f), 0.0f), (float)H) - 1;
+    const BandOrder bg = s2_band_order(a, max(0, yhi_g - ylo_g + 1));
+    g_aim = s2_own_unit(a, bg, wave);
+    g_y = ylo_g + g_aim.yr;
+    if (g_aim.nl) aim(g_y, g_aim.sg, g_aim.l0);
+    // (always NSETS items of loads -- sets without a layer re-read the first
+    // bytes: the number of loads in flight behind M is then known statically,
+    // and waiting for M does not wait for them)
+#pragma unroll
+    for (int k = 0; k < NSETS; ++k) {
+      if (k == g_aim.nl) { p_disp = g_disp; p_tex = g_tex; }
+      load_layer(set[k]);
+      if (k >= g_aim.nl) { p_disp = g_disp; p_tex = g_tex; }
+    }
+  }
+  // ---- LDS init and the opening barrier: nothing here needs M ---------------
+  {
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = tid; i < NW * WCELLS + rows * Wt; i += T) rb_all[i] = z4;  // windows + tile
+    if (tid < 4 + R) ctl[tid] = (tid == 0) ? NW : 0;  // tickets, arrivals, locks
+    if (CELL)
+      for (int i = tid; i < rows * Wt; i += T) clk[i] = 0;
+  }
+  __syncthreads();
+  float m[8];
+  {
+    float ml = m_lane;
+    asm volatile("" : "+v"(ml));  // (M is not waited for before the barrier)
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      m[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ml), k));
+  }
+  const float s = a.s;
+  const float xmax = (float)Wt - 1.0f, ymax = (float)Ht - 1.0f;
+
+  // Row-uniform target coordinate Y(y) = q1 * s - 0.5 (exact op order; the
+  // normaliser is exactly 1 here)
+  auto row_Y = [&](int y) {
+    const float py = (float)y + 0.5f;
+    return mrow(m, 1, 0.5f, py, 0.0f) * s - 0.5f;
+  };
+
+  // ---- source rows of the band (every wave on its own: no barrier) --------
+  int y_lo = H, y_hi = -1;
+  bool ranged = false;
+  {
+    const float YA = row_Y(0), YB = row_Y(H - 1);
+    const bool ok = finite_f(YA) && finite_f(YB) && fabsf(YA) < 65536.0f &&
+                    fabsf(YB) < 65536.0f &&
+                    (H == 1 || (YB - YA) >= 0.0625f * (float)(H - 1));
+    if (ok) {
+      const float inv_s = __builtin_amdgcn_rcpf(s);  // estimates only
+      const float inv_m5 = __builtin_amdgcn_rcpf(m[5]);
+      auto lower = [&](float k, bool& good) {
+        const float t = (k + 0.5f) * inv_s;
+        const float py = (t - m[6]) * inv_m5;
+        const int c = finite_f(py) ? (int)fminf(fmaxf(ceilf(py - 0.5f), 0.0f),
+                                                (float)H)
+                                   : 0;
+        const int base = max(0, min(c - 32, H - 64));
+        const int y = base + lane;
+        const bool pass_ = y >= H || row_Y(y) >= k;
+        const unsigned long long mask = __ballot(pass_);
+        const int p = mask ? __builtin_ctzll(mask) : 64;
+        good = good && mask == (p < 64 ? (~0ull << p) : 0ull) &&
+               (p > 0 || base == 0) && (p < 64 || base + 64 >= H);
+        return min(base + p, H);
+      };
+      bool good = true;
+      const int lo = lower((float)k_lo, good);
+      const int hi = lower((float)(k_hi + 1), good) - 1;
+      if (good) { y_lo = lo; y_hi = hi; ranged = true; }
+    }
+  }
+  if (!S2_RFL(ranged ? 1 : 0)) {  // maps too flat / decreasing: scan, per wave
+    int lo = H, hi = -1;
+    for (int y = lane; y < H; y += 64) {
+      const float Y = row_Y(y);
+      if (!finite_f(Y)) continue;
+      const float y0 = floorf(Y);
+      if (y0 >= (float)k_lo && y0 <= (float)k_hi) { lo = min(lo, y); hi = max(hi, y); }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      lo = min(lo, __shfl_xor(lo, o));
+      hi = max(hi, __shfl_xor(hi, o));
+    }
+    y_lo = lo; y_hi = hi;
+  }
+  y_lo = S2_RFL(y_lo); y_hi = S2_RFL(y_hi);
+  const int nsrc = (y_hi >= y_lo) ? (y_hi - y_lo + 1) : 0;
+  const BandOrder bo = s2_band_order(a, nsrc);
+  const int ntask = bo.ntask;
+  // the table holds a.cap tickets: one chunk unless the band has more source
+  // rows than the planner assumed (it does not see the matrices)
+  const int CAPT = a.cap;
+  int chunk0 = 0, nchunk = min(CAPT, ntask);
+
+  // One item of loads into dst; returns its tag: -1 (none), or task slot |
+  // bit 20 (first layer of the task) | bit 21 (last).  Always exactly one
+  // load per input array, so that every path has the same number in flight.
+  // Before its first ticket a wave makes sure that every wave has filled its
+  // share of the task table (ctl[1] counts them).
+  int synced = 0;
+  auto table_ready = [&]() {
+    if (!synced) {
+      if (lane == 0) {
+        while (__hip_atomic_load(&ctl[1], __ATOMIC_ACQUIRE,
+                                 __HIP_MEMORY_SCOPE_WORKGROUP) < NW)
+          __builtin_amdgcn_s_sleep(1);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      S2_STAMP(3);
+      synced = 1;
+    }
+  };
+  auto issue = [&](Px& dst) -> int {
+    if (S2_RFL(ld_left) == 0 && S2_RFL(ld_done) == 0) {
+      table_ready();
+      int t = 0;
+      if (lane == 0) t = atomicAdd(&ctl[0], 1);
+      const int sl = S2_RFL(t);
+      if (sl >= nchunk) {
+        ld_done = 1;
+      } else {
+        const Task ta = task[sl];
+        // rows masked at the border add nothing: not even started
+        if (S2_RFL((ta.wy0 != 0.0f || ta.wy1 != 0.0f) ? 1 : 0)) {
+          const int yx = S2_RFL(taskx[sl].yx);
+          const Unit un = s2_unit_of(a, bo, chunk0 + sl);
+          aim(yx & 0xffff, yx >> 16, un.l0);
+          ld_left = un.nl; ld_slot = sl; ld_first = 1 << 20;
+        }
+      }
+    }
+    int tag = -1;
+    const bool have = S2_RFL(ld_left) != 0;
+    if (!have) { p_disp = g_disp; p_tex = g_tex; }  // harmless re-read
+    load_layer(dst);
+    if (have) {
+      ld_left = S2_RFL(ld_left) - 1;
+      tag = ld_slot | ld_first | (ld_left == 0 ? (1 << 21) : 0);
+      ld_first = 0;
+    }
+    return S2_RFL(tag);
+  };
+
+  // ---- the exact first unit: keep the loads in flight, or aim again ---------
+  {
+    const Aim r = s2_own_unit(a, bo, wave);
+    const int r_y = y_lo + r.yr;
+    const bool same = r.nl == g_aim.nl &&
+                      (r.nl == 0 || (r_y == g_y && r.sg == g_aim.sg && r.l0 == g_aim.l0));
+    if (!S2_RFL(same ? 1 : 0) && r.nl) {
+      aim(r_y, r.sg, r.l0);
+#pragma unroll
+      for (int k = 0; k < NSETS; ++k) {
+        if (k == r.nl) { p_disp = g_disp; p_tex = g_tex; }
+        load_layer(set[k]);
+        if (k >= r.nl) { p_disp = g_disp; p_tex = g_tex; }
+      }
+    }
+    const int issued = min(NSETS, r.nl);
+    ld_left = r.nl - issued; ld_slot = wave; ld_first = 0;
+#pragma unroll
+    for (int k = 0; k < NSETS; ++k)
+      tag[k] = k < issued ? (wave | (k == 0 ? (1 << 20) : 0) |
+                             (k == r.nl - 1 ? (1 << 21) : 0))
+                          : -1;
+  }
+  S2_STAMP(1);
+  // table entry of ticket tg (exact row geometry, clamp threshold, window)
+  auto make_task = [&](const int tg, Task& ta, TaskX& tx) {
+    ta.row0 = -1000000; ta.wy0 = 0.f; ta.wy1 = 0.f; ta.win = 0;
+    tx.yx = 0; tx.tmin = __builtin_inff();
+    int sg;
+    const int yr = s2_unit_row(a, bo, s2_unit_of(a, bo, tg).u, sg);
+    const int y = y_lo + yr;
+    const float Y = row_Y(y);
+    if (yr < bo.nsrc && finite_f(Y) && fabsf(Y) < 1.0e7f) {
+      const Axis ay = splat_axis(Y, ymax);
+      ta.row0 = (int)floorf(Y) - row0;
+      ta.wy0 = ay.w0;
+      ta.wy1 = ay.w1;
+      tx.yx = y | (sg << 16);
+      const float wymin =
+          (ay.w0 == 0.f) ? ay.w1 : ((ay.w1 == 0.f) ? ay.w0 : fminf(ay.w0, ay.w1));
+      tx.tmin = s2_clamp_threshold(wymin);
+      // window hint: cells reachable for d in [0, max_disp] on the segment
+      const int xs = sg * SEG;
+      const float py = (float)y + 0.5f;
+      auto x_of = [&](int xx, float dd) {
+        return mrow(m, 0, (float)xx + 0.5f, py, dd) * s - 0.5f;
+      };
+      float lo = __builtin_inff(), hi = -__builtin_inff();
+      if (m[0] > 0.0f) {
+        const bool neg = m[3] < 0.0f;
+        lo = x_of(xs, neg ? a.max_disp : 0.0f);
+        hi = x_of(xs + SEG - 1, neg ? 0.0f : a.max_disp);
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float X = x_of((c & 1) ? (xs + SEG - 1) : xs,
+                               (c & 2) ? a.max_disp : 0.0f);
+          lo = fminf(lo, X); hi = fmaxf(hi, X);
+        }
+      }
+      if (finite_f(lo) && finite_f(hi) && fabsf(lo) < 1.0e7f &&
+          fabsf(hi) < 1.0e7f) {
+        // cells [wlo, wlo + wwin): not confined to the image (cells outside
+        // are dummies the merge drops: the reference's border rule)
+        const int c_lo = max((int)floorf(lo) - 1, -32000);
+        const int c_hi = min((int)floorf(hi) + 4, 32000);
+        const int wwin = max(0, min(WMAX, c_hi - c_lo + 1));
+        ta.win = (c_lo + 32768) | (wwin << 16);
+      }
+    }
+  };
+  // tickets [c0 + first, c0 + n): one ticket per thread
+  auto fill_table = [&](const int c0, const int first, const int n) {
+    for (int sl = first + tid; sl < n; sl += T) {
+      Task ta; TaskX tx;
+      make_task(c0 + sl, ta, tx);
+      task[sl] = ta;
+      taskx[sl] = tx;
+    }
+  };
+  // The wave's own table entry, its share of the other tickets, and "arrived":
+  // the table is complete once every wave has (checked before a wave's first
+  // ticket, by which time it normally is: no wave waits).
+  {
+    if (wave < nchunk) {
+      Task ta; TaskX tx;
+      make_task(wave, ta, tx);
+      if (lane == 0) { task[wave] = ta; taskx[wave] = tx; }
+    }
+    fill_table(0, NW, nchunk);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0)
+      __hip_atomic_fetch_add(&ctl[1], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  S2_STAMP(2);
+
+  // ---- per-wave compute state ---------------------------------------------------
+  const float m3 = m[3];
+  const float zA = a.zA, zB = a.zB, max_disp = a.max_disp;
+  int slot = 0, t_row0 = 0, t_wlo = 0, t_wwin = 0, has_max = 0, rmax_row = 0;
+  int fastA_ok = 0, win_ok = 0;
+  unsigned wspan = 0u, wspanA = 0u;
+  float tmin = 0.f, wy0 = 0.f, wy1 = 0.f, wymin = 0.f, wymax = 0.f, wlo_f = 0.f;
+  int use_a = 0, use_b = 0;
+  float qb[4] = {0.f, 0.f, 0.f, 0.f};
+  int qn = 0;
+  // merge: the lane's window slots (cells lane, lane + 64, ...)
+  const int mslot = (lane >> 1) + (lane & 1) * WHS;
+
+  // (tile cell, value) records for corners the window cannot hold
+  auto flush = [&]() {
+    s2_flush_queue<CELL>((unsigned)(uintptr_t)tile4, (unsigned)(uintptr_t)locks,
+                         clk_addr, (unsigned)(uintptr_t)qv, (unsigned)(uintptr_t)qc,
+                         qn, lane, use_a ? t_row0 : -1, use_b ? t_row0 + 1 : -1);
+    qn = 0;
+  };
+  auto push = [&](bool pred, int tcell, float4 val) {
+    const unsigned long long mask = __ballot(pred);
+    if (mask == 0ull) return;
+    const int n = __builtin_popcountll(mask);
+    if (qn + n > Q) flush();  // full: empty it into the tile now (rare)
+    const int rank = (int)__builtin_amdgcn_mbcnt_hi(
+        (unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+    if (n > Q) {  // (a queue of fewer than 64 records: in rounds of Q lanes)
+      for (int base = 0; base < n; base += Q) {
+        if (pred && rank >= base && rank < base + Q) {
+          qv[rank - base] = val; qc[rank - base] = tcell;
+        }
+        qn = min(Q, n - base);
+        flush();
+      }
+      return;
+    }
+    if (pred) { qv[qn + rank] = val; qc[qn + rank] = tcell; }
+    qn += n;
+  };
+  // exact 4-corner footprint of one pixel (sampling.py:193-222) for lanes whose
+  // cells are not inside the window
+  auto push_corners = [&](bool pred, float4 V, float x0, float gx, float fx) {
+    const float x1 = x0 + 1.0f;
+    const float x0s = fminf(fmaxf(x0, 0.0f), xmax);
+    const float x1s = fminf(fmaxf(x1, 0.0f), xmax);
+    const float wx[2] = {(x0 == x0s) ? gx : 0.0f, (x1 == x1s) ? fx : 0.0f};
+    const int cx[2] = {(int)x0s, (int)x1s};
+    const float wy[2] = {wy0, wy1};
+#pragma unroll 1
+    for (int k = 0; k < 4; ++k) {
+      const int r = t_row0 + (k >> 1);
+      const float c = ((k & 1) ? wx[1] : wx[0]) * ((k >> 1) ? wy[1] : wy[0]);
+      const bool ok = pred && (c > 1.0e-3f) && r >= 0 && r < rows;
+      push(ok, r * Wt + ((k & 1) ? cx[1] : cx[0]),
+           make_float4(V.x * c, V.y * c, V.z * c, V.w * c));
+    }
+  };
+
+  auto item = [&](Px& cur, const int tg_) -> int {
+    const bool live = tg_ >= 0;
+    if (live && (tg_ & (1 << 20))) {  // ---- the item starts a task ----------
+      slot = tg_ & 0xfffff;
+      const Task ta = task[slot];
+      const TaskX tx = taskx[slot];
+      t_row0 = S2_RFL(ta.row0);
+      const int t_win = S2_RFL(ta.win);
+      t_wlo = (t_win & 0xffff) - 32768; t_wwin = t_win >> 16;
+      const int yx = S2_RFL(tx.yx);
+      const int y = yx & 0xffff, xs = (yx >> 16) * SEG;
+      tmin = tx.tmin;
+      const float py = (float)y + 0.5f;
+      const float pym01 = py * m[1];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float px = (float)(xs + 4 * lane + i) + 0.5f;
+        qb[i] = (px * m[0] + pym01) + m[2];
+      }
+      wy0 = ta.wy0; wy1 = ta.wy1;
+      wymin = (wy0 == 0.f) ? wy1 : ((wy1 == 0.f) ? wy0 : fminf(wy0, wy1));
+      wymax = fmaxf(wy0, wy1);
+      wlo_f = (float)t_wlo;
+      const int rmax = t_row0 + ((wy1 > wy0) ? 1 : 0);
+      has_max = S2_RFL(((wymax != wymin) && rmax >= 0 && rmax < rows) ? 1 : 0);
+      rmax_row = S2_RFL(rmax);
+      wspan = (unsigned)max(t_wwin - 2, 0);
+      win_ok = t_wwin >= 2 ? 1 : 0;
+      wspanA = (unsigned)max(t_wwin - 4, 0);
+      fastA_ok = S2_RFL((t_wwin >= 4 && tmin <= 0.5f) ? 1 : 0);
+      use_a = S2_RFL((wy0 != 0.f && t_row0 >= 0 && t_row0 < rows) ? 1 : 0);
+      use_b = S2_RFL((wy1 != 0.f && t_row0 + 1 >= 0 && t_row0 + 1 < rows) ? 1 : 0);
+    }
+    float x0v[4], w0v[4], w1v[4];
+    float4 Vv[4];  // route A: the lane's 4 cell sums; else V of its 4 pixels
+    int cl0 = 0, routeA = 0;
+    if (live) {
+      const float dv[4] = {cur.d4.x, cur.d4.y, cur.d4.z, cur.d4.w};
+      const float tx_[12] = {cur.t0.x, cur.t0.y, cur.t0.z, cur.t0.w,
+                             cur.t1.x, cur.t1.y, cur.t1.z, cur.t1.w,
+                             cur.t2.x, cur.t2.y, cur.t2.z, cur.t2.w};
+      float pwv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        // q0 = ((px*m00 + py*m01) + m02) + d*m03, each op rounded; n' == 1
+        const float q0 = qb[i] + dv[i] * m3;
+        const float X = q0 * s - 0.5f;
+        const float x0 = floorf(X);
+        const float fx = X - x0;
+        // (x0 + 1) - X == 1 - fx exactly for X >= 0; for X < 0 the left cell
+        // is outside the image and its weight is never used
+        const float gx = 1.0f - fx;
+        // helpers.py:180-193 with D = d: exp((clip(d/max,0,1) - 0.5)*scale)
+        const float dc = __builtin_amdgcn_fmed3f(dv[i], 0.0f, max_disp);
+        const float e = __builtin_amdgcn_exp2f(__fmaf_rn(dc, zA, zB));
+#ifdef S2X_NOEXP
+        pwv[i] = dc;
+        (void)e;
+#else
+        pwv[i] = dv[i] > 0.0f ? e : 0.0f;  // (NaN disparity -> weight 0)
+#endif
+        x0v[i] = x0; w0v[i] = gx; w1v[i] = fx;
+      }
+      // ---- route A: the lane's 4 pixels land in cells cl0 .. cl0 + 3 --------
+      cl0 = (int)(x0v[0] - wlo_f);
+      int dl[4];
+      dl[0] = 0;
+      unsigned long long regA =
+          __ballot((unsigned)cl0 <= wspanA) &
+          (__ballot(x0v[0] > s2_lane_below(x0v[0])) | 1ull);
+#pragma unroll
+      for (int i = 1; i < 4; ++i) {
+        dl[i] = (int)(x0v[i] - x0v[0]);
+        regA &= __ballot((unsigned)dl[i] <= 2u);
+      }
+      routeA = S2_RFL(((regA == ~0ull) && fastA_ok) ? 1 : 0);
+#ifdef S2X_NOSUMS
+      if (routeA) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          Vv[k] = make_float4(tx_[3 * k] * pwv[k] * w0v[k], tx_[3 * k + 1] * pwv[k] * w1v[k],
+                              tx_[3 * k + 2] * pwv[k], pwv[k]);
+      } else
+#endif
+      if (routeA) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) Vv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float w0 = w0v[i], w1 = w1v[i];
+          const float4 V = make_float4(tx_[3 * i] * pwv[i], tx_[3 * i + 1] * pwv[i],
+                                       tx_[3 * i + 2] * pwv[i], pwv[i]);
+          // clamp (at most the smaller side: tmin <= 0.5 on this route)
+#ifdef S2X_NOCLAMP
+          if (false) {
+#else
+          if (__ballot(!(fminf(w0, w1) >= tmin)) != 0ull) {
+#endif
+            const bool c0 = !(w0 >= tmin), c1 = !(w1 >= tmin);
+            if (has_max) {
+              const float kq = (c0 ? w0 : w1) * wymax;
+              const int cellq = t_wlo + cl0 + dl[i] + (c0 ? 0 : 1);
+              push((c0 || c1) && kq > 1.0e-3f && (unsigned)cellq < (unsigned)Wt,
+                   rmax_row * Wt + cellq,
+                   make_float4(V.x * kq, V.y * kq, V.z * kq, V.w * kq));
+            }
+            if (c0) w0 = 0.0f;
+            if (c1) w1 = 0.0f;
+          }
+          if (i == 0) {
+            Vv[0] = make_float4(V.x * w0, V.y * w0, V.z * w0, V.w * w0);
+            Vv[1] = make_float4(V.x * w1, V.y * w1, V.z * w1, V.w * w1);
+          } else {
+            const bool e0 = dl[i] == 0, e1 = dl[i] == 1, e2 = dl[i] == 2;
+            const float a0 = e0 ? w0 : 0.0f;
+            const float a1 = e1 ? w0 : (e0 ? w1 : 0.0f);
+            const float a2 = e2 ? w0 : (e1 ? w1 : 0.0f);
+            const float a3 = e2 ? w1 : 0.0f;
+            Vv[0] = s2_fma4(Vv[0], V, a0);
+            Vv[1] = s2_fma4(Vv[1], V, a1);
+            Vv[2] = s2_fma4(Vv[2], V, a2);
+            Vv[3] = s2_fma4(Vv[3], V, a3);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          Vv[i] = make_float4(tx_[3 * i] * pwv[i], tx_[3 * i + 1] * pwv[i],
+                              tx_[3 * i + 2] * pwv[i], pwv[i]);
+      }
+      // pinned: the projection is not sunk below the loads, which then
+      // overwrite dead registers
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        asm volatile("" : "+v"(Vv[i].x), "+v"(Vv[i].y), "+v"(Vv[i].z),
+                          "+v"(Vv[i].w), "+v"(x0v[i]), "+v"(w0v[i]), "+v"(w1v[i]));
+    }
+    const int next_tag = issue(cur);  // the set takes the item NSETS ahead
+    if (live) {
+      if (routeA) {
+        const int par = cl0 & 1, hlf = cl0 >> 1;
+        float4* ce = rb + hlf + par * WHS;              // cell cl0 (and cl0 + 2)
+        float4* co = rb + hlf + par + (1 - par) * WHS;  // cell cl0 + 1 (and + 3)
+        float4 t;
+#ifndef S2X_NOWIN
+        t = ce[0]; t.x += Vv[0].x; t.y += Vv[0].y; t.z += Vv[0].z; t.w += Vv[0].w; ce[0] = t;
+        S2_FENCE();
+        t = co[0]; t.x += Vv[1].x; t.y += Vv[1].y; t.z += Vv[1].z; t.w += Vv[1].w; co[0] = t;
+        S2_FENCE();
+        t = ce[1]; t.x += Vv[2].x; t.y += Vv[2].y; t.z += Vv[2].z; t.w += Vv[2].w; ce[1] = t;
+        S2_FENCE();
+        t = co[1]; t.x += Vv[3].x; t.y += Vv[3].y; t.z += Vv[3].z; t.w += Vv[3].w; co[1] = t;
+#else
+        t = ce[0]; t.x += Vv[0].x + Vv[1].x + Vv[2].x + Vv[3].x; t.y += Vv[0].y + Vv[1].y + Vv[2].y + Vv[3].y;
+        t.z += Vv[0].z + Vv[1].z + Vv[2].z + Vv[3].z; t.w += Vv[0].w + Vv[1].w + Vv[2].w + Vv[3].w;
+        if (t.x == 123.456f) ce[0] = t;
+        (void)co;
+#endif
+        S2_FENCE();
+      } else {
+        // ---- per pixel (one copy of the code; the pixel's values are
+        // selected).  In-window lanes whose cells are distinct add directly;
+        // folded fields elect the lanes of a cell one at a time through a byte
+        // table; lanes outside the window take the exact 4-corner path.
+#pragma unroll 1
+        for (int i = 0; i < 4; ++i) {
+          auto pick = [&](float a0, float a1, float a2, float a3) {
+            return i == 0 ? a0 : (i == 1 ? a1 : (i == 2 ? a2 : a3));
+          };
+          const float x0 = pick(x0v[0], x0v[1], x0v[2], x0v[3]);
+          float w0 = pick(w0v[0], w0v[1], w0v[2], w0v[3]);
+          float w1 = pick(w1v[0], w1v[1], w1v[2], w1v[3]);
+          const float4 V = make_float4(
+              pick(Vv[0].x, Vv[1].x, Vv[2].x, Vv[3].x),
+              pick(Vv[0].y, Vv[1].y, Vv[2].y, Vv[3].y),
+              pick(Vv[0].z, Vv[1].z, Vv[2].z, Vv[3].z),
+              pick(Vv[0].w, Vv[1].w, Vv[2].w, Vv[3].w));
+          const int cl = (int)(x0 - wlo_f);
+          const bool inw = ((unsigned)cl <= wspan) && win_ok;
+          const unsigned long long inw_mask = __ballot(inw);
+          const unsigned long long mono_ok =
+              __ballot(x0 > s2_lane_below(x0)) | 1ull;
+          // clamped sides: !(p > 1e-3) is also true for NaN weights
+          const bool c0 = !(w0 * wymin > 1.0e-3f);
+          const bool c1 = !(w1 * wymin > 1.0e-3f);
+          if (has_max) {
+            const float k0 = w0 * wymax, k1 = w1 * wymax;
+            const int cm = rmax_row * Wt + t_wlo + cl;
+            push(inw && c0 && k0 > 1.0e-3f &&
+                     (unsigned)(t_wlo + cl) < (unsigned)Wt, cm,
+                 make_float4(V.x * k0, V.y * k0, V.z * k0, V.w * k0));
+            push(inw && c1 && k1 > 1.0e-3f &&
+                     (unsigned)(t_wlo + cl + 1) < (unsigned)Wt, cm + 1,
+                 make_float4(V.x * k1, V.y * k1, V.z * k1, V.w * k1));
+          }
+          if (inw_mask != ~0ull)
+            push_corners(!inw && V.w != 0.0f, V, x0, w0, w1);
+          if (c0) w0 = 0.0f;
+          if (c1) w1 = 0.0f;
+          float4* cell = rb + (cl >> 1) + (cl & 1) * WHS;
+          float4* cell1 = rb + ((cl + 1) >> 1) + ((cl + 1) & 1) * WHS;
+          if (mono_ok == ~0ull) {
+            if (inw) {
+              *cell = s2_fma4(*cell, V, w0);
+              S2_FENCE();
+              *cell1 = s2_fma4(*cell1, V, w1);
+            }
+            S2_FENCE();
+          } else if (inw_mask != 0ull) {
+            bool pending = inw;
+            for (;;) {
+              if (__ballot(pending) == 0ull) break;
+              if (pending) sc[cl] = (unsigned char)lane;
+              S2_FENCE();
+              const bool won = pending && sc[cl] == (unsigned char)lane;
+              S2_FENCE();
+              if (won) {
+                *cell = s2_fma4(*cell, V, w0);
+                S2_FENCE();
+                *cell1 = s2_fma4(*cell1, V, w1);
+              }
+              S2_FENCE();
+              pending = pending && !won;
+            }
+          }
+        }
+      }
+      if (tg_ & (1 << 21)) {
+        // ---- last layer done: window -> the task's two tile rows ------------
+#ifndef S2X_NOLOCK
+        if (!CELL) {  // ascending order: no deadlock
+          if (use_a) s2_lock_row(locks, t_row0, lane);
+          if (use_b) s2_lock_row(locks, t_row0 + 1, lane);
+        }
+#endif
+        if (qn != 0) {
+          s2_apply_queue<CELL>(tile4, clk_addr, qv, qc, qn, lane);
+          qn = 0;
+        }
+        float4* const trow = tile4 + (long)t_row0 * Wt + t_wlo + lane;
+        float4* const wrow = rb + mslot;
+        const int c_in = t_wlo + lane;
+        if (CELL) {
+          const unsigned lrow = clk_addr + (unsigned)(t_row0 * Wt + t_wlo + lane) * 4u;
+          for (int c = 0; c + lane < t_wwin; c += 64) {
+            float4* wc = wrow + (c >> 1);
+            const float4 v = *wc;
+            *wc = make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool inside = (unsigned)(c_in + c) < (unsigned)Wt;
+            bool na = use_a && inside, nb = use_b && inside;
+            const unsigned la = lrow + (unsigned)c * 4u, lb = la + (unsigned)Wt * 4u;
+            while (__ballot(na || nb) != 0ull) {
+              if (na && nb) {
+                int oa, ob;
+                s2_try2(la, lb, oa, ob);
+                if (oa == 0) { trow[c] = s2_fma4(trow[c], v, wy0); }
+                if (ob == 0) { trow[Wt + c] = s2_fma4(trow[Wt + c], v, wy1); }
+                S2_FENCE();
+                if (oa == 0) { s2_unlock(la); na = false; }
+                if (ob == 0) { s2_unlock(lb); nb = false; }
+              } else if (na) {
+                if (s2_try1(la) == 0) {
+                  trow[c] = s2_fma4(trow[c], v, wy0);
+                  S2_FENCE();
+                  s2_unlock(la);
+                  na = false;
+                }
+              } else if (nb) {
+                if (s2_try1(lb) == 0) {
+                  trow[Wt + c] = s2_fma4(trow[Wt + c], v, wy1);
+                  S2_FENCE();
+                  s2_unlock(lb);
+                  nb = false;
+                }
+              }
+            }
+          }
+        } else {
+          for (int c = 0; c + lane < t_wwin; c += 64) {
+            float4* wc = wrow + (c >> 1);
+            const float4 v = *wc;
+            *wc = make_float4(0.f, 0.f, 0.f, 0.f);  // ready for the next task
+            const bool inside = (unsigned)(c_in + c) < (unsigned)Wt;
+#ifndef S2X_NOMERGE
+            if (use_a && inside) trow[c] = s2_fma4(trow[c], v, wy0);
+            if (use_b && inside) trow[Wt + c] = s2_fma4(trow[Wt + c], v, wy1);
+#else
+            if (inside && v.x == 123.456f) trow[c] = v;
+#endif
+          }
+#ifndef S2X_NOLOCK
+          if (use_b) s2_unlock_row(locks, t_row0 + 1, lane);
+          if (use_a) s2_unlock_row(locks, t_row0, lane);
+#endif
+        }
+      }
+    }
+    return next_tag;
+  };
+
+  for (;;) {
+    for (;;) {
+      int any = ld_done == 0;
+#pragma unroll
+      for (int k = 0; k < NSETS; ++k) any |= tag[k] >= 0;
+      if (!S2_RFL(any ? 1 : 0)) break;
+#pragma unroll
+      for (int k = 0; k < NSETS; ++k) tag[k] = item(set[k], tag[k]);
+    }
+    chunk0 += CAPT;
+    if (chunk0 >= ntask) break;
+    __syncthreads();  // (every wave is done with this chunk's table)
+    nchunk = min(CAPT, ntask - chunk0);
+    fill_table(chunk0, 0, nchunk);
+    if (tid == 0) ctl[0] = 0;
+    synced = 1;
+    ld_done = 0;
+    __syncthreads();
+  }
+  S2_STAMP(4);
+  __syncthreads();  // every window is merged: the tile is complete
+  S2_STAMP(5);
+
+  // ---- epilogue: (tile + background) normalised, each output written once --
+  {
+    const float lbg = a.lbg;
+    const size_t P = (size_t)Ht * Wt;
+    float* const oi = a.out_img + ((size_t)b * P + (size_t)row0 * Wt) * 3;
+    float* const ow = a.out_wts + (size_t)b * P + (size_t)row0 * Wt;
+    const int ncell = rows * Wt;
+    for (int i = tid; i < ncell; i += T) {
+      const float4 A = tile4[i];
+      const float Wsum = A.w + lbg;
+      const float rw = __builtin_amdgcn_rcpf(safe_den(Wsum));
+      oi[3 * i + 0] = (A.x + lbg) * rw;
+      oi[3 * i + 1] = (A.y + lbg) * rw;
+      oi[3 * i + 2] = (A.z + lbg) * rw;
+      ow[i] = Wsum;
+    }
+  }
+  S2_STAMP(6);
+}
+
+size_t s2_lds_bytes(int R, int Wt, int nw, int wmax, int cap, int qcap, int cell) {
+  const int whs = ((wmax / 2 + 15) & ~15) + 8;
+  return (size_t)nw * 2 * whs * 16 + (size_t)R * Wt * 16 +
+         (size_t)cap * (sizeof(Task) + sizeof(TaskX)) +
+         (size_t)((4 + R + 3) & ~3) * 4 + (size_t)nw * qcap * 20 +
+         (size_t)((nw * wmax + 15) & ~15) + (cell ? (size_t)R * Wt * 4 : 0) + 16;
+}
+
+struct S2Plan { int R, nw, cell, cap, qcap, ilv, nsplit, lsub; size_t lds; double est; };
+
+// Band height, waves per workgroup, how many row-segment units are handed out
+// layer by layer.  Grounded in measurements (profiles/r03/): a launch streams
+// at ~5.7 TB/s once every CU has a workgroup with >= 48 KB of loads in flight;
+// what a launch loses is its start (first loads ~3 us after the workgroup
+// starts), its tail (waves of a workgroup and workgroups of a launch finish
+// apart) and whole rounds of workgroups: so one workgroup per CU (the LDS tile
+// allows only one) in ONE round, as many waves as fit, the tallest band that
+// still gives every CU a workgroup.
+int s2_plan(const LsiSplatDesc* d, int wmax, int maxnw, S2Plan* out) {
+  const int nseg = d->W / SEG;
+  static const char* cap_env = getenv("LSI_STREAM_LDS_CAP");
+  const size_t lds_cap = cap_env ? (size_t)atol(cap_env) : 160 * 1024;
+  static const char* ns_env = getenv("LSI_S2_NSPLIT");  // experiments
+  static const char* ls_env = getenv("LSI_S2_LSUB");
+  const int force_cell = (d->reserved >> 18) & 3;
+  const double NCU = 256.0, CHIP_GBPS = 5700.0, CU_GBPS = 32.0;
+  S2Plan best; best.est = -1.0; best.nw = 0;
+  for (int R = 1; R <= 64; R *= 2) {
+    if (d->tune_rows > 0 && R != d->tune_rows) continue;
+    if (d->tune_rows <= 0 && R > 1 && R / 2 >= d->Ht) break;
+    const long nwg = (long)((d->Ht + R - 1) / R) * d->B;
+    const int srows = (int)ceilf((float)(R + 1) / d->trg_downsampling);
+    const int ilv = srows >= 15 ? 1 : 0;
+    const int nrow = ilv ? (srows + 4) / 5 * 5 : srows;
+    const int nunit = nrow * nseg;
+    int cell = (R <= 8 && nunit <= 40) ? 1 : 0;
+    if (force_cell == 1) cell = 0;
+    if (force_cell == 2) cell = 1;
+    for (int c = maxnw; c >= 2; --c) {
+      if (d->tune_threads > 0 && c != (d->tune_threads + 63) / 64) continue;
+      // A unit is all L layers of a row segment on one wave (one merge per
+      // unit).  Units are handed out whole up to 6 layers; deeper LDIs in
+      // parts of at most 4 layers, so that a wave's last unit stays short.
+      // (Measured at L = 4: halves or single layers cost more in merges and
+      // task switches than they win in balance -- cfg3 86 -> 87..154 us, a
+      // 4-view shard 22 -> 24..31 us.)  reserved bits 12-15 (tests,
+      // experiments): layers per ticket for every unit.
+      int lsub = d->L <= 6 ? d->L : (d->L + (d->L + 3) / 4 - 1) / ((d->L + 3) / 4);
+      const int sub_override = (d->reserved >> 12) & 0xf;
+      if (sub_override) lsub = sub_override < d->L ? sub_override : d->L;
+      if (ls_env) lsub = atoi(ls_env);
+      if (lsub < 1) lsub = 1;
+      int nsplit = lsub < d->L ? nunit : 0;
+      if (ns_env) nsplit = atoi(ns_env);
+      if (nsplit > nunit) nsplit = nunit;
+      const int tickets = nunit - nsplit + nsplit * ((d->L + lsub - 1) / lsub);
+      if (d->tune_threads <= 0 && c > tickets && c > 2) continue;
+      const int cap = (tickets + 15) / 16 * 16;
+      int q = 64;
+      while (q >= 16 && s2_lds_bytes(R, d->Wt, c, wmax, cap, q, cell) > lds_cap) q /= 2;
+      if (q < 16) continue;
+      const size_t lds = s2_lds_bytes(R, d->Wt, c, wmax, cap, q, cell);
+      long k = (long)(160 * 1024 / lds);          // co-resident workgroups per CU
+      if (k > maxnw / c) k = maxnw / c;
+      if (k < 1) k = 1;
+      const double slots = NCU * (double)k;
+      const double rounds = ceil((double)nwg / slots);
+      const double conc = fmin((double)nwg, slots);   // workgroups running together
+      // microseconds: streaming share of the chip (a CU alone cannot pull more
+      // than ~CU_GBPS), or the waves' own latency chains (2 items in flight)
+      const double bytes = (double)srows * nseg * d->L * 4096.0;
+      const double gbps = fmin(CU_GBPS / (double)k, CHIP_GBPS / conc);
+      const double t_stream = bytes / (gbps * 1e3);
+      const double t_lat = ceil((double)nunit * d->L / c) * 1.1;
+      const double t_wg = 3.0 + fmax(t_stream, t_lat) + 0.5 +
+                          (double)R * d->Wt / (c * 64.0) * 0.02;
+      const double est = rounds * t_wg + (nwg < (long)NCU ? 0.0 : 0.0);
+      if (best.nw == 0 || est < best.est - 1e-9 ||
+          (est <= best.est * 1.0001 && R > best.R)) {
+        best.est = est; best.R = R; best.nw = c; best.cell = cell;
+        best.cap = cap; best.qcap = q; best.lds = lds; best.ilv = ilv;
+        best.nsplit = nsplit; best.lsub = lsub;
+      }
+    }
+  }
+  if (best.nw == 0) return LSI_EINVAL;
+  *out = best;
+  static const bool verbose = getenv("LSI_STREAM_VERBOSE") != nullptr;
+  if (verbose)
+    fprintf(stderr, "lsi stream2 plan: R=%d waves=%d %s-locks table=%d queue=%d "
+            "interleave=%d split=%dx%d est=%.1f us lds=%zu\n", best.R, best.nw,
+            best.cell ? "cell" : "row", best.cap, best.qcap, best.ilv,
+            best.nsplit, best.lsub, best.est, best.lds);
+  return LSI_OK;
+}
+
+#ifndef LSI_S2_NSETS
+#define LSI_S2_NSETS 2
+#endif
+#ifndef LSI_S2_MAXT
+#define LSI_S2_MAXT 768
+#endif
+
+}  // namespace
+
+// Whether the compact instance renders this call (else: splat_stream_kernel).
+bool lsi_stream2_applies(const SplatArgs& a, bool simple, int layout) {
+  const LsiSplatDesc* d = &a.d;
+  static const char* off = getenv("LSI_STREAM2");
+  if (off && off[0] == '0') return false;
+  if (d->reserved & 0x40000000) return false;  // tests: force the general kernel
+  if (((d->reserved >> 16) & 3) == 2) return false;  // exchange bands asked for
+  if (!simple || layout != 0) return false;
+  if ((d->flags & (LSI_COMPOSE | LSI_HAS_MASK | LSI_WANT_DISP | LSI_DETERMINISTIC)) !=
+      LSI_COMPOSE)
+    return false;
+  if (a.out_img_c != nullptr) return false;
+  if (d->W % SEG != 0 || d->H > 65535 || d->W / SEG > 32767) return false;
+  if (d->tex_sx != 3 || d->tex_sc != 1 || d->disp_sx != 1) return false;
+  return true;
+}
+
+int lsi_stream2_launch(const SplatArgs& a, int wmax, hipStream_t stream) {
+  const LsiSplatDesc* d = &a.d;
+  S2Plan plan;
+  if (s2_plan(d, wmax, LSI_S2_MAXT / 64, &plan) != LSI_OK) return LSI_EINVAL;
+  S2Args k;
+  k.tex = a.tex; k.disp = a.disp; k.M = a.M;
+  k.out_img = a.out_img; k.out_wts = a.out_wts;
+  k.B = d->B; k.H = d->H; k.Ht = d->Ht; k.Wt = d->Wt; k.L = d->L;
+  k.nseg = d->W / SEG;
+  k.tex_sl = (int)d->tex_sl; k.tex_sb = (int)d->tex_sb; k.tex_sy = (int)d->tex_sy;
+  k.disp_sl = (int)d->disp_sl; k.disp_sb = (int)d->disp_sb; k.disp_sy = (int)d->disp_sy;
+  k.s = d->trg_downsampling; k.max_disp = d->max_disp;
+  // exp((clip(d/max,0,1) - 0.5)*scale) = exp2(clip(d,0,max)*zA + zB)
+  const double l2e = 1.4426950408889634;
+  k.zA = (float)((double)d->zbuf_scale * l2e / (double)d->max_disp);
+  k.zB = (float)(-0.5 * (double)d->zbuf_scale * l2e);
+  k.lbg = (float)d->L * d->bg_wt;
+  k.R = plan.R; k.wmax = wmax; k.qcap = plan.qcap; k.cap = plan.cap;
+  k.ilv = plan.ilv;
+  k.nsplit = plan.nsplit;
+  k.lsub = plan.lsub;
+  const int nbands = (d->Ht + plan.R - 1) / plan.R;
+  k.inv_gx = 1.0f / (float)nbands;
+  k.inv_nseg = 1.0f / (float)k.nseg;
+  k.stamps = nullptr;
+#ifdef S2X_STAMPS
+  if ((d->reserved & 4) && a.canvas &&
+      a.ws_bytes >= (size_t)nbands * d->B * 16 * 8 * 8)
+    k.stamps = reinterpret_cast<long long*>(a.canvas);
+#endif
+  const void* fn = plan.cell
+      ? (const void*)splat_stream2_kernel<LSI_S2_NSETS, true, LSI_S2_MAXT>
+      : (const void*)splat_stream2_kernel<LSI_S2_NSETS, false, LSI_S2_MAXT>;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)plan.lds) != hipSuccess)
+    return LSI_ELAUNCH;
+  void* kargs[1] = {&k};
+  if (hipLaunchKernel(fn, dim3(nbands, d->B), dim3(plan.nw * 64), kargs, plan.lds,
+                      stream) != hipSuccess)
+    return LSI_ELAUNCH;
+  return hipGetLastError() == hipSuccess ? LSI_OK : LSI_ELAUNCH;
+}
