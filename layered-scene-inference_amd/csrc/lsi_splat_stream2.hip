@@ -654,7 +654,7 @@ __global__ __launch_bounds__(MAXT) void splat_stream2_kernel(S2Args a) {
   const float m3 = m[3];
   const float zA = a.zA, zB = a.zB, max_disp = a.max_disp;
   int slot = 0, t_row0 = 0, t_wlo = 0, t_wwin = 0, has_max = 0, rmax_row = 0;
-  int fastA_ok = 0, win_ok = 0;
+  int fast_ok = 0, fastA_ok = 0, win_ok = 0;
   unsigned wspan = 0u, wspanA = 0u;
   float tmin = 0.f, wy0 = 0.f, wy1 = 0.f, wymin = 0.f, wymax = 0.f, wlo_f = 0.f;
   int use_a = 0, use_b = 0;
@@ -738,6 +738,7 @@ __global__ __launch_bounds__(MAXT) void splat_stream2_kernel(S2Args a) {
       wspan = (unsigned)max(t_wwin - 2, 0);
       win_ok = t_wwin >= 2 ? 1 : 0;
       wspanA = (unsigned)max(t_wwin - 4, 0);
+      fast_ok = S2_RFL((win_ok && tmin <= 0.5f) ? 1 : 0);
       fastA_ok = S2_RFL((t_wwin >= 4 && tmin <= 0.5f) ? 1 : 0);
       use_a = S2_RFL((wy0 != 0.f && t_row0 >= 0 && t_row0 < rows) ? 1 : 0);
       use_b = S2_RFL((wy1 != 0.f && t_row0 + 1 >= 0 && t_row0 + 1 < rows) ? 1 : 0);
@@ -868,7 +869,66 @@ __global__ __launch_bounds__(MAXT) void splat_stream2_kernel(S2Args a) {
         (void)co;
 #endif
         S2_FENCE();
-      } else {
+      }
+#ifndef S2X_ONLYA
+      else {
+        // every pixel inside the window (but not route A's pattern: folded or
+        // steep disparity fields): per pixel, unrolled -- route B when floor(X)
+        // increases strictly across the wave (distinct cells), else B': the
+        // lanes of a cell elected one at a time through a byte table
+        int clv[4];
+        unsigned long long regular = ~0ull, inwin = ~0ull;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          clv[i] = (int)(x0v[i] - wlo_f);
+          inwin &= __ballot((unsigned)clv[i] <= wspan);
+          regular &= __ballot(x0v[i] > s2_lane_below(x0v[i])) | 1ull;
+        }
+        if (S2_RFL((inwin == ~0ull && fast_ok) ? 1 : 0)) {
+          const bool fold = regular != ~0ull;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float w0 = w0v[i], w1 = w1v[i];
+            const float4 V = Vv[i];
+            // w0 + w1 = 1 and tmin <= 0.5: at most the smaller side is clamped
+            if (__ballot(!(fminf(w0, w1) >= tmin)) != 0ull) {
+              const bool c0 = !(w0 >= tmin), c1 = !(w1 >= tmin);
+              if (has_max) {
+                const float kq = (c0 ? w0 : w1) * wymax;
+                const int cellq = t_wlo + clv[i] + (c0 ? 0 : 1);
+                push((c0 || c1) && kq > 1.0e-3f && (unsigned)cellq < (unsigned)Wt,
+                     rmax_row * Wt + cellq,
+                     make_float4(V.x * kq, V.y * kq, V.z * kq, V.w * kq));
+              }
+              if (c0) w0 = 0.0f;
+              if (c1) w1 = 0.0f;
+            }
+            float4* cell = rb + (clv[i] >> 1) + (clv[i] & 1) * WHS;
+            float4* cell1 = rb + ((clv[i] + 1) >> 1) + ((clv[i] + 1) & 1) * WHS;
+            if (!fold) {
+              *cell = s2_fma4(*cell, V, w0);
+              S2_FENCE();
+              *cell1 = s2_fma4(*cell1, V, w1);
+              S2_FENCE();
+            } else {
+              bool pending = true;
+              for (;;) {
+                if (__ballot(pending) == 0ull) break;
+                if (pending) sc[clv[i]] = (unsigned char)lane;
+                S2_FENCE();
+                const bool won = pending && sc[clv[i]] == (unsigned char)lane;
+                S2_FENCE();
+                if (won) {
+                  *cell = s2_fma4(*cell, V, w0);
+                  S2_FENCE();
+                  *cell1 = s2_fma4(*cell1, V, w1);
+                }
+                S2_FENCE();
+                pending = pending && !won;
+              }
+            }
+          }
+        } else {
         // ---- per pixel (one copy of the code; the pixel's values are
         // selected).  In-window lanes whose cells are distinct add directly;
         // folded fields elect the lanes of a cell one at a time through a byte
@@ -935,7 +995,9 @@ __global__ __launch_bounds__(MAXT) void splat_stream2_kernel(S2Args a) {
             }
           }
         }
+        }
       }
+#endif
       if (tg_ & (1 << 21)) {
         // ---- last layer done: window -> the task's two tile rows ------------
 #ifndef S2X_NOLOCK
