@@ -7,11 +7,14 @@ defaults, same dataset-dependent overrides, same six loss terms).
   python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 \\
       layered-scene-inference_amd/ldi_enc_dec.py ...      # DDP over RCCL
 
-KITTI and the SUN/PASCAL synthetic scenes are not available here (no datasets,
-no network): `--dataset` selects the camera model and the dataset-dependent
-constants (ldi_enc_dec.py:415-427) and the images are procedural (a smooth
-random texture seen from the two cameras through one fronto-parallel plane, so
-that the view-synthesis loss has something consistent to explain).
+`--dataset=kitti` reads stereo pairs through lsi/data/kitti (--kitti_data_root,
+--kitti_dataset_variant, --data_split, as the reference).  The data set is not
+available in the build container (no network): `--kitti_procedural=true` keeps
+the KITTI camera model and the dataset-dependent constants
+(ldi_enc_dec.py:415-427) and feeds procedural pairs instead (a smooth random
+texture seen from the two cameras through one fronto-parallel plane, so that
+the view-synthesis loss has something consistent to explain); the SUN / PASCAL
+textures of the synthetic scenes are procedural as well.
 """
 import argparse
 import math
@@ -45,6 +48,16 @@ def build_parser():
   a('--n_layers', type=int, default=2)
   a('--pred_ldi_masks', type=_bool, default=False)
   a('--dataset', default='synthetic', choices=['synthetic', 'kitti'])
+  a('--data_split', default='train', choices=['all', 'train', 'val', 'test'])
+  # KITTI (reference ldi_enc_dec.py:76-83)
+  a('--kitti_data_root', default='/datasets/kitti')
+  a('--kitti_dataset_variant', default='mview',
+    choices=['odom', 'mview', 'raw_city'])
+  a('--kitti_dl_disparities', type=_bool, default=False)
+  a('--kitti_procedural', type=_bool, default=False,
+    help='no KITTI files: procedural stereo pairs seen through the KITTI camera '
+    'model and constants (throughput runs, tests).  Without this switch a '
+    'missing --kitti_data_root is an error')
   a('--self_cons_wt', type=float, default=1.0)
   a('--l0_self_cons', type=_bool, default=False)
   a('--indep_splat_wt', type=float, default=1.0)
@@ -76,7 +89,9 @@ def build_parser():
   a('--n_box_planes', type=int, default=5)
   a('--bf16', type=_bool, default=False, help='bf16 autocast for the convs')
   a('--channels_last', type=_bool, default=True)
-  a('--cpu', type=_bool, default=False, help='CPU run (no splat losses)')
+  a('--cpu', type=_bool, default=False,
+    help='keep the model on the CPU (plumbing tests only: the renderer and the '
+    'losses are HIP kernels, compute_losses raises without a ROCm device)')
   a('--miopen_search', type=_bool, default=False,
     help='exhaustive MIOpen solver search (torch.backends.cudnn.benchmark)')
   a('--hip_graph', type=_bool, default=False,
@@ -163,6 +178,24 @@ class SyntheticPairs(object):
     return (src, trg, k, k.clone(), rot, t)
 
 
+class KittiBatches(object):
+  """lsi.data.kitti.DataLoader batches (NumPy) as float32 torch tensors:
+  (img_s, img_t, k_s, k_t, rot, trans[, disp_s, disp_t])."""
+
+  def __init__(self, loader, rank=0):
+    self.loader = loader
+    # every rank walks the data in its own order
+    loader._rng = __import__('numpy').random.RandomState(rank)
+
+  @property
+  def src_image_names(self):
+    return self.loader.src_image_names
+
+  def forward(self, bs):
+    return tuple(torch.as_tensor(a, dtype=torch.float32)
+                 for a in self.loader.forward(bs))
+
+
 class Trainer(train_utils.Trainer):
   """LDI prediction trainer (reference ldi_enc_dec.py:126-410)."""
 
@@ -178,6 +211,15 @@ class Trainer(train_utils.Trainer):
                                  bool(getattr(opts, 'synth_dl_eval_data', False)))
       self.data_loader = synthetic_planes.DataLoader(
           opts, device=self.device, seed=1234 + self.rank)
+    elif opts.dataset == 'kitti' and not opts.kitti_procedural:
+      # reference ldi_enc_dec.py:134-137
+      from lsi.data.kitti import data as kitti_data  # pylint: disable=g-import-not-at-top
+      if not os.path.isdir(opts.kitti_data_root):
+        raise FileNotFoundError(
+            '--dataset=kitti: no directory %r (--kitti_data_root); pass '
+            '--kitti_procedural=true for procedural pairs with KITTI cameras'
+            % opts.kitti_data_root)
+      self.data_loader = KittiBatches(kitti_data.DataLoader(opts), self.rank)
     else:
       self.data_loader = SyntheticPairs(opts, self.device, 1234 + self.rank)
     bs = self.opts.batch_size
@@ -221,21 +263,28 @@ class Trainer(train_utils.Trainer):
                              o.max_disp, self.host_mats[w])
           for w in ('trg', 'src'))
     dev = self.device
-    return [imgs_src.to(dev), imgs_trg.to(dev), mat_trg.to(dev),
-            mat_src.to(dev)], plan
+    staged = [imgs_src.to(dev), imgs_trg.to(dev), mat_trg.to(dev),
+              mat_src.to(dev)]
+    if getattr(self, 'gt_disps', None) is not None:
+      # (part of the staged batch: a captured HIP graph replays on static copies)
+      staged += [self.gt_disps[0].to(dev), self.gt_disps[1].to(dev)]
+    return staged, plan
 
   def compute_losses(self, staged):
     opts = self.opts
-    imgs_src, imgs_trg, mat_trg, mat_src = staged
+    if self.device.type != 'cuda':
+      raise RuntimeError('the renderer and the six loss terms are HIP kernels: '
+                         'training needs a ROCm device')
+    imgs_src, imgs_trg, mat_trg, mat_src = staged[:4]
     mats = {'trg': mat_trg, 'src': mat_src}
-    amp = (torch.autocast('cuda', dtype=torch.bfloat16) if
-           (opts.bf16 and self.device.type == 'cuda') else _NullCtx())
+    amp = (torch.autocast('cuda', dtype=torch.bfloat16) if opts.bf16
+           else _NullCtx())
     with amp:
       ldi_src, ldi_trg = self.train_model(imgs_src, imgs_trg)
-    if opts.debug_synth_texture and getattr(self, 'gt_disps', None) is not None:
+    if opts.debug_synth_texture and len(staged) >= 6:
       # ldi_enc_dec.py:223-225: keep the graph, substitute the values
-      ldi_src[2] = 0 * ldi_src[2] + self.gt_disps[0].to(ldi_src[2].device)
-      ldi_trg[2] = 0 * ldi_trg[2] + self.gt_disps[1].to(ldi_trg[2].device)
+      ldi_src[2] = 0 * ldi_src[2] + staged[4]
+      ldi_trg[2] = 0 * ldi_trg[2] + staged[5]
 
     def ones_like_mask(l):
       return l[1] if l[1] is not None else torch.ones_like(l[2])
@@ -261,8 +310,7 @@ class Trainer(train_utils.Trainer):
     # One sweep per direction renders the per-layer AND the composed view
     # (the reference makes four forward_splat calls whose per-layer splats
     # are identical pairwise).
-    if self.device.type == 'cuda' and (opts.indep_splat_wt > 0 or
-                                       opts.compose_splat_wt > 0):
+    if opts.indep_splat_wt > 0 or opts.compose_splat_wt > 0:
       for which in ('trg', 'src'):
         if which == 'trg':
           target, l = imgs_trg, ldi_src
@@ -279,20 +327,13 @@ class Trainer(train_utils.Trainer):
           compose_splat_loss = compose_splat_loss + loss.view_synthesis_loss(
               img_c, target, opts.splat_bdry_ignore)
 
-    # regularisers (ldi_enc_dec.py:388-396)
-    if self.device.type == 'cuda':
-      # both regularisers from one read of each disparity tensor (fused HIP
-      # kernel lsi_disp_reg_loss_fwd)
-      from lsi.loss import _hip as loss_hip  # pylint: disable=g-import-not-at-top
-      sm_s, dc_s = loss_hip.disp_regularisers(ldi_src[2])
-      sm_t, dc_t = loss_hip.disp_regularisers(ldi_trg[2])
-      disp_smoothness_loss = sm_s + sm_t
-      incr_depth_loss = (dc_s + dc_t) if opts.n_layers > 1 else zero
-    else:
-      disp_smoothness_loss = (ldi_utils.disp_smoothness_loss(ldi_src[2]) +
-                              ldi_utils.disp_smoothness_loss(ldi_trg[2]))
-      incr_depth_loss = (loss.decreasing_disp_loss(ldi_src[2]) +
-                         loss.decreasing_disp_loss(ldi_trg[2]))
+    # regularisers (ldi_enc_dec.py:388-396): both from one read of each
+    # disparity tensor (fused HIP kernel lsi_disp_reg_loss_fwd)
+    from lsi.loss import _hip as loss_hip  # pylint: disable=g-import-not-at-top
+    sm_s, dc_s = loss_hip.disp_regularisers(ldi_src[2])
+    sm_t, dc_t = loss_hip.disp_regularisers(ldi_trg[2])
+    disp_smoothness_loss = sm_s + sm_t
+    incr_depth_loss = (dc_s + dc_t) if opts.n_layers > 1 else zero
 
     total = zero
     if opts.self_cons_wt > 0:

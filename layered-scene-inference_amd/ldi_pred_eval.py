@@ -41,6 +41,8 @@ def build_parser():
     'ldi_pred_eval.py:45-46)')
   a('--results_dir', default='')
   a('--disocc_thresh', type=float, default=1e-2)
+  a('--random_weights', type=train_script._bool, default=False,
+    help='evaluate an untrained model when no checkpoint exists (smoke runs)')
   return p
 
 
@@ -63,13 +65,21 @@ class Tester(object):
     else:
       cand = os.path.join(ckpt_dir, 'model.latest')
       path = cand if os.path.exists(cand) else None
-    if path is not None and os.path.exists(path):
+    if path is None or not os.path.exists(path):
+      # (the reference's Tester fails on a missing checkpoint,
+      # test_utils.py:119-140; random weights only on request)
+      if not self.opts.random_weights:
+        raise FileNotFoundError(
+            'no checkpoint %s under %s (--random_weights=true evaluates an '
+            'untrained model: smoke runs)' %
+            ('model-%d' % self.opts.train_iter if self.opts.train_iter > 0
+             else 'model.latest', ckpt_dir))
+      self.restored = None
+    else:
       state = torch.load(path, map_location=self.device)
       tr.model.load_state_dict(state['model'] if 'model' in state else state,
-                               strict=False)
+                               strict=True)
       self.restored = path
-    else:
-      self.restored = None  # (random weights: smoke runs)
     nets.set_is_training(tr.model, bool(self.opts.batch_norm_training))
 
   @torch.no_grad()
@@ -83,17 +93,28 @@ class Tester(object):
     inv_rot = nn_helpers.transpose(rot)
     inv_trans = -torch.matmul(inv_rot, trans)
     pc = nn_helpers.pixel_coords(o.batch_size, o.img_height, o.img_width)
-    gt = None
-    if len(batch) > 6:  # synthetic planes with ground truth
+    # ground truth by data set (ldi_pred_eval.py:226-262): synthetic planes
+    # carry 14 outputs (fg / bg disparities and background textures), KITTI
+    # with --kitti_dl_disparities 8 (the SPS-stereo disparities of both views)
+    gt, kitti_disp = None, None
+    if o.dataset == 'synthetic' and len(batch) >= 14:
       (_, _, d_s_fg, d_s_bg, d_t_fg, d_t_bg, img_s_bg, img_t_bg) = batch[6:14]
       gt = {'src_gt_disp': d_s_fg.to(dev), 'trg_gt_disp': d_t_fg.to(dev),
             'src_gt_disp_bg': d_s_bg.to(dev), 'trg_gt_disp_bg': d_t_bg.to(dev),
             'src_gt_tex_bg': img_s_bg.to(dev), 'trg_gt_tex_bg': img_t_bg.to(dev)}
+    elif o.dataset == 'kitti' and len(batch) == 8:
+      kitti_disp = {'src': batch[6].to(dev), 'trg': batch[7].to(dev)}
+    elif len(batch) != 6:
+      raise ValueError('unexpected batch layout: %d outputs for dataset %r' %
+                       (len(batch), o.dataset))
     out = []
     for ldi, k_a, k_b, r, t, target, key in (
         (ldi_src, k_s, k_t, rot, trans, imgs_trg, 'trg'),
         (ldi_trg, k_t, k_s, inv_rot, inv_trans, imgs_src, 'src')):
-      disocc = gt_disp = None
+      disocc = gt_disp = valid = None
+      if kitti_disp is not None:
+        # ldi_pred_eval.py:171-172: pixels the stereo matcher left empty
+        disocc = (kitti_disp[key] == 0)
       if gt is not None:
         # pixels of the view being reconstructed that the other view does not
         # see (ldi_pred_eval.py:153-160)
@@ -104,9 +125,11 @@ class Tester(object):
             gt[a + '_gt_disp'], gt[b_ + '_gt_disp'],
             pc.to(dev), mat.to(dev), thresh=o.disocc_thresh)
         gt_disp = gt[a + '_gt_disp']
+        # ldi_pred_eval.py:354-356: only pixels with geometry are scored
+        valid = (gt_disp > o.bg_layer_disp).float()
       out.append(eval_metrics.view_synthesis_metrics(
-          ldi, pc, k_a, k_b, r, t, target, o, disocc_mask=disocc,
-          gt_disp_trg=gt_disp))
+          ldi, pc, k_a, k_b, r, t, target, o, valid_mask=valid,
+          disocc_mask=disocc, gt_disp_trg=gt_disp))
     if gt is not None:
       out.append(eval_metrics.layer_prediction_metrics(
           ldi_src, ldi_trg, imgs_src, imgs_trg, gt, o))

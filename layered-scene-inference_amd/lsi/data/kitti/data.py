@@ -7,7 +7,9 @@ the excluded frame (:152, :168-172) and the SPS-stereo disparity names
 (:181-192), calibration parsing (:227-245), the camera model of a pair --
 intrinsics of P_rect_02 / P_rect_03, translation from the projection matrices'
 fourth column, identity rotation, intrinsics rescaled to img_width x img_height
-(:303-342) -- and AREA resizing of the decoded images to that size (:262-264).
+(:303-342) -- decoding to uint8 (16-bit PNGs keep their high byte, as
+tf.image.decode_image does) and AREA resizing in float32 with exact fractional
+pixel coverage (:247-266).
 
 What is not: the order in which TF's three independently seeded shuffle queues
 emit samples (:250-279) -- here one seeded permutation per epoch pairs each left
@@ -24,11 +26,9 @@ import numpy as np
 
 
 def resize_instrinsic(intrinsic, scale_x, scale_y):
-  """Intrinsics of an image resized by (scale_x, scale_y) (reference :32-36)."""
-  intrinsic_rsz = np.copy(intrinsic)
-  intrinsic_rsz[0, :] *= scale_x
-  intrinsic_rsz[1, :] *= scale_y
-  return intrinsic_rsz
+  """Intrinsics of an image resized by (scale_x, scale_y): the first row of K
+  scales with x, the second with y (reference :32-36)."""
+  return np.diag([scale_x, scale_y, 1.0]) @ np.asarray(intrinsic, np.float64)
 
 
 # drive numbers of the city sequences of the KITTI raw data set, by date
@@ -47,60 +47,108 @@ def raw_city_sequences():
           for date in sorted(_RAW_CITY) for n in _RAW_CITY[date]]
 
 
+def _numbers(text):
+  """The float array a calibration value spells, or None when any token is not
+  a number (e.g. the `calib_time` stamp)."""
+  try:
+    return np.array([float(tok) for tok in text.split()], np.float64)
+  except ValueError:
+    return None
+
+
 def read_calib_file(file_path):
-  """`key: v0 v1 ...` lines -> {key: float array | string} (reference
-  :227-245)."""
-  float_chars = set('0123456789.e+- ')
+  """KITTI calibration file -> {key: float array, or the text when the value is
+  not numeric} (reference :227-245)."""
   data = {}
   with open(file_path, 'r') as f:
     for line in f:
-      if ':' not in line:
+      key, sep, value = line.partition(':')
+      if not sep:
         continue
-      key, value = line.split(':', 1)
       value = value.strip()
-      data[key] = value
-      if float_chars.issuperset(value):
-        try:
-          data[key] = np.array([float(v) for v in value.split(' ')])
-        except ValueError:
-          pass
+      arr = _numbers(value) if value else None
+      data[key] = value if arr is None else arr
   return data
 
 
 def pair_cameras(calib_data, src_shape, trg_shape, h, w):
   """Camera model of a rectified pair (reference forward_instance :303-342).
 
-  Returns k_s, k_t (3x3, rescaled to w x h), rot (identity) and trans (3x1),
-  the translation from the source (cam 2) to the target (cam 3) frame."""
-  rot = np.eye(3)
-  p2 = calib_data['P_rect_02'].reshape(3, 4)
-  p3 = calib_data['P_rect_03'].reshape(3, 4)
-  k_s, k_t = np.copy(p2[:3, :3]), np.copy(p3[:3, :3])
-  trans_src, trans_trg = np.copy(p2[:, 3]), np.copy(p3[:, 3])
-  # the fourth column is K t: back to a 3-D translation
-  trans_src[0] = (trans_src[0] - k_s[0, 2] * trans_src[2]) / k_s[0, 0]
-  trans_src[1] = (trans_src[1] - k_s[1, 2] * trans_src[2]) / k_s[1, 1]
-  trans_trg[0] = (trans_trg[0] - k_t[0, 2] * trans_trg[2]) / k_t[0, 0]
-  trans_trg[1] = (trans_trg[1] - k_t[1, 2] * trans_trg[2]) / k_t[1, 1]
-  trans = trans_trg - trans_src
-  k_s = resize_instrinsic(k_s, w / src_shape[1], h / src_shape[0])
-  k_t = resize_instrinsic(k_t, w / trg_shape[1], h / trg_shape[0])
-  return k_s, k_t, rot, trans.reshape(3, 1)
+  P_rect_0x = K [I | c] with K c in the fourth column: the camera centre offset
+  is c = K^-1 P[:, 3] (K is upper triangular with K[2] = (0, 0, 1), so the
+  reference's two explicit back-substitutions are exactly this solve).  Returns
+  k_s, k_t (3x3, rescaled to w x h), rot (identity) and trans (3x1), the
+  translation from the source (cam 2) to the target (cam 3) frame."""
+  p2 = np.asarray(calib_data['P_rect_02'], np.float64).reshape(3, 4)
+  p3 = np.asarray(calib_data['P_rect_03'], np.float64).reshape(3, 4)
+
+  def offset(p):
+    k, kt = p[:, :3], p[:, 3]
+    z = kt[2]
+    return np.array([(kt[0] - k[0, 2] * z) / k[0, 0],
+                     (kt[1] - k[1, 2] * z) / k[1, 1], z])
+
+  trans = offset(p3) - offset(p2)
+  k_s = resize_instrinsic(p2[:, :3], w / src_shape[1], h / src_shape[0])
+  k_t = resize_instrinsic(p3[:, :3], w / trg_shape[1], h / trg_shape[0])
+  return k_s, k_t, np.eye(3), trans.reshape(3, 1)
+
+
+def _area_matrix(n_in, n_out):
+  """n_out x n_in weights of TF's AREA resize along one axis: output cell i is
+  the mean of the input over [i * n_in / n_out, (i + 1) * n_in / n_out), every
+  input pixel weighted by the fraction of it that lies inside."""
+  scale = n_in / float(n_out)
+  m = np.zeros((n_out, n_in), np.float64)
+  for i in range(n_out):
+    lo, hi = i * scale, (i + 1) * scale
+    j0, j1 = int(np.floor(lo)), min(int(np.ceil(hi)), n_in)
+    for j in range(j0, j1):
+      m[i, j] = min(hi, j + 1) - max(lo, j)
+    m[i] /= scale
+  return m.astype(np.float32)
+
+
+def area_resize(img, h, w):
+  """tf.image.resize_images(AREA) of an H x W x C float image (exact
+  fractional-coverage box filter, separable)."""
+  img = np.asarray(img, np.float32)
+  if img.shape[0] != h:
+    img = np.tensordot(_area_matrix(img.shape[0], h), img, axes=(1, 0))
+  if img.shape[1] != w:
+    img = np.tensordot(_area_matrix(img.shape[1], w), img,
+                       axes=(1, 1)).transpose(1, 0, 2)
+  return np.ascontiguousarray(img, np.float32)
+
+
+def decode_png(path):
+  """tf.image.decode_image(...) with its default uint8 output, as float32 in
+  [0, 255], H x W x C.  16-bit PNGs (the SPS-stereo disparity maps are
+  disp * 256) keep their HIGH byte, as TF's conversion to uint8 does -- Pillow's
+  convert('L') would saturate them at 255."""
+  from PIL import Image  # pylint: disable=g-import-not-at-top
+  with Image.open(path) as im:
+    if im.mode in ('I;16', 'I;16B', 'I;16L', 'I'):
+      arr = (np.asarray(im).astype(np.int64) >> 8).astype(np.float32)
+    elif im.mode in ('L', 'P', '1', 'LA'):
+      arr = np.asarray(im.convert('L'), np.float32)
+    else:
+      arr = np.asarray(im.convert('RGB'), np.float32)
+  if arr.ndim == 2:
+    arr = arr[:, :, None]
+  return arr
 
 
 def _load_image(path, h, w, nc=3):
-  """Decoded image in [0, 1], first nc channels, AREA-resized to h x w
-  (reference img_queue_loader :247-266).  Returns (image, original shape)."""
-  from PIL import Image  # pylint: disable=g-import-not-at-top
-  with Image.open(path) as im:
-    im = im.convert('RGB' if nc == 3 else 'L')
-    orig = (im.height, im.width, nc)
-    # BOX = the mean of the covered source pixels = TF's AREA method
-    im = im.resize((w, h), resample=Image.BOX)
-    arr = np.asarray(im, dtype=np.float32) * np.float32(1.0 / 255)
-  if arr.ndim == 2:
-    arr = arr[:, :, None]
-  return arr[:, :, :nc], orig
+  """Decoded image scaled to [0, 1], first nc channels, AREA-resized to h x w in
+  float32 (reference img_queue_loader :247-266).  Returns (image, original
+  shape)."""
+  arr = decode_png(path) * np.float32(1.0 / 255)
+  if arr.shape[2] < nc:
+    raise ValueError('%s has %d channels, %d needed' % (path, arr.shape[2], nc))
+  arr = arr[:, :, :nc]
+  orig = (arr.shape[0], arr.shape[1], nc)
+  return area_resize(arr, h, w), orig
 
 
 class DataLoader(object):

@@ -25,16 +25,10 @@ def gradient(pred):
 
 
 def disp_smoothness_loss(pred_disp):
-  """Mean absolute second differences (reference ldi.py:47-68).  On a ROCm
-  device: the fused HIP kernel (lsi_disp_reg_loss_fwd)."""
-  if pred_disp.is_cuda:
-    from lsi.loss import _hip  # pylint: disable=g-import-not-at-top
-    return _hip.disp_regularisers(pred_disp)[0]
-  dx, dy = gradient(pred_disp)
-  dx2, dxdy = gradient(dx)
-  dydx, dy2 = gradient(dy)
-  return (dx2.abs().mean() + dxdy.abs().mean() + dydx.abs().mean() +
-          dy2.abs().mean())
+  """Mean absolute second differences (reference ldi.py:47-68): the fused HIP
+  kernel (lsi_disp_reg_loss_fwd / _bwd); CPU tensors raise."""
+  from lsi.loss import _hip  # pylint: disable=g-import-not-at-top
+  return _hip.disp_regularisers(pred_disp)[0]
 
 
 def _desc(tex, mask, disp, ht, wt, s, max_disp, zbuf_scale, bg_wt, flags, path,
@@ -233,8 +227,14 @@ class _ForwardSplatBoth(torch.autograd.Function):
     img_c = torch.empty((1, b, ht, wt, 3), dtype=torch.float32, device=dev)
     wts_c = torch.empty((1, b, ht, wt, 1), dtype=torch.float32, device=dev)
     lib = _C.lib()
-    ws_bytes = int(lib.lsi_splat_workspace_bytes(ctypes.byref(desc)))
-    ws = torch.zeros((max(ws_bytes, 16),), dtype=torch.uint8, device=dev)
+    if desc.path == _C.LSI_PATH_STREAM:
+      # the stream path needs no canvases: the kept, zero-filled-once workspace
+      # (no L*B*Ht*Wt*16-byte memset in every training step)
+      ws, ws_bytes = _stream_workspace(desc, dev)
+      desc.flags |= _C.LSI_WS_KEEP
+    else:
+      ws_bytes = int(lib.lsi_splat_workspace_bytes(ctypes.byref(desc)))
+      ws = torch.zeros((max(ws_bytes, 16),), dtype=torch.uint8, device=dev)
     mat = mat.contiguous()
     rc = lib.lsi_splat_fwd_both(ctypes.byref(desc), _C.ptr(tex), _C.ptr(disp),
                                 _C.ptr(mask), _C.ptr(mat), _C.ptr(img),
@@ -353,17 +353,28 @@ def forward_splat(ldi_src,
         for signature compatibility.
     k_s, k_t: B x 3 x 3 intrinsics; rot: B x 3 x 3; t: B x 3 x 1.  Camera
         tensors on the CPU avoid a device->host copy when choosing the kernel.
-    focal_disps: not supported (lytro data only; None in both reference scripts).
+    focal_disps: optional B x 1 x 1 x 1 (reference ldi.py:130-143, lytro data):
+        the source disparity is shifted by it before the projection and the
+        target disparity shifted back.  Done around the kernels: the shifted
+        disparities are one elementwise pass, and D + f = (q3 + f n) / n is
+        folded into row 3 of the projection matrix (not index-critical: only
+        the z-buffer weight and the disparity output see it).
   Returns:
     trg_img nl x B x Ht x Wt x 3, trg_wts nl x B x Ht x Wt x 1 (un-normalised)
     [, trg_disp nl x B x Ht x Wt x 1]; nl = 1 if compose_layers else L.
   """
   del pixel_coords_src
-  if focal_disps is not None:
-    raise NotImplementedError('focal_disps is not supported by the HIP renderer')
   mat_host = projection.forward_projection_matrix(
       k_s.detach().to('cpu', torch.float32), k_t.detach().to('cpu', torch.float32),
       rot.detach().to('cpu', torch.float32), t.detach().to('cpu', torch.float32))
+  if focal_disps is not None:
+    tex, masks, disps = ldi_src
+    f = focal_disps.detach().to(torch.float32).reshape(-1)
+    if f.numel() != disps.shape[1]:
+      raise ValueError('focal_disps: one value per batch element (B x 1 x 1 x 1)')
+    ldi_src = [tex, masks, disps - f.to(disps.device).view(1, -1, 1, 1, 1)]
+    mat_host = mat_host.clone()
+    mat_host[:, 3, :] += f.to('cpu').view(-1, 1) * mat_host[:, 2, :]
   return forward_splat_matrix(
       ldi_src, mat_host, compose_layers=compose_layers,
       compute_trg_disp=compute_trg_disp, trg_downsampling=trg_downsampling,

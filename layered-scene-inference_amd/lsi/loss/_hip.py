@@ -183,6 +183,8 @@ def compose(imgs, masks, dmaps, soft, min_disp, depth_softmax_temp):
 def compose_depth(masks, dmaps, bg_layer, min_disp, depth_softmax_temp):
   """lsi_compose_depth_fwd (reference layers.py:73-115); forward only."""
   dev = _C.require_device(masks, dmaps)
+  if masks.requires_grad or dmaps.requires_grad:
+    raise RuntimeError('layers.compose_depth on the GPU is forward-only')
   nl = masks.shape[0]
   lead = tuple(masks.shape[1:-1])
   masks_c = _f32(masks).reshape(nl, -1).contiguous()

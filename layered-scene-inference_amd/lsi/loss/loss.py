@@ -1,10 +1,14 @@
 """Loss functions on LDIs (mirror of the reference's lsi/loss/loss.py) plus the
-view-synthesis loss the reference computes inline in ldi_enc_dec.py:337-357."""
+view-synthesis loss the reference computes inline in ldi_enc_dec.py:337-357.
+
+The three losses are fused HIP kernels (csrc/lsi_loss.hip, forward and
+backward); tensors that do not live on a ROCm device raise, as for the
+renderer -- there is no second implementation (the torch restatements the
+tests check gradients against live in oracle/lsi_torch_ref.py)."""
 import math
 
 import torch
 
-from lsi.nnutils import helpers as nn_helpers
 
 
 def event_prob(layer_masks):
@@ -22,17 +26,12 @@ def event_prob(layer_masks):
 def decreasing_disp_loss(layer_disps):
   """Penalises disparities that increase from one layer to the next, with the
   nearer layer detached (reference loss.py:48-63).  On a ROCm device: the fused
-  HIP kernel (lsi_disp_reg_loss_fwd); CPU tensors: the same arithmetic in
-  torch ops (host logic, checked against the goldens)."""
+  HIP kernel (lsi_disp_reg_loss_fwd)."""
   n_layers = layer_disps.shape[0]
   if n_layers == 1:
     return 0
-  if layer_disps.is_cuda:
-    from lsi.loss import _hip  # pylint: disable=g-import-not-at-top
-    return _hip.disp_regularisers(layer_disps)[1]
-  disps_pre = layer_disps[0:n_layers - 1].detach()
-  disps_post = layer_disps[1:n_layers]
-  return torch.relu(disps_post - disps_pre).mean()
+  from lsi.loss import _hip  # pylint: disable=g-import-not-at-top
+  return _hip.disp_regularisers(layer_disps)[1]
 
 
 def zbuffer_composition_loss(layer_imgs, layer_masks, layer_disps, trg_imgs,
@@ -40,22 +39,10 @@ def zbuffer_composition_loss(layer_imgs, layer_masks, layer_disps, trg_imgs,
   """Depth+mask weighted self-consistency loss with a white background layer
   (reference loss.py:66-115).  On a ROCm device: one fused HIP pass
   (lsi_zbuf_comp_loss_fwd / _bwd)."""
-  if layer_imgs.is_cuda:
-    from lsi.loss import _hip  # pylint: disable=g-import-not-at-top
-    return _hip.zbuffer_composition_loss(layer_imgs, layer_masks, layer_disps,
-                                         trg_imgs, bg_layer_disp, max_disp,
-                                         zbuf_scale)
-  layer_imgs = torch.cat([layer_imgs, torch.ones_like(layer_imgs[:1])], 0)
-  layer_masks = torch.cat([layer_masks, torch.ones_like(layer_masks[:1])], 0)
-  layer_disps = torch.cat(
-      [layer_disps, torch.ones_like(layer_disps[:1]) * bg_layer_disp], 0)
-  layer_probs = nn_helpers.zbuffer_weights(
-      layer_disps / max_disp, scale=zbuf_scale) * layer_masks
-  probs_sum = torch.sum(layer_probs, dim=0, keepdim=True)
-  layer_probs = nn_helpers.divide_safe(layer_probs, probs_sum)
-  layerwise_cost = torch.square(layer_imgs - trg_imgs) * layer_probs
-  layerwise_cost = torch.sum(layerwise_cost, dim=0)
-  return 0.5 * layerwise_cost.mean()
+  from lsi.loss import _hip  # pylint: disable=g-import-not-at-top
+  return _hip.zbuffer_composition_loss(layer_imgs, layer_masks, layer_disps,
+                                       trg_imgs, bg_layer_disp, max_disp,
+                                       zbuf_scale)
 
 
 def area_downsample(img, ht, wt):
@@ -79,15 +66,7 @@ def view_synthesis_loss(recons_splat, to_recons_img, splat_bdry_ignore=0.05):
   (ldi_enc_dec.py:337-357): AREA-downsample the target to the splat's size,
   mean |diff| over channels, min over layers, crop the border, mean."""
   _, _, ht, wt, _ = recons_splat.shape
-  if recons_splat.is_cuda:
-    from lsi.loss import _hip  # pylint: disable=g-import-not-at-top
-    return _hip.view_synthesis_loss(recons_splat, to_recons_img,
-                                    _py2_round(wt * splat_bdry_ignore),
-                                    _py2_round(ht * splat_bdry_ignore))
-  tgt = area_downsample(to_recons_img, ht, wt)
-  pw = torch.min(torch.mean(torch.abs(tgt.unsqueeze(0) - recons_splat), dim=4),
-                 dim=0)[0]
-  x_min = _py2_round(wt * splat_bdry_ignore)
-  y_min = _py2_round(ht * splat_bdry_ignore)
-  pw = pw[:, y_min:ht - y_min, x_min:wt - x_min]
-  return pw.mean()
+  from lsi.loss import _hip  # pylint: disable=g-import-not-at-top
+  return _hip.view_synthesis_loss(recons_splat, to_recons_img,
+                                  _py2_round(wt * splat_bdry_ignore),
+                                  _py2_round(ht * splat_bdry_ignore))

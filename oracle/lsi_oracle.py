@@ -584,3 +584,73 @@ def view_synthesis_loss(recons_splat, to_recons_img, splat_bdry_ignore=0.05):
   y_min = py2_round(ht * splat_bdry_ignore)
   pw = pw[:, y_min:ht - y_min, x_min:wt - x_min]
   return F(np.mean(pw))
+
+
+# ---------------------------------------------------------------------------
+# Evaluation metrics, ldi_pred_eval.py:297-548 (define_metrics): (sum, norm)
+# pairs per metric for ONE direction / one pair of LDIs.
+# ---------------------------------------------------------------------------
+def eval_view_synthesis_metrics(recons_splat, recons_disp, to_recons_img,
+                                splat_bdry_ignore, valid_mask=None,
+                                disocc_mask=None, to_recons_disp=None):
+  """ldi_pred_eval.py:385-460 for one rendered view: recons_splat 1 x B x Ht x
+  Wt x 3 and recons_disp 1 x B x Ht x Wt x 1 from forward_splat(compose=True,
+  compute_trg_disp=True).  valid_mask (B x H x W x 1, {0,1}) is thresholded at
+  0.95 after the AREA resize (:398); the dis-occlusion mask's DOWNSAMPLED but
+  un-thresholded values weight the restricted sums (:403-409, 446-451)."""
+  r = _f32(recons_splat)
+  _, b, ht, wt, _ = r.shape
+  tgt = area_downsample(to_recons_img, ht, wt)
+  if valid_mask is None:
+    valid = np.ones((b, ht, wt), np.float32)
+  else:
+    valid = (area_downsample(valid_mask, ht, wt)[..., 0] > F(0.95)).astype(np.float32)
+  x_min, y_min = py2_round(wt * splat_bdry_ignore), py2_round(ht * splat_bdry_ignore)
+  centre = np.zeros((b, ht, wt), np.float32)
+  centre[:, y_min:ht - y_min, x_min:wt - x_min] = 1
+  centre = centre * valid
+  pw = np.min(np.mean(np.abs(tgt[None] - r), axis=4), axis=0) * centre
+  out = {'compose_splat_loss': (float(pw.sum(dtype=np.float64)),
+                                float(centre.sum(dtype=np.float64)))}
+  dm = None
+  if disocc_mask is not None:
+    dm = area_downsample(_f32(disocc_mask), ht, wt)[..., 0]
+    out['compose_splat_loss_disocc'] = (float((pw * dm).sum(dtype=np.float64)),
+                                        float((centre * dm).sum(dtype=np.float64)))
+  if to_recons_disp is not None:
+    gds = area_downsample(to_recons_disp, ht, wt)
+    pd = np.min(np.mean(np.abs(gds[None] - _f32(recons_disp)), axis=4), axis=0) * centre
+    out['depth_splat_loss'] = (float(pd.sum(dtype=np.float64)),
+                               float(centre.sum(dtype=np.float64)))
+    if dm is not None:
+      out['depth_splat_loss_disocc'] = (float((pd * dm).sum(dtype=np.float64)),
+                                        float((centre * dm).sum(dtype=np.float64)))
+  return out
+
+
+def eval_layer_prediction_metrics(ldi_src, ldi_trg, imgs_src, imgs_trg, gt,
+                                  bg_layer_disp):
+  """ldi_pred_eval.py:476-531: foreground layer (0) against the images / gt
+  disparities where gt_disp > bg_layer_disp; background layer (last) against
+  the gt background texture / disparity where the foreground hides it
+  (gt_disp > gt_disp_bg).  Texture sums are divided by 3."""
+  n = ldi_src[0].shape[0]
+  f64 = lambda a: float(np.sum(a, dtype=np.float64))
+  v_s = (_f32(gt['src_gt_disp']) > F(bg_layer_disp)).astype(np.float32)
+  v_t = (_f32(gt['trg_gt_disp']) > F(bg_layer_disp)).astype(np.float32)
+  out = {}
+  n_fg = f64(v_s + v_t)
+  out['fg_tex_error'] = (f64(np.abs(ldi_src[0][0] - imgs_src) * v_s) / 3 +
+                         f64(np.abs(ldi_trg[0][0] - imgs_trg) * v_t) / 3, n_fg)
+  out['fg_disp_error'] = (f64(np.abs(ldi_src[2][0] - gt['src_gt_disp']) * v_s) +
+                          f64(np.abs(ldi_trg[2][0] - gt['trg_gt_disp']) * v_t), n_fg)
+  b_s = (_f32(gt['src_gt_disp']) > _f32(gt['src_gt_disp_bg'])).astype(np.float32)
+  b_t = (_f32(gt['trg_gt_disp']) > _f32(gt['trg_gt_disp_bg'])).astype(np.float32)
+  n_bg = f64(b_s + b_t)
+  out['bg_tex_error'] = (
+      f64(np.abs(ldi_src[0][n - 1] - gt['src_gt_tex_bg']) * b_s) / 3 +
+      f64(np.abs(ldi_trg[0][n - 1] - gt['trg_gt_tex_bg']) * b_t) / 3, n_bg)
+  out['bg_disp_error'] = (
+      f64(np.abs(ldi_src[2][n - 1] - gt['src_gt_disp_bg']) * b_s) +
+      f64(np.abs(ldi_trg[2][n - 1] - gt['trg_gt_disp_bg']) * b_t), n_bg)
+  return out

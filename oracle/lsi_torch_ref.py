@@ -117,3 +117,123 @@ def bilinear(imgs, coords):
   out = out + vx1 * vy0 * wx1 * wy0 * tap(x1s, y0s)
   out = out + vx1 * vy1 * wx1 * wy1 * tap(x1s, y1s)
   return out
+
+
+# ---------------------------------------------------------------------------
+# Losses and layer composition (gradient oracles of csrc/lsi_loss.hip).  Same
+# op graphs as the reference, torch ops, any float dtype; their forward values
+# are pinned by the reference-generated goldens (tests/test_oracle_golden.py).
+# ---------------------------------------------------------------------------
+def zbuffer_composition_loss(layer_imgs, layer_masks, layer_disps, trg_imgs,
+                             bg_layer_disp=0, max_disp=1, zbuf_scale=10):
+  """loss.py:66-115: white background layer at bg_layer_disp appended,
+  p_l = zw(d_l / max_disp) * m_l / sum, 0.5 * mean(sum_l (img_l - trg)^2 p_l)."""
+  layer_imgs = torch.cat([layer_imgs, torch.ones_like(layer_imgs[:1])], 0)
+  layer_masks = torch.cat([layer_masks, torch.ones_like(layer_masks[:1])], 0)
+  layer_disps = torch.cat(
+      [layer_disps, torch.ones_like(layer_disps[:1]) * bg_layer_disp], 0)
+  layer_probs = zbuffer_weights(layer_disps / max_disp, zbuf_scale) * layer_masks
+  probs_sum = torch.sum(layer_probs, dim=0, keepdim=True)
+  layer_probs = divide_safe(layer_probs, probs_sum)
+  layerwise_cost = torch.square(layer_imgs - trg_imgs) * layer_probs
+  return 0.5 * torch.sum(layerwise_cost, dim=0).mean()
+
+
+def decreasing_disp_loss(layer_disps):
+  """loss.py:48-63: mean(relu(d_{l+1} - stop_gradient(d_l))); 0 for L = 1."""
+  n_layers = layer_disps.shape[0]
+  if n_layers == 1:
+    return 0
+  return torch.relu(layer_disps[1:] - layer_disps[:-1].detach()).mean()
+
+
+def gradient(pred):
+  """ldi.py:33-44: forward differences along W (dx) and H (dy)."""
+  dy = pred[:, :, 1:, :, :] - pred[:, :, :-1, :, :]
+  dx = pred[:, :, :, 1:, :] - pred[:, :, :, :-1, :]
+  return dx, dy
+
+
+def disp_smoothness_loss(pred_disp):
+  """ldi.py:47-68: mean |dxx| + mean |dxy| + mean |dyx| + mean |dyy|, each
+  over its own (shrunken) shape; torch.abs has the TF gradient abs'(0) = 0."""
+  dx, dy = gradient(pred_disp)
+  dx2, dxdy = gradient(dx)
+  dydx, dy2 = gradient(dy)
+  return (dx2.abs().mean() + dxdy.abs().mean() + dydx.abs().mean() +
+          dy2.abs().mean())
+
+
+def area_downsample(img, ht, wt):
+  """tf.image.resize_images(AREA) for integer factors: exact box mean."""
+  b, h, w, c = img.shape
+  fy, fx = h // ht, w // wt
+  return img.reshape(b, ht, fy, wt, fx, c).mean(dim=(2, 4))
+
+
+def py2_round(x):
+  import math
+  return int(math.floor(abs(x) + 0.5)) * (1 if x >= 0 else -1)
+
+
+def view_synthesis_loss(recons_splat, to_recons_img, splat_bdry_ignore=0.05):
+  """ldi_enc_dec.py:337-357: AREA-downsample the target, mean |diff| over
+  channels, min over layers, crop round(size * f) border pixels (py2 round),
+  mean.  (torch.min sends the gradient to one of several tied layers where TF
+  splits it evenly: the tests account for that.)"""
+  _, _, ht, wt, _ = recons_splat.shape
+  tgt = area_downsample(to_recons_img, ht, wt)
+  pw = torch.min(torch.mean(torch.abs(tgt.unsqueeze(0) - recons_splat), dim=4),
+                 dim=0)[0]
+  x_min, y_min = py2_round(wt * splat_bdry_ignore), py2_round(ht * splat_bdry_ignore)
+  return pw[:, y_min:ht - y_min, x_min:wt - x_min].mean()
+
+
+def soft_z_buffering(layer_masks, layer_disps, depth_softmax_temp=1):
+  """helpers.py:140-160: p_l ~ (mask + 1e-8) * exp(-1 / (relu(d) * temp)),
+  max-subtracted softmax over the layers."""
+  eps = 1e-8
+  layer_disps = torch.relu(layer_disps)
+  layer_depths = divide_safe(torch.ones_like(layer_disps), layer_disps)
+  log_depth_probs = -layer_depths / depth_softmax_temp
+  log_layer_probs = torch.log(layer_masks + eps) + log_depth_probs
+  log_layer_probs = log_layer_probs - torch.max(log_layer_probs, dim=0,
+                                                keepdim=True)[0]
+  layer_probs = torch.exp(log_layer_probs)
+  return divide_safe(layer_probs, torch.sum(layer_probs, dim=0, keepdim=True))
+
+
+def _one_hot_argmax(selection_mask, depth):
+  idx = torch.argmax(selection_mask, dim=0)
+  return torch.moveaxis(
+      torch.nn.functional.one_hot(idx, depth).to(selection_mask.dtype), -1, 0)
+
+
+def compose(imgs, masks, dmaps, soft=False, min_disp=1e-6, depth_softmax_temp=1):
+  """layers.py:29-70."""
+  n_layers = imgs.shape[0]
+  dmaps = torch.relu(dmaps)
+  imgs = torch.cat([imgs, torch.ones_like(imgs[:1])], 0)
+  masks = torch.cat([masks, torch.ones_like(masks[:1])], 0)
+  dmaps = torch.cat([dmaps, torch.ones_like(dmaps[:1]) * min_disp], 0)
+  sel = soft_z_buffering(masks, dmaps, depth_softmax_temp)
+  if not soft:
+    sel = _one_hot_argmax(sel, n_layers + 1)
+  return torch.sum(sel * imgs, dim=0)
+
+
+def compose_depth(masks, dmaps, bg_layer=False, min_disp=1e-6,
+                  depth_softmax_temp=1):
+  """layers.py:73-115."""
+  n_layers = masks.shape[0]
+  dmaps = torch.relu(dmaps)
+  bg_disp = torch.ones_like(dmaps[:1]) * min_disp
+  masks = torch.cat([masks, torch.ones_like(masks[:1])], 0)
+  dmaps = torch.cat([dmaps, bg_disp], 0)
+  if bg_layer:
+    sel_d = torch.cat([torch.max(dmaps) - dmaps[0:n_layers], bg_disp], 0)
+  else:
+    sel_d = dmaps
+  sel = _one_hot_argmax(soft_z_buffering(masks, sel_d, depth_softmax_temp),
+                        n_layers + 1)
+  return torch.sum(sel * dmaps, dim=0)

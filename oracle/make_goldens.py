@@ -379,6 +379,138 @@ def make_view_synthesis():
   np.savez_compressed(os.path.join(OUT, 'view_synthesis.npz'), **out)
 
 
+def make_focal(mods):
+  """forward_splat with focal_disps (ldi.py:130-143: the disparity is shifted by
+  a per-sample focal disparity before the projection and shifted back
+  afterwards; lytro data).  Both compose modes, with the disparity output."""
+  ldi = mods['lsi.geometry.ldi']
+  helpers = mods['lsi.nnutils.helpers']
+  proj = mods['lsi.geometry.projection']
+  rs = np.random.RandomState(4321)
+  nl, b, h, w = 2, 2, 16, 32
+  out = {}
+  for tag, cams in (('kitti', kitti_cams(b, h, w)),
+                    ('general', synth_cams(rs, b, h, w, ang=0.1, tr=0.3, tz=0.2))):
+    k_s, k_t, rot, t = cams
+    tex = rs.rand(nl, b, h, w, 3).astype(np.float32)
+    disp = (0.05 + 0.3 * rs.rand(nl, b, h, w, 1)).astype(np.float32)
+    mask = rs.rand(nl, b, h, w, 1).astype(np.float32)
+    focal = f32([0.07, 0.15]).reshape(b, 1, 1, 1)
+    pc = helpers.pixel_coords(b, h, w)
+    out[tag + '_M'] = proj.forward_projection_matrix(T(k_s), T(k_t), T(rot), T(t)).a
+    for k_, v in (('tex', tex), ('mask', mask), ('disp', disp), ('focal', focal),
+                  ('k_s', k_s), ('k_t', k_t), ('rot', rot), ('t', t)):
+      out[tag + '_' + k_] = v
+    for compose in (True, False):
+      img, wts, dsp = ldi.forward_splat(
+          [T(tex), T(mask), T(disp)], pc, T(k_s), T(k_t), T(rot), T(t),
+          focal_disps=T(focal), compose_layers=compose, compute_trg_disp=True,
+          trg_downsampling=0.5, bg_layer_disp=1e-3, max_disp=0.4, zbuf_scale=50)
+      c = 'compose' if compose else 'indep'
+      out['%s_%s_img' % (tag, c)] = img.a
+      out['%s_%s_wts' % (tag, c)] = wts.a
+      out['%s_%s_disp' % (tag, c)] = dsp.a
+  out['params'] = np.array([0.5, 1e-3, 0.4, 50], np.float64)
+  np.savez_compressed(os.path.join(OUT, 'focal_splat.npz'), **out)
+  print('focal_splat', out['kitti_compose_img'].shape)
+
+
+def make_scene_geometry():
+  """The procedural scene generator's geometry: the reference's
+  pure-NumPy helpers lsi/data/syntheticPlanes/utils.py:29-201 are executed in
+  place (the module's imports of tensorflow / absl resolve to the shim, the
+  texture-queue class below line 201 is never instantiated), and the view
+  sampler data.py:29-52 is executed from its own lines with numpy's global
+  generator seeded.  Stored: inputs and outputs."""
+  import textwrap
+  import types
+  tf.install()
+  path = '/root/reference/lsi/data/syntheticPlanes/utils.py'
+  utils = types.ModuleType('ref_synth_utils')
+  utils.__file__ = path
+  with open(path, 'r') as f:
+    ulines = f.readlines()
+  # everything above the texture-queue class (py2-only print statements there)
+  stop = next(i for i, l in enumerate(ulines)
+              if l.startswith('class QueuedRandomTextureLoader'))
+  assert 195 <= stop <= 210, stop
+  exec(compile(''.join(ulines[:stop]), path, 'exec'), utils.__dict__)  # pylint: disable=exec-used
+  rs = np.random.RandomState(2024)
+  out = {}
+  # dims2kmat / resize_instrinsic
+  dims = rs.uniform(0.5, 4.0, (6, 2))
+  tex_sz = rs.randint(64, 512, (6, 2)).astype(np.float64)
+  out['kmat_in'] = np.concatenate([dims, tex_sz], 1)
+  out['kmat_out'] = np.stack([utils.dims2kmat(*row) for row in out['kmat_in']])
+  out['rsz_scale'] = rs.uniform(0.25, 2.0, (6, 2))
+  out['rsz_out'] = np.stack([
+      utils.resize_instrinsic(k, sx, sy)
+      for k, (sx, sy) in zip(out['kmat_out'], out['rsz_scale'])])
+  # get_centre / canonical_transform on random (non-normalised) plane frames
+  n = 8
+  pts = rs.uniform(-2, 2, (n, 3))
+  x_dirs = rs.uniform(-1, 1, (n, 3))
+  y_raw = rs.uniform(-1, 1, (n, 3))
+  # y orthogonal to x (the generator only builds orthogonal frames)
+  y_dirs = y_raw - x_dirs * (np.sum(y_raw * x_dirs, 1, keepdims=True) /
+                             np.sum(x_dirs * x_dirs, 1, keepdims=True))
+  wh = rs.uniform(0.3, 3.0, (n, 2))
+  offs = rs.uniform(0, 1, (n, 2))
+  out['gc_pt'], out['gc_x'], out['gc_y'] = pts, x_dirs, y_dirs
+  out['gc_wh'], out['gc_off'] = wh, offs
+  out['gc_out'] = np.stack([
+      utils.get_centre(pts[i], x_dirs[i], y_dirs[i], wh[i, 0], wh[i, 1],
+                       offs[i, 0], offs[i, 1]) for i in range(n)])
+  out['gc_out_default'] = np.stack([
+      utils.get_centre(pts[i], x_dirs[i], y_dirs[i], wh[i, 0], wh[i, 1])
+      for i in range(n)])
+  ct = [utils.canonical_transform(out['gc_out'][i], x_dirs[i], y_dirs[i])
+        for i in range(n)]
+  out['ct_rot'] = np.stack([c[0] for c in ct])
+  out['ct_trans'] = np.stack([c[1] for c in ct])
+  ti = rs.uniform(-1, 1, (n, 3))
+  ct2 = [utils.canonical_transform(out['gc_out'][i], x_dirs[i], y_dirs[i], ti[i])
+         for i in range(n)]
+  out['ct_init'] = ti
+  out['ct_rot_init'] = np.stack([c[0] for c in ct2])
+  out['ct_trans_init'] = np.stack([c[1] for c in ct2])
+  # box_planes: two extents, every parameter of the five planes
+  extents = np.array([[-1.0, -1.0, 1.0, 1.0, 1.0, 3.5],
+                      [-1.7, -0.9, 0.5, 1.2, 1.1, 2.75]])
+  out['box_extent'] = extents
+  keys = ('pt', 'x_dir', 'y_dir')
+  for e, ext in enumerate(extents):
+    planes = utils.box_planes(ext)
+    assert len(planes) == 5
+    for k in keys:
+      out['box%d_%s' % (e, k)] = np.stack(
+          [np.asarray(pl[k], np.float64) for pl in planes])
+    out['box%d_whoff' % e] = np.array(
+        [[pl['w'], pl['h'], pl['off_x'], pl['off_y']] for pl in planes])
+  # lookat_rotation
+  deltas = rs.uniform(-1, 1, (10, 3))
+  deltas[:, 2] = rs.uniform(0.5, 4.0, 10)
+  out['lookat_delta'] = deltas
+  out['lookat_rot'] = np.stack([utils.lookat_rotation(d) for d in deltas])
+  # sample_views: data.py:29-52, its own lines, numpy's global generator seeded
+  dpath = '/root/reference/lsi/data/syntheticPlanes/data.py'
+  with open(dpath, 'r') as f:
+    lines = f.readlines()
+  first = next(i for i, l in enumerate(lines) if l.startswith('def sample_views('))
+  last = next(i for i, l in enumerate(lines)
+              if i > first and l.startswith('  return rot_trans_list'))
+  assert 25 <= first < last <= 55, (first, last)
+  ns = {'np': np, 'utils': utils}
+  exec(compile(textwrap.dedent(''.join(lines[first:last + 1])), dpath, 'exec'), ns)  # pylint: disable=exec-used
+  np.random.seed(31337)
+  views = ns['sample_views'](5)
+  out['views_seed'] = np.int64(31337)
+  out['views_rot'] = np.stack([v[0] for v in views])
+  out['views_trans'] = np.stack([v[1] for v in views])
+  np.savez_compressed(os.path.join(OUT, 'scene_geometry.npz'), **out)
+  print('scene geometry', {k: v.shape for k, v in out.items() if hasattr(v, 'shape')})
+
+
 def main():
   os.makedirs(OUT, exist_ok=True)
   mods = tf.load_reference()
@@ -389,6 +521,8 @@ def main():
   make_disocclusion(mods)
   make_losses(mods)
   make_view_synthesis()
+  make_scene_geometry()
+  make_focal(mods)
   total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
   print('wrote %d bytes under %s' % (total, OUT))
 

@@ -68,11 +68,12 @@ def test_loader_on_a_miniature_raw_city_tree(tmp_path):
   np.testing.assert_allclose(rot[0], np.eye(3))
   # translation between the rectified cameras: -(0.59 - 0.06) along x
   np.testing.assert_allclose(trans[0].ravel(), [-0.53, 0, 0], atol=1e-9)
-  # AREA resize by 2 = exact 2x2 box mean (up to the uint8 rounding of Pillow)
+  # AREA resize by 2 = exact 2x2 box mean (computed in float32: no rounding to
+  # 1/255 steps)
   from PIL import Image
   raw = np.asarray(Image.open(dl.src_image_names[0]), np.float32) / 255
   box = raw.reshape(16, 2, 48, 2, 3).mean(axis=(1, 3))
-  assert np.abs(img_s[0] - box).max() <= 1.0 / 255 + 1e-6
+  assert np.abs(img_s[0] - box).max() <= 1e-6
   # every sample of an epoch exactly once
   seen = [dl._next_index() for _ in range(1)] + []
   assert len(set(seen)) == 1
@@ -121,3 +122,98 @@ def test_tf_checkpoint_names_and_round_trip():
   for u, v in zip(a, b):
     if u is not None:
       assert torch.equal(u, v)
+
+
+def test_scene_generator_geometry_matches_the_reference():
+  """tests/golden/scene_geometry.npz: outputs of the reference's own NumPy
+  helpers (syntheticPlanes/utils.py:29-201, executed in place by
+  oracle/make_goldens.py) and of its view sampler (data.py:29-52) with numpy's
+  generator seeded: plane intrinsics, plane centres, canonical transforms, the
+  five box planes, look-at rotations and sampled views."""
+  import numpy as np
+  from conftest import golden
+  from lsi.data import synthetic_planes as sp
+  g = golden('scene_geometry.npz')
+  close = lambda a, b: np.testing.assert_allclose(a, b, rtol=1e-12, atol=1e-12)
+  for row, want in zip(g['kmat_in'], g['kmat_out']):
+    close(sp.dims2kmat(*row), want)
+  for k, (sx, sy), want in zip(g['kmat_out'], g['rsz_scale'], g['rsz_out']):
+    close(sp.resize_instrinsic(k, sx, sy), want)
+  n = len(g['gc_pt'])
+  for i in range(n):
+    args = (g['gc_pt'][i], g['gc_x'][i], g['gc_y'][i], g['gc_wh'][i, 0],
+            g['gc_wh'][i, 1])
+    close(sp.get_centre(*args, g['gc_off'][i, 0], g['gc_off'][i, 1]), g['gc_out'][i])
+    close(sp.get_centre(*args), g['gc_out_default'][i])
+    rot, trans = sp.canonical_transform(g['gc_out'][i], g['gc_x'][i], g['gc_y'][i])
+    close(rot, g['ct_rot'][i]); close(trans, g['ct_trans'][i])
+    rot, trans = sp.canonical_transform(g['gc_out'][i], g['gc_x'][i], g['gc_y'][i],
+                                        g['ct_init'][i])
+    close(rot, g['ct_rot_init'][i]); close(trans, g['ct_trans_init'][i])
+  for e, ext in enumerate(g['box_extent']):
+    planes = sp.box_planes(ext)
+    assert len(planes) == 5
+    for k in ('pt', 'x_dir', 'y_dir'):
+      close(np.stack([np.asarray(p[k], np.float64) for p in planes]),
+            g['box%d_%s' % (e, k)])
+    close(np.array([[p['w'], p['h'], p['off_x'], p['off_y']] for p in planes]),
+          g['box%d_whoff' % e])
+  for d, want in zip(g['lookat_delta'], g['lookat_rot']):
+    close(sp.lookat_rotation(d), want)
+  views = sp.sample_views(5, np.random.RandomState(int(g['views_seed'])))
+  close(np.stack([v[0] for v in views]), g['views_rot'])
+  close(np.stack([v[1] for v in views]), g['views_trans'])
+
+
+def test_kitti_decode_and_area_resize_follow_tensorflow(tmp_path):
+  """Reference kitti/data.py:247-266: tf.image.decode_image gives uint8 -- a
+  16-bit PNG (the SPS-stereo disparity maps store disp * 256) keeps its HIGH
+  byte, it is not saturated; the AREA resize weights every source pixel by the
+  fraction of it inside the output cell (non-integer factors such as
+  1242 x 375 -> 768 x 256)."""
+  import numpy as np
+  from PIL import Image
+  from lsi.data.kitti import data
+  rs = np.random.RandomState(0)
+  raw16 = rs.randint(0, 65536, (30, 50)).astype(np.uint16)
+  raw16[0, :4] = [300, 10240, 255, 256]
+  path = str(tmp_path / 'disp16.png')
+  Image.fromarray(raw16).save(path)
+  dec = data.decode_png(path)
+  assert dec.shape == (30, 50, 1)
+  np.testing.assert_array_equal(dec[..., 0], (raw16 >> 8).astype(np.float32))
+  assert list(dec[0, :4, 0]) == [1.0, 40.0, 0.0, 1.0]      # not 255, 255, ...
+  # non-integer AREA factor against a brute-force coverage integral
+  img = rs.rand(7, 10, 2).astype(np.float32)
+  got = data.area_resize(img, 3, 4)
+
+  def cover(n_in, n_out):
+    m = np.zeros((n_out, n_in))
+    sub = 1000                        # sub-samples per source pixel
+    pos = (np.arange(n_in * sub) + 0.5) / sub
+    cell = np.minimum((pos * n_out / n_in).astype(int), n_out - 1)
+    for p, c in zip(pos, cell):
+      m[c, int(p)] += 1
+    return m / m.sum(1, keepdims=True)
+
+  want = np.einsum('ai,bj,ijc->abc', cover(7, 3), cover(10, 4), img.astype(np.float64))
+  np.testing.assert_allclose(got, want, atol=2e-3)
+  assert abs(float(got.mean()) - float(img.mean())) < 1e-6   # mass preserved
+  img8, orig = data._load_image(path, 15, 25, 1)              # disparity channel
+  assert orig == (30, 50, 1) and img8.shape == (15, 25, 1)
+  assert float(img8.max()) <= 1.0
+
+
+def test_kitti_dataset_without_files_fails_loudly(tmp_path):
+  """--dataset=kitti reads KITTI through lsi/data/kitti; a missing data root is
+  an error unless procedural pairs are asked for explicitly."""
+  import pytest
+  import ldi_enc_dec as script
+  argv = ['--dataset', 'kitti', '--n_layers', '2', '--img_height', '128',
+          '--img_width', '128', '--batch_size', '1', '--cpu', 'true',
+          '--kitti_data_root', str(tmp_path / 'nope'), '--checkpoint_dir',
+          str(tmp_path)]
+  opts = script.apply_dataset_overrides(script.build_parser().parse_args(argv))
+  tr = script.Trainer(opts)
+  with pytest.raises(FileNotFoundError, match='kitti_data_root'):
+    tr.setup()

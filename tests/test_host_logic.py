@@ -1,6 +1,8 @@
 """Host-side mirror functions (torch elementwise / small-matrix helpers) against
 the reference-generated goldens, on CPU tensors.  The HIP-backed ops
-(forward_splat, splat, bilinear, scatter_add) are covered by the -m gpu tests."""
+(forward_splat, splat, bilinear, scatter_add, the losses, compose) are covered
+by the -m gpu tests; their torch restatements (oracle/lsi_torch_ref.py, the
+gradient oracles of those tests) are pinned to the same goldens here."""
 import numpy as np
 import pytest
 import torch
@@ -8,7 +10,8 @@ import torch
 import lsi_oracle as O
 
 from conftest import golden
-from lsi.geometry import homography, layers, ldi, projection
+import lsi_torch_ref as TR
+from lsi.geometry import homography, ldi, projection
 from lsi.loss import loss
 from lsi.nnutils import helpers
 
@@ -50,14 +53,14 @@ def test_projection_matrices_match_reference_bitwise():
   assert projection.pad_extrinsic(k, torch.rand(2, 3, 1)).shape == (2, 4, 4)
 
 
-def test_layers_compose_and_soft_z():
+def test_torch_oracle_compose_and_soft_z():
   g = golden('layers.npz')
   imgs, masks, dmaps = T(g['imgs']), T(g['masks']), T(g['dmaps'])
-  close(layers.compose(imgs, masks, dmaps), g['compose_hard'])
-  close(layers.compose(imgs, masks, dmaps, soft=True, min_disp=1e-3,
+  close(TR.compose(imgs, masks, dmaps), g['compose_hard'])
+  close(TR.compose(imgs, masks, dmaps, soft=True, min_disp=1e-3,
                        depth_softmax_temp=0.4), g['compose_soft'], 1e-4, 1e-6)
-  close(layers.compose_depth(masks, dmaps), g['compose_depth'])
-  close(layers.compose_depth(masks, dmaps, bg_layer=True, min_disp=1e-3,
+  close(TR.compose_depth(masks, dmaps), g['compose_depth'])
+  close(TR.compose_depth(masks, dmaps, bg_layer=True, min_disp=1e-3,
                              depth_softmax_temp=0.4), g['compose_depth_bg'])
   close(helpers.soft_z_buffering(masks, dmaps, 0.4), g['soft_z'], 1e-4, 1e-7)
   np.testing.assert_array_equal(helpers.enforce_bg_occupied(masks).numpy(),
@@ -85,16 +88,17 @@ def test_homography_algebra():
         (pts[..., :2] / pts[..., 2:]).numpy())
 
 
-def test_losses():
+def test_torch_oracle_losses():
   g = golden('losses.npz')
   imgs, masks, disps, trg = (T(g[k]) for k in ('imgs', 'masks', 'disps', 'trg'))
-  got = loss.zbuffer_composition_loss(imgs, masks, disps, trg,
-                                      bg_layer_disp=1e-3, max_disp=0.4,
-                                      zbuf_scale=50)
+  got = TR.zbuffer_composition_loss(imgs, masks, disps, trg,
+                                    bg_layer_disp=1e-3, max_disp=0.4,
+                                    zbuf_scale=50)
   assert abs(float(got) - float(g['zbuf_comp_loss'])) < 1e-5 * float(g['zbuf_comp_loss'])
-  assert abs(float(loss.decreasing_disp_loss(disps)) - float(g['decr_disp_loss'])) < 1e-6
-  assert loss.decreasing_disp_loss(disps[:1]) == 0
-  assert abs(float(ldi.disp_smoothness_loss(disps)) - float(g['smooth_loss'])) < 1e-5
+  assert abs(float(TR.decreasing_disp_loss(disps)) - float(g['decr_disp_loss'])) < 1e-6
+  assert TR.decreasing_disp_loss(disps[:1]) == 0
+  assert loss.decreasing_disp_loss(disps[:1]) == 0        # (L = 1: no kernel)
+  assert abs(float(TR.disp_smoothness_loss(disps)) - float(g['smooth_loss'])) < 1e-5
   dx, dy = ldi.gradient(disps)
   np.testing.assert_array_equal(dx.numpy(), g['grad_dx'])
   np.testing.assert_array_equal(dy.numpy(), g['grad_dy'])
@@ -103,17 +107,17 @@ def test_losses():
   assert float((probs.sum(0, keepdim=True) + esc - 1).abs().max()) < 1e-5
 
 
-def test_view_synthesis_loss():
+def test_torch_oracle_view_synthesis_loss():
   import lsi_oracle as O
   rs = np.random.RandomState(3)
   tgt = rs.rand(2, 16, 24, 3).astype(np.float32)
   recon = rs.rand(3, 2, 8, 12, 3).astype(np.float32)
   want = O.view_synthesis_loss(recon, tgt, 0.05)
-  got = loss.view_synthesis_loss(T(recon), T(tgt), 0.05)
+  got = TR.view_synthesis_loss(T(recon), T(tgt), 0.05)
   assert abs(float(got) - float(want)) < 1e-6
   # decreasing_disp_loss stops the gradient of the nearer layer (loss.py:58-60)
   d = torch.rand(3, 1, 4, 4, 1, requires_grad=True)
-  loss.decreasing_disp_loss(d).backward()
+  TR.decreasing_disp_loss(d).backward()
   assert float(d.grad[0].abs().sum()) == 0
 
 
@@ -133,8 +137,8 @@ def test_view_synthesis_loss_matches_the_reference_script_lines(tag):
   """tests/golden/view_synthesis.npz holds the output of the reference's own
   statements (ldi_enc_dec.py:337-351, executed in place by
   oracle/make_goldens.py): AREA resize, L1, mean over channels, min over
-  layers, py2-rounded border crop.  Both the oracle's restatement and the
-  torch mirror (CPU tensors) must reproduce it."""
+  layers, py2-rounded border crop.  The oracle's NumPy and torch restatements
+  must both reproduce it."""
   import torch
   from lsi.loss import loss
   g = golden('view_synthesis.npz')
@@ -143,8 +147,8 @@ def test_view_synthesis_loss_matches_the_reference_script_lines(tag):
   want = float(g[tag + '_loss'])
   got_oracle = float(O.view_synthesis_loss(recons, target, bdry))
   assert abs(got_oracle - want) <= 1e-6 * abs(want)
-  got = float(loss.view_synthesis_loss(torch.tensor(recons), torch.tensor(target),
-                                       bdry))
+  got = float(TR.view_synthesis_loss(torch.tensor(recons), torch.tensor(target),
+                                     bdry))
   assert abs(got - want) <= 1e-6 * abs(want)
   assert g[tag + '_pwise'].shape[1:] == (
       recons.shape[2] - 2 * loss._py2_round(recons.shape[2] * bdry),

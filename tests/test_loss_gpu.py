@@ -31,11 +31,18 @@ def T(a, dev, grad=False):
   return t.requires_grad_(True) if grad else t
 
 
-def _cpu_loss():
-  """The torch-op mirrors of the losses (what CPU tensors go through)."""
+def _product():
   from lsi.geometry import ldi
   from lsi.loss import loss
   return loss, ldi
+
+
+def _oracle():
+  """oracle/lsi_torch_ref.py: the same op graphs in torch ops, differentiated
+  in fp64 -- the gradient oracle (forward values pinned by the goldens in
+  tests/test_oracle_golden.py)."""
+  import lsi_torch_ref as TR
+  return TR
 
 
 def _close(got, want, rtol=1e-5):
@@ -46,7 +53,8 @@ def _close(got, want, rtol=1e-5):
 
 
 def test_zbuffer_composition_loss_forward_and_backward(dev):
-  loss, _ = _cpu_loss()
+  loss, _ = _product()
+  TR = _oracle()
   g = golden('losses.npz')
   args = dict(bg_layer_disp=1e-3, max_disp=0.4, zbuf_scale=50)
   imgs, masks, disps = T(g['imgs'], dev, True), T(g['masks'], dev, True), T(g['disps'], dev, True)
@@ -56,9 +64,9 @@ def test_zbuffer_composition_loss_forward_and_backward(dev):
   (got * 3.0).backward()
   ci, cm, cd = [torch.tensor(g[k], dtype=torch.float64, requires_grad=True)
                 for k in ('imgs', 'masks', 'disps')]
-  ref = loss.zbuffer_composition_loss(ci, cm, cd,
-                                      torch.tensor(g['trg'], dtype=torch.float64),
-                                      **args)
+  ref = TR.zbuffer_composition_loss(ci, cm, cd,
+                                    torch.tensor(g['trg'], dtype=torch.float64),
+                                    **args)
   (ref * 3.0).backward()
   _close(imgs.grad, ci.grad)
   _close(masks.grad, cm.grad)
@@ -77,7 +85,8 @@ def test_zbuffer_composition_loss_forward_and_backward(dev):
 
 
 def test_disparity_regularisers_forward_and_backward(dev):
-  loss, ldi = _cpu_loss()
+  loss, ldi = _product()
+  TR = _oracle()
   g = golden('losses.npz')
   d = T(g['disps'], dev, True)
   smooth = ldi.disp_smoothness_loss(d)
@@ -88,7 +97,7 @@ def test_disparity_regularisers_forward_and_backward(dev):
   assert loss.decreasing_disp_loss(d[:1]) == 0           # L == 1 (loss.py:58)
   (0.7 * smooth + 1.3 * decr).backward()
   c = torch.tensor(g['disps'], dtype=torch.float64, requires_grad=True)
-  (0.7 * ldi.disp_smoothness_loss(c) + 1.3 * loss.decreasing_disp_loss(c)).backward()
+  (0.7 * TR.disp_smoothness_loss(c) + 1.3 * TR.decreasing_disp_loss(c)).backward()
   _close(d.grad, c.grad)
   # a smooth (piecewise-linear) field: second differences that vanish exactly
   # must get the TF gradient abs'(0) = 0
@@ -101,7 +110,8 @@ def test_disparity_regularisers_forward_and_backward(dev):
 
 @pytest.mark.parametrize('tag', ['compose', 'indep', 'full'])
 def test_view_synthesis_loss_forward_and_backward(tag, dev):
-  loss, _ = _cpu_loss()
+  loss, _ = _product()
+  TR = _oracle()
   g = golden('view_synthesis.npz')
   recons_np, target_np = g[tag + '_recons'], g[tag + '_target']
   bdry = float(g[tag + '_bdry'])
@@ -111,8 +121,8 @@ def test_view_synthesis_loss_forward_and_backward(tag, dev):
   assert abs(float(got) - want) <= LOSS_RTOL * abs(want)
   (got * 2.0).backward()
   c = torch.tensor(recons_np, dtype=torch.float64, requires_grad=True)
-  (loss.view_synthesis_loss(c, torch.tensor(target_np, dtype=torch.float64),
-                            bdry) * 2.0).backward()
+  (TR.view_synthesis_loss(c, torch.tensor(target_np, dtype=torch.float64),
+                          bdry) * 2.0).backward()
   gd, cd = r.grad.cpu().double(), c.grad
   if recons_np.shape[0] > 1:
     # rows 0-1: layers 0 and 1 are identical (exact ties).  TF's reduce_min
@@ -144,6 +154,25 @@ def test_compose_variants_match_goldens(dev):
   assert np.array_equal(depth_bg.cpu().numpy(), g['compose_depth_bg'])
   with pytest.raises(RuntimeError, match='forward-only'):
     layers.compose(imgs.clone().requires_grad_(True), masks, dmaps)
+  with pytest.raises(RuntimeError, match='forward-only'):
+    layers.compose_depth(masks, dmaps.clone().requires_grad_(True))
+
+
+def test_losses_and_composition_have_no_cpu_path():
+  """a tensor that does not live on a ROCm device raises in
+  every HIP-backed op -- there is no second (torch) implementation."""
+  from lsi.geometry import layers, ldi
+  from lsi.loss import loss
+  d = torch.rand(2, 1, 8, 8, 1)
+  im = torch.rand(2, 1, 8, 8, 3)
+  for fn in (lambda: loss.decreasing_disp_loss(d),
+             lambda: ldi.disp_smoothness_loss(d),
+             lambda: loss.zbuffer_composition_loss(im, d, d, im[0]),
+             lambda: loss.view_synthesis_loss(im, torch.rand(1, 16, 16, 3)),
+             lambda: layers.compose(im, d, d),
+             lambda: layers.compose_depth(d, d)):
+    with pytest.raises(RuntimeError):
+      fn()
 
 
 def test_six_loss_scalars_of_a_fixed_batch_match_the_oracle(dev):

@@ -200,6 +200,65 @@ def test_eval_metrics_against_numpy_restatement(dev):
   assert 0 < agg['psnr'] < 60
 
 
+def test_eval_disocclusion_and_layer_metrics_against_the_oracle(dev):
+  """The metrics of ldi_pred_eval.py:403-451 (dis-occlusion-restricted L1 and
+  depth error, valid-pixel masks) and :476-531 (foreground / background layer
+  texture and disparity errors) on random inputs, against the NumPy
+  restatement in oracle/lsi_oracle.py: sums AND normalisers."""
+  import types
+  from lsi.nnutils import eval_metrics, helpers
+  g = golden('fs_kitti_L2_s05.npz')
+  s, bg, md, zb = [float(v) for v in g['params']]
+  opts = types.SimpleNamespace(trg_splat_downsampling=s, zbuf_scale=zb,
+                               bg_layer_disp=0.05, max_disp=md,
+                               splat_bdry_ignore=0.1)
+  nl, b, h, w, _ = g['tex'].shape
+  rs = np.random.RandomState(5)
+  f32 = lambda a: np.asarray(a, np.float32)
+  target = f32(rs.rand(b, h, w, 3))
+  gt_disp = f32(0.4 * rs.rand(b, h, w, 1))
+  gt_disp[:, : h // 4] = 0.01                    # a band below bg_layer_disp
+  disocc = rs.rand(b, h, w, 1) > 0.6             # boolean mask, as the data has
+  valid = f32(gt_disp > opts.bg_layer_disp)
+  ldi_src = [T(g[k], dev) for k in ('tex', 'mask', 'disp')]
+  got = eval_metrics.view_synthesis_metrics(
+      ldi_src, helpers.pixel_coords(b, h, w), torch.tensor(g['k_s']),
+      torch.tensor(g['k_t']), torch.tensor(g['rot']), torch.tensor(g['t']),
+      T(target, dev), opts, valid_mask=T(valid, dev),
+      disocc_mask=torch.tensor(disocc, device=dev), gt_disp_trg=T(gt_disp, dev))
+  r = O.forward_splat(g['tex'], g['mask'], g['disp'], g['M'], s, 0.05, md, zb, True)
+  want = O.eval_view_synthesis_metrics(r['img'], r['disp'], target, 0.1, valid,
+                                       disocc, gt_disp)
+  assert set(want) <= set(got)
+  for k, (ws, wn) in want.items():
+    assert abs(float(got[k][0]) - ws) <= 2e-4 * abs(ws), (k, float(got[k][0]), ws)
+    assert abs(float(got[k][1]) - wn) <= 1e-5 * abs(wn), (k, float(got[k][1]), wn)
+  assert want['compose_splat_loss_disocc'][1] < want['compose_splat_loss'][1]
+
+  # layer metrics: two random LDIs, gt foreground / background layers
+  ldis = [[f32(rs.rand(nl, b, h, w, 3)), None, f32(0.4 * rs.rand(nl, b, h, w, 1))]
+          for _ in range(2)]
+  imgs = [f32(rs.rand(b, h, w, 3)) for _ in range(2)]
+  gt = {}
+  for side in ('src', 'trg'):
+    gt[side + '_gt_disp'] = f32(0.4 * rs.rand(b, h, w, 1))
+    gt[side + '_gt_disp_bg'] = f32(0.4 * rs.rand(b, h, w, 1))
+    gt[side + '_gt_tex_bg'] = f32(rs.rand(b, h, w, 3))
+  dev_ldis = [[T(l[0], dev), None, T(l[2], dev)] for l in ldis]
+  got_l = eval_metrics.layer_prediction_metrics(
+      dev_ldis[0], dev_ldis[1], T(imgs[0], dev), T(imgs[1], dev),
+      {k: T(v, dev) for k, v in gt.items()}, opts)
+  want_l = O.eval_layer_prediction_metrics(ldis[0], ldis[1], imgs[0], imgs[1], gt,
+                                           opts.bg_layer_disp)
+  assert set(got_l) == set(want_l)
+  for k, (ws, wn) in want_l.items():
+    assert abs(float(got_l[k][0]) - ws) <= 1e-4 * abs(ws), k
+    assert float(got_l[k][1]) == wn, k
+  agg = eval_metrics.aggregate([got_l, got_l])
+  assert abs(agg['bg_disp_error'] - want_l['bg_disp_error'][0] /
+             want_l['bg_disp_error'][1]) < 1e-5
+
+
 def test_scene_generator_views_are_geometrically_consistent(dev):
   """Procedural scene -> two views through planar_transform + compose (HIP
   bilinear).  Splatting the source view with its ground-truth disparity into the

@@ -106,10 +106,46 @@ def test_camera_api_matches_golden(dev):
       compose_layers=True, compute_trg_disp=True, trg_downsampling=s,
       bg_layer_disp=bg, max_disp=md, zbuf_scale=zb)
   _cmp(got, g, 'compose')
-  with pytest.raises(NotImplementedError):
-    ldi.forward_splat(ldi_src, None, torch.tensor(g['k_s']),
-                      torch.tensor(g['k_t']), torch.tensor(g['rot']),
-                      torch.tensor(g['t']), focal_disps=torch.zeros(b, 1, 1, 1))
+  # focal_disps = 0 is the identity (ldi.py:130-143)
+  zero = ldi.forward_splat(
+      ldi_src, None, torch.tensor(g['k_s']), torch.tensor(g['k_t']),
+      torch.tensor(g['rot']), torch.tensor(g['t']),
+      focal_disps=torch.zeros(b, 1, 1, 1), compose_layers=True,
+      compute_trg_disp=True, trg_downsampling=s, bg_layer_disp=bg, max_disp=md,
+      zbuf_scale=zb)
+  _cmp(zero, g, 'compose')
+
+
+@pytest.mark.parametrize('tag', ['kitti', 'general'])
+@pytest.mark.parametrize('compose', [True, False])
+def test_focal_disps_matches_the_reference(tag, compose, dev):
+  """forward_splat(focal_disps=...) (ldi.py:130-143) against outputs of the
+  reference itself (tests/golden/focal_splat.npz)."""
+  from lsi.geometry import ldi
+  from lsi.nnutils import helpers
+  g = golden('focal_splat.npz')
+  s, bg, md, zb = [float(v) for v in g['params']]
+  ldi_src = [torch.tensor(g[tag + '_' + k], device=dev) for k in ('tex', 'mask', 'disp')]
+  b, h, w = g[tag + '_tex'].shape[1:4]
+  got = ldi.forward_splat(
+      ldi_src, helpers.pixel_coords(b, h, w), torch.tensor(g[tag + '_k_s']),
+      torch.tensor(g[tag + '_k_t']), torch.tensor(g[tag + '_rot']),
+      torch.tensor(g[tag + '_t']), focal_disps=torch.tensor(g[tag + '_focal']),
+      compose_layers=compose, compute_trg_disp=True, trg_downsampling=s,
+      bg_layer_disp=bg, max_disp=md, zbuf_scale=zb)
+  c = 'compose' if compose else 'indep'
+  img, wts, dsp = [t.cpu().numpy() for t in got]
+  np.testing.assert_allclose(img, g['%s_%s_img' % (tag, c)], rtol=0, atol=IMG_ATOL)
+  np.testing.assert_allclose(wts, g['%s_%s_wts' % (tag, c)], rtol=WTS_RTOL, atol=0)
+  np.testing.assert_allclose(dsp, g['%s_%s_disp' % (tag, c)], rtol=DSP_RTOL,
+                             atol=1e-7)
+  # and it differs from the rendering without the focal shift
+  plain = ldi.forward_splat(
+      ldi_src, helpers.pixel_coords(b, h, w), torch.tensor(g[tag + '_k_s']),
+      torch.tensor(g[tag + '_k_t']), torch.tensor(g[tag + '_rot']),
+      torch.tensor(g[tag + '_t']), compose_layers=compose,
+      trg_downsampling=s, bg_layer_disp=bg, max_disp=md, zbuf_scale=zb)
+  assert float((plain[0] - got[0]).abs().max()) > 1e-3
 
 
 def _synth(rs, nl, b, h, w, kitti=True, max_disp=0.4):

@@ -82,7 +82,7 @@ def test_unet_and_heads_shapes_and_layout():
 def _opts(tmpdir, **kw):
   sys.path.insert(0, PKG)
   import ldi_enc_dec as script
-  args = ['--dataset', 'kitti', '--batch_size', '1', '--n_layers', '2',
+  args = ['--dataset', 'kitti', '--kitti_procedural', 'true', '--batch_size', '1', '--n_layers', '2',
           '--img_height', '128', '--img_width', '128', '--num_iter', '2',
           '--indep_splat_wt', '0', '--compose_splat_wt', '0', '--cpu', 'true',
           '--log_freq', '1', '--save_latest_freq', '2',
@@ -92,10 +92,41 @@ def _opts(tmpdir, **kw):
   return script, script.apply_dataset_overrides(script.build_parser().parse_args(args))
 
 
+def _plumbing_trainer(script, opts):
+  """The training script's Trainer with a stand-in for compute_losses: the
+  renderer and the six loss terms are HIP kernels (no CPU path; the real
+  compute_losses is pinned on the GPU: tests/test_train_gpu.py), what runs here
+  is everything around them -- model, optimiser, DDP, checkpoints, resume."""
+
+  class PlumbingTrainer(script.Trainer):
+
+    def compute_losses(self, staged):
+      imgs_src, imgs_trg = staged[0], staged[1]
+      ldi_src, ldi_trg = self.train_model(imgs_src, imgs_trg)
+      total = ((ldi_src[0] - imgs_src).abs().mean() +
+               (ldi_trg[0] - imgs_trg).abs().mean() +
+               ldi_src[2].mean() + ldi_trg[2].mean())
+      names = ('self_cons_loss', 'compose_splat_loss', 'indep_splat_loss',
+               'incr_depth_loss', 'disp_smoothness_loss')
+      scalars = {n: total.detach() * 0 for n in names}
+      scalars['total_loss'] = total
+      return total, scalars
+
+  return PlumbingTrainer(opts)
+
+
+def test_compute_losses_has_no_cpu_path(tmp_path):
+  script, opts = _opts(tmp_path)
+  tr = script.Trainer(opts)
+  tr.setup()
+  with pytest.raises(RuntimeError, match='ROCm device'):
+    tr.train_step()
+
+
 def test_eager_trainer_steps_saves_and_resumes(tmp_path):
   script, opts = _opts(tmp_path)
   assert opts.bg_layer_disp == 1e-3 and opts.max_disp == 0.4   # kitti overrides
-  tr = script.Trainer(opts)
+  tr = _plumbing_trainer(script, opts)
   tr.setup()
   before = [p.detach().clone() for p in tr.model.parameters()]
   total, scalars = tr.train_step()
@@ -108,7 +139,7 @@ def test_eager_trainer_steps_saves_and_resumes(tmp_path):
   tr.train()
   assert tr.global_step == 2
   assert os.path.exists(os.path.join(opts.checkpoint_dir, 'model.latest'))
-  tr2 = script.Trainer(opts)
+  tr2 = _plumbing_trainer(script, opts)
   tr2.setup()
   assert tr2.global_step == 2            # auto-resume (train_utils.py:190-195)
   for a, b in zip(tr.model.parameters(), tr2.model.parameters()):
@@ -128,7 +159,7 @@ def _ddp_worker(rank, world, port, tmpdir, out):
                     RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
   torch.set_num_threads(2)
   script, opts = _opts(tmpdir, num_iter=1)
-  tr = script.Trainer(opts)
+  tr = _plumbing_trainer(script, opts)
   tr.setup(backend='gloo')
   tr.train_step()
   flat = torch.cat([p.detach().reshape(-1) for p in tr.model.parameters()])

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 def _trainer(tmp_path, **kw):
   sys.path.insert(0, PKG)
   import ldi_enc_dec as script
-  args = ['--dataset', 'kitti', '--batch_size', '2', '--n_layers', '2',
+  args = ['--dataset', 'kitti', '--kitti_procedural', 'true', '--batch_size', '2', '--n_layers', '2',
           '--img_height', '128', '--img_width', '256', '--num_iter', '3',
           '--log_freq', '1', '--checkpoint_dir', str(tmp_path)]
   for k, v in kw.items():
@@ -103,8 +103,8 @@ def test_eval_script_writes_results(tmp_path):
   import ldi_pred_eval as ev
   argv = ['--dataset', 'synthetic', '--synth_scene', 'planes', '--batch_size', '1',
           '--n_layers', '2', '--img_height', '128', '--img_width', '128',
-          '--n_obj_max', '2', '--num_eval_iter', '2', '--checkpoint_dir',
-          str(tmp_path)]
+          '--n_obj_max', '2', '--num_eval_iter', '2', '--random_weights', 'true',
+          '--checkpoint_dir', str(tmp_path)]
   opts = script_overrides(ev, argv)
   tester = ev.Tester(opts)
   results = tester.test()
@@ -123,3 +123,64 @@ def script_overrides(ev, argv):
   opts.debug_synth_texture = False
   opts.synth_dl_eval_data = True
   return opts
+
+
+def test_compute_losses_six_scalars_match_the_oracle(tmp_path, built_lib):
+  """Trainer.compute_losses itself (ldi_enc_dec.py:265-410) on a FIXED pair of
+  LDIs (the network is bypassed): both view-synthesis directions through
+  forward_splat_both, the two self-consistency terms, the regularisers and the
+  weighting (/ max_disp, / max_disp^2) against the NumPy oracle."""
+  import lsi_oracle as O
+  tr = _trainer(tmp_path, img_height=64, img_width=256, self_cons_wt=10,
+                incr_depth_wt=7, disp_smoothness_wt=0.3, compose_splat_wt=1.5,
+                indep_splat_wt=0.5)
+  o = tr.opts
+  rs = np.random.RandomState(11)
+  nl, b, h, w = o.n_layers, o.batch_size, o.img_height, o.img_width
+  f32 = lambda a: np.asarray(a, np.float32)
+  img_s, img_t = f32(rs.rand(b, h, w, 3)), f32(rs.rand(b, h, w, 3))
+  ldis = []
+  for _ in range(2):
+    tex = f32(rs.rand(nl, b, h, w, 3))
+    disp = f32(o.max_disp * rs.rand(nl, b, h, w, 1))
+    ldis.append((tex, disp))
+  k = f32([[0.58 * w, 0, w / 2.0], [0, 0.58 * w, h / 2.0], [0, 0, 1.0]])
+  k_s = np.broadcast_to(k, (b, 3, 3)).copy()
+  k_t = k_s.copy(); k_t[:, 0, 2] += 1.5                    # principal point moves
+  rot = np.broadcast_to(np.eye(3, dtype=np.float32), (b, 3, 3)).copy()
+  t = np.broadcast_to(f32([[-0.532], [0.0], [0.0]]), (b, 3, 1)).copy()
+  T = torch.tensor
+  staged, _ = tr.stage((T(img_s), T(img_t), T(k_s), T(k_t), T(rot), T(t)))
+  dev = tr.device
+  fixed = [[T(tex).to(dev), None, T(disp).to(dev)] for tex, disp in ldis]
+  tr.train_model = lambda a, b_: (fixed[0], fixed[1])
+  total, got = tr.compute_losses(staged)
+
+  md, bg, zb, s = o.max_disp, o.bg_layer_disp, o.zbuf_scale, o.trg_splat_downsampling
+  ones = np.ones((nl, b, h, w, 1), np.float32)
+  m_trg = O.forward_projection_matrix(k_s, k_t, rot, t)
+  rot_inv = np.swapaxes(rot, -1, -2)
+  m_src = O.forward_projection_matrix(k_t, k_s, rot_inv,
+                                      -np.matmul(rot_inv, t).astype(np.float32))
+  want = {k_: 0.0 for k_ in ('self_cons_loss', 'compose_splat_loss',
+                             'indep_splat_loss', 'incr_depth_loss',
+                             'disp_smoothness_loss')}
+  for (tex, disp), own, other, mat in ((ldis[0], img_s, img_t, m_trg),
+                                       (ldis[1], img_t, img_s, m_src)):
+    want['self_cons_loss'] += O.zbuffer_composition_loss(tex, ones, disp, own,
+                                                         bg, md, zb)
+    for compose, key in ((True, 'compose_splat_loss'), (False, 'indep_splat_loss')):
+      r = O.forward_splat(tex, ones, disp, mat, s, bg, md, zb, compose)
+      want[key] += O.view_synthesis_loss(r['img'], other, o.splat_bdry_ignore)
+    want['incr_depth_loss'] += O.decreasing_disp_loss(disp)
+    want['disp_smoothness_loss'] += O.disp_smoothness_loss(disp)
+  want['total_loss'] = (o.self_cons_wt * want['self_cons_loss'] +
+                        o.compose_splat_wt * want['compose_splat_loss'] +
+                        o.indep_splat_wt * want['indep_splat_loss'] +
+                        o.incr_depth_wt / md * want['incr_depth_loss'] +
+                        o.disp_smoothness_wt / (md * md) * want['disp_smoothness_loss'])
+  assert set(got) == set(want)
+  for key, v in want.items():
+    assert abs(float(got[key]) - float(v)) <= 2e-5 * abs(float(v)), (
+        key, float(got[key]), float(v))
+  assert abs(float(total) - float(want['total_loss'])) <= 2e-5 * abs(want['total_loss'])

@@ -14,7 +14,7 @@ def main():
   steps, warm = 20, 5
   if '--steps' in argv:
     i = argv.index('--steps'); steps = int(argv[i + 1]); del argv[i:i + 2]
-  base = ['--dataset', 'kitti', '--batch_size', '4', '--n_layers', '2',
+  base = ['--dataset', 'kitti', '--kitti_procedural', 'true', '--batch_size', '4', '--n_layers', '2',
           '--img_height', '256', '--img_width', '768', '--checkpoint_dir', '/tmp/lsi_ckpt',
           '--save_latest_freq', '1000000', '--checkpoint_freq', '1000000', '--log_freq', '1000000']
   opts = script.apply_dataset_overrides(script.build_parser().parse_args(base + argv))

@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'layered-scene-inference_amd'))
 import ldi_enc_dec as script
 argv = sys.argv[1:]
-base = ['--dataset', 'kitti', '--batch_size', '4', '--n_layers', '2', '--img_height', '256', '--img_width', '768',
+base = ['--dataset', 'kitti', '--kitti_procedural', 'true', '--batch_size', '4', '--n_layers', '2', '--img_height', '256', '--img_width', '768',
         '--checkpoint_dir', '/tmp/lsi_ckpt', '--save_latest_freq', '1000000', '--checkpoint_freq', '1000000', '--log_freq', '1000000']
 opts = script.apply_dataset_overrides(script.build_parser().parse_args(base + argv))
 tr = script.Trainer(opts); tr.setup()
