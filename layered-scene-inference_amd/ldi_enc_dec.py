@@ -94,6 +94,11 @@ def build_parser():
     'losses are HIP kernels, compute_losses raises without a ROCm device)')
   a('--miopen_search', type=_bool, default=False,
     help='exhaustive MIOpen solver search (torch.backends.cudnn.benchmark)')
+  a('--tf_checkpoint_complete', type=_bool, default=False,
+    help='also hold the variables the reference creates and checkpoints but '
+    'never trains (the fc stack on the U-Net bottleneck, upcnv3 .. icnv1), '
+    'frozen: the exact variable list of a TF checkpoint (lsi/nnutils/'
+    'tf_checkpoint.py)')
   a('--hip_graph', type=_bool, default=False,
     help='capture the training step in a HIP graph (single process)')
   return p
@@ -122,8 +127,11 @@ class LdiNet(torch.nn.Module):
   def __init__(self, opts):
     super().__init__()
     if opts.use_unet:
+      complete = bool(getattr(opts, 'tf_checkpoint_complete', False))
       self.enc_dec = nets.encoder_decoder_unet(
-          nl_diff_enc_dec=opts.n_layerwise_steps)
+          nl_diff_enc_dec=opts.n_layerwise_steps, with_fc=complete,
+          with_dead_decoder=complete,
+          in_hw=(opts.img_height, opts.img_width))
     else:
       self.enc_dec = nets.encoder_decoder_simple(
           nl_diff_enc_dec=opts.n_layerwise_steps,

@@ -148,18 +148,26 @@ class SlimFC(nn.Module):
     nn.init.xavier_uniform_(self.fc.weight)
     self.beta = nn.Parameter(torch.zeros(cout))
     self.register_buffer('gamma', torch.ones(cout))
+    # (TF creates and checkpoints the moving statistics; never updated: the
+    # reference runs no UPDATE_OPS, train_utils.py:107-117)
+    self.register_buffer('moving_mean', torch.zeros(cout))
+    self.register_buffer('moving_variance', torch.ones(cout))
     self.eps = 1e-3
+    self.is_training = True
 
   def forward(self, x):
     x = self.fc(x)
-    return F.relu(F.batch_norm(x, None, None, self.gamma, self.beta, True, 0.0,
-                               self.eps))
+    if self.is_training:
+      return F.relu(F.batch_norm(x, None, None, self.gamma, self.beta, True, 0.0,
+                                 self.eps))
+    return F.relu(F.batch_norm(x, self.moving_mean, self.moving_variance,
+                               self.gamma, self.beta, False, 0.0, self.eps))
 
 
 def set_is_training(module, is_training):
   """slim's `is_training` switch for every batch norm below `module`."""
   for m in module.modules():
-    if isinstance(m, SlimBatchNorm):
+    if isinstance(m, (SlimBatchNorm, SlimFC)):
       m.is_training = bool(is_training)
   return module
 
@@ -301,14 +309,19 @@ class EncoderDecoderUnet(nn.Module):
   feat_dec = feats_dec[-1 - nl_diff_enc_dec] (NCHW), skip_feat =
   [cnv6b, cnv5b, cnv4b, cnv3b, cnv2b, cnv1b] (NCHW), feat = bottleneck `fc`
   features (None unless with_fc).  H and W must be multiples of 128.
-  Decoder stages below the returned one are not built."""
+  Decoder stages below the returned one are not built -- unless
+  `with_dead_decoder`: the reference creates (and checkpoints) upcnv / icnv down
+  to stage 1 and the `fc` stack although nothing trains them when
+  nl_diff_enc_dec > 0 (nets.py:289-291, 328-345); with the two switches the
+  module holds exactly the reference's variable list (frozen, never executed
+  below the returned stage), for TF-checkpoint import / export."""
 
   _DEC = [('7', 512, 'cnv6b'), ('6', 512, 'cnv5b'), ('5', 256, 'cnv4b'),
           ('4', 128, 'cnv3b'), ('3', 64, 'cnv2b'), ('2', 32, 'cnv1b'),
           ('1', 32, None)]
 
   def __init__(self, nz=1000, nl_diff_enc_dec=0, in_channels=3, with_fc=False,
-               in_hw=None):
+               in_hw=None, with_dead_decoder=False):
     super().__init__()
     self.encoder = _Encoder14(in_channels)
     self.nl_diff_enc_dec = nl_diff_enc_dec
@@ -316,12 +329,19 @@ class EncoderDecoderUnet(nn.Module):
     skip_c = {'cnv6b': 512, 'cnv5b': 512, 'cnv4b': 256, 'cnv3b': 128,
               'cnv2b': 64, 'cnv1b': 32}
     cin = 512
-    for tag, cout, skip in self._DEC[:self.n_dec]:
-      setattr(self, 'upcnv' + tag, SlimConvTranspose2d(cin, cout))
-      setattr(self, 'icnv' + tag,
-              SlimConv2d(cout + (skip_c[skip] if skip else 0), cout, 3, 1))
+    for i, (tag, cout, skip) in enumerate(self._DEC):
+      if i >= self.n_dec and not with_dead_decoder:
+        break
+      up = SlimConvTranspose2d(cin, cout)
+      ic = SlimConv2d(cout + (skip_c[skip] if skip else 0), cout, 3, 1)
+      if i >= self.n_dec:  # never executed: keep it out of the optimiser / DDP
+        up.requires_grad_(False)
+        ic.requires_grad_(False)
+      setattr(self, 'upcnv' + tag, up)
+      setattr(self, 'icnv' + tag, ic)
       cin = cout
-    self.out_channels = cin
+      if i == self.n_dec - 1:
+        self.out_channels = cout
     self.skip_channels = [512, 512, 256, 128, 64, 32]
     self.fc = None
     if with_fc:

@@ -11,7 +11,7 @@ Variable scopes of the reference (slim):
   ldi_tex_disp/pixelwise_pred/upsample_<l>/decoder/upcnv<k>[b]/... (nets.py:73-114,
       117-161, 164-208)
   ldi_tex_disp/pixelwise_pred/upsample_<l>/pred_<l>/{weights, biases}
-  (non-U-Net variant: encoder_decoder_simple/encoder/..., .../decoder/...)
+  (non-U-Net variant, nets.py:211-241: top-level scopes encoder/..., decoder/...)
 Layouts: slim.conv2d weights are [kh, kw, in, out] (torch: [out, in, kh, kw]);
 slim.conv2d_transpose weights are [kh, kw, out, in] (torch ConvTranspose2d:
 [in, out, kh, kw]); fully_connected [in, out] (torch Linear: [out, in]).
@@ -36,8 +36,7 @@ def _layer_entries(tf_scope, torch_prefix, module):
     bn = torch_prefix + '.bn'
   elif isinstance(module, nets.SlimFC):
     out.append((tf_scope + '/weights', torch_prefix + '.fc.weight', 'fc'))
-    out.append((tf_scope + '/BatchNorm/beta', torch_prefix + '.beta', 'vec'))
-    return out
+    bn = torch_prefix
   else:
     return out
   if bn is not None:
@@ -67,16 +66,17 @@ def variable_map(model):
         entries += _layer_entries('%s/fc/fc_%d' % (top, i + 1),
                                   'enc_dec.fc.%d' % i, mod)
   else:
-    top = 'encoder_decoder_simple'
+    # encoder_decoder_simple opens no scope of its own (nets.py:211-241): its
+    # variables live under the top-level scopes `encoder` and `decoder`
     enc = enc_dec.encoder
     for name, mod in enc.encoder.named_children():
-      entries += _layer_entries('%s/encoder/%s' % (top, name),
+      entries += _layer_entries('encoder/%s' % name,
                                 'enc_dec.encoder.encoder.' + name, mod)
     for i, mod in enumerate(enc.fc):
-      entries += _layer_entries('%s/encoder/fc/fc_%d' % (top, i + 1),
+      entries += _layer_entries('encoder/fc/fc_%d' % (i + 1),
                                 'enc_dec.encoder.fc.%d' % i, mod)
     for name, mod in enc_dec.decoder.named_children():
-      entries += _layer_entries('%s/decoder/%s' % (top, name),
+      entries += _layer_entries('decoder/%s' % name,
                                 'enc_dec.decoder.' + name, mod)
   pp = model.ldi_tex_disp.pixelwise_pred
   for l, (dec, head) in enumerate(zip(pp.decoders, pp.preds)):

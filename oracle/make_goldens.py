@@ -379,6 +379,112 @@ def make_view_synthesis():
   np.savez_compressed(os.path.join(OUT, 'view_synthesis.npz'), **out)
 
 
+def load_reference_nets(mods):
+  """Executes the reference's unchanged lsi/nnutils/nets.py on the slim shim
+  (oracle/tf1_slim_shim.py); its `from lsi.nnutils import helpers` resolves to
+  the reference's own helpers module loaded by load_reference()."""
+  import types
+  import tf1_slim_shim as slim
+  slim.install()
+  names = ('lsi', 'lsi.nnutils', 'lsi.nnutils.helpers')
+  saved = {n: sys.modules.get(n) for n in names}
+  path = '/root/reference/lsi/nnutils/nets.py'
+  nets = types.ModuleType('ref_nets')
+  nets.__file__ = path
+  try:
+    for n in names:
+      sys.modules[n] = mods[n]
+    with open(path, 'r') as f:
+      exec(compile(f.read(), path, 'exec'), nets.__dict__)  # pylint: disable=exec-used
+  finally:
+    for n, old in saved.items():
+      if old is None:
+        sys.modules.pop(n, None)
+      else:
+        sys.modules[n] = old
+  return nets, slim
+
+
+def _sample(name, arr, n=96):
+  """Fixed pseudo-random sample of a stage's activations (the indices are a
+  pure function of the stage name and the shape) + its mean and std."""
+  import zlib
+  flat = np.asarray(arr, np.float32).reshape(-1)
+  rs = np.random.RandomState(zlib.crc32(name.encode('utf-8')) & 0x7fffffff)
+  idx = rs.randint(0, flat.size, size=min(n, flat.size))
+  return idx.astype(np.int64), flat[idx], np.array(
+      [flat.astype(np.float64).mean(), flat.astype(np.float64).std()])
+
+
+def make_nets(mods):
+  """The networks of nets.py:29-348 with seeded weights (tf1_slim_shim.
+  seeded_value: a pure function of the TF variable name, so no weights are
+  stored): the variable list the reference creates -- names and shapes, dead
+  variables included -- and stage-by-stage activation samples of
+    unet:   encoder_decoder_unet(nl_diff_enc_dec=3) + ldi_predictor(L=2, 3 steps)
+            on 4 x 128 x 128 images  (define_pred_graph, ldi_enc_dec.py:196-221)
+    masks:  the same heads with pred_masks=True (double sigmoid, last mask 1)
+    simple: encoder_decoder_simple(nl_diff_enc_dec=3) + ldi_predictor(L=1), 8 images."""
+  nets, slim = load_reference_nets(mods)
+  # (batch statistics over N*H*W values per channel: at the 1 x 1 bottleneck
+  # that is the batch size -- 4 / 8 images keep those layers well conditioned)
+  # (inputs are not stored either: RandomState(imgs_seed).rand(12, 128, 128, 3),
+  # the first 4 images for unet / masks, the last 8 for simple)
+  out = {'imgs_seed': np.int64(99)}
+  all_imgs = np.random.RandomState(99).rand(12, 128, 128, 3).astype(np.float32)
+  imgs, imgs8 = all_imgs[:4], all_imgs[4:]
+
+  def record(tag, end_points, ldi):
+    names = list(slim.VARIABLES)
+    out[tag + '_var_names'] = np.array(names)
+    out[tag + '_var_shapes'] = np.array(
+        [','.join(str(d) for d in slim.VARIABLES[n].shape) for n in names])
+    stages = sorted(end_points)
+    out[tag + '_stages'] = np.array(stages)
+    out[tag + '_stage_shapes'] = np.array(
+        [','.join(str(d) for d in end_points[k].a.shape) for k in stages])
+    for k in stages:
+      idx, val, stat = _sample(k, end_points[k].a)
+      out['%s_act_idx/%s' % (tag, k)] = idx
+      out['%s_act_val/%s' % (tag, k)] = val
+      out['%s_act_stat/%s' % (tag, k)] = stat
+    for name, t in zip(('tex', 'mask', 'disp'), ldi):
+      idx, val, stat = _sample(tag + '/ldi_' + name, t.a, 2048)
+      out['%s_ldi_%s_idx' % (tag, name)] = idx
+      out['%s_ldi_%s_val' % (tag, name)] = val
+      out['%s_ldi_%s_stat' % (tag, name)] = stat
+      out['%s_ldi_%s_shape' % (tag, name)] = np.array(t.a.shape)
+    print('nets', tag, len(names), 'variables', len(stages), 'stages',
+          sum(int(np.prod(slim.VARIABLES[n].shape)) for n in names), 'parameters')
+
+  def heads_end_points():
+    ep = {}
+    for coll in slim.COLLECTIONS:
+      ep.update(slim.convert_collection_to_dict(coll))
+    return ep
+
+  slim.reset()
+  _, feat_dec, skip_feat, _ = nets.encoder_decoder_unet(T(imgs), nl_diff_enc_dec=3)
+  ldi = nets.ldi_predictor(feat_dec, n_layers=2, n_layerwise_steps=3,
+                           skip_feat=skip_feat)
+  record('unet', heads_end_points(), ldi)
+
+  slim.reset()
+  _, feat_dec, skip_feat, _ = nets.encoder_decoder_unet(T(imgs), nl_diff_enc_dec=3)
+  ldi = nets.ldi_predictor(feat_dec, n_layers=2, n_layerwise_steps=3,
+                           skip_feat=skip_feat, pred_masks=True)
+  record('masks', {k: v for k, v in heads_end_points().items()
+                   if k.startswith('ldi_tex_disp')}, ldi)
+
+  slim.reset()
+  _, feat_dec, skip_feat, _ = nets.encoder_decoder_simple(T(imgs8), nl_diff_enc_dec=3)
+  assert skip_feat is None
+  ldi = nets.ldi_predictor(feat_dec, n_layers=1, n_layerwise_steps=3,
+                           skip_feat=skip_feat)
+  record('simple', heads_end_points(), ldi)
+  np.savez_compressed(os.path.join(OUT, 'nets.npz'), **out)
+
+
 def make_focal(mods):
   """forward_splat with focal_disps (ldi.py:130-143: the disparity is shifted by
   a per-sample focal disparity before the projection and shifted back
@@ -523,6 +629,7 @@ def main():
   make_view_synthesis()
   make_scene_geometry()
   make_focal(mods)
+  make_nets(mods)
   total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
   print('wrote %d bytes under %s' % (total, OUT))
 

@@ -311,7 +311,7 @@ def install():
   me = sys.modules[__name__]
   tf.install()
   tf.variable_scope = variable_scope
-  tf.nn.sigmoid = staticmethod(sigmoid)
+  tf.nn.sigmoid = sigmoid
   tf.sigmoid = sigmoid
   if not hasattr(Tensor, 'ndims'):
     tf._Shape.ndims = property(lambda self: len(self))
