@@ -361,6 +361,29 @@ int lsi_compose_depth_fwd(int32_t L, int64_t N, const float* masks,
                           float min_disp, float depth_softmax_temp, float* out,
                           lsi_stream_t stream);
 
+/*
+ * Fused batch norm (batch statistics) + beta + ReLU of the reference's conv
+ * layers: slim.batch_norm(center=True, scale=False, epsilon, is_training=True)
+ * followed by tf.nn.relu (nets.py:44-67, 95-111, 265-347).  x, y, dy, dx:
+ * npix x C values, C innermost (torch channels_last), fp32 (bf16 = 0) or
+ * bfloat16 (bf16 = 1); C a multiple of 4 (fp32) / 8 (bf16) with C / that a
+ * power of two <= 256, C <= 2048 -- else LSI_EINVAL.  Statistics in fp32
+ * (shifted sums, fp32 device atomics across workgroups), biased variance
+ * (tf.nn.moments).  relu = 0: batch norm only.
+ *   workspace: lsi_bn_workspace_floats(npix, C, bf16) floats, ZERO-FILLED ONCE
+ *   by the caller and then reusable by any later call on the same stream (the
+ *   library leaves its counter and accumulators zero).
+ *   mean_rstd: [2][C] out (forward), in (backward).  dbeta: [C] out.
+ */
+size_t lsi_bn_workspace_floats(int64_t npix, int32_t C, int32_t bf16);
+int lsi_bn_relu_fwd(const void* x, void* y, const float* beta, float* workspace,
+                    float* mean_rstd, int64_t npix, int32_t C, int32_t bf16,
+                    int32_t relu, float eps, lsi_stream_t stream);
+int lsi_bn_relu_bwd(const void* x, const void* dy, const float* mean_rstd,
+                    const float* beta, void* dx, float* dbeta, float* workspace,
+                    int64_t npix, int32_t C, int32_t bf16, int32_t relu,
+                    lsi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

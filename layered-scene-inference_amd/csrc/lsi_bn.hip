@@ -1,0 +1,391 @@
+// Fused batch norm (batch statistics) + beta + ReLU for channels-last
+// activations -- slim.batch_norm(center=True, scale=False, epsilon=1e-3,
+// is_training=True) followed by tf.nn.relu, the normaliser / activation of every
+// slim.conv2d / conv2d_transpose of the reference's networks (nets.py:44-67,
+// 95-111, 265-347).
+//
+// Why: in the bf16 training step the convolutions (MIOpen implicit GEMM) are
+// followed by three MIOpen batch-norm kernels, a ReLU kernel and dtype casts per
+// layer, and by five more in the backward (profiles/r02/train_step_summary.json:
+// the BN / elementwise chain is ~25 % of the step's kernel time).  Here the
+// forward is two passes over the activation (statistics; normalise + ReLU +
+// store in the input's dtype) and the backward two (reductions; dx), each a
+// pure HBM stream of 16-byte accesses.
+//
+// Layout: x is N*H*W pixels x C channels, C innermost (torch channels_last),
+// fp32 or bf16; C a multiple of the 16-byte vector (4 fp32 / 8 bf16) with
+// C / vector a power of two <= 256.  Statistics are accumulated in fp32 per
+// thread (around a per-channel shift: the channel's first value, so that
+// E[(x-k)^2] - E[x-k]^2 does not cancel), per workgroup in fp32 through LDS,
+// across workgroups by fp32 device-scope atomic adds into 2*C accumulators; the
+// workgroup that arrives LAST (a device-scope counter) turns the totals into
+// the per-channel constants the second pass reads and leaves accumulators and
+// counter zero for the next launch.
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+
+#include "../../include/lsi_hip.h"
+
+namespace {
+
+constexpr int BN_THREADS = 256;
+
+template <bool BF16> struct Vec;
+template <> struct Vec<false> {
+  static constexpr int N = 4;
+  typedef float4 raw;
+  __device__ static void load(const void* p, long i, float* v) {
+    const float4 r = reinterpret_cast<const float4*>(p)[i];
+    v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w;
+  }
+  __device__ static void store(void* p, long i, const float* v) {
+    reinterpret_cast<float4*>(p)[i] = make_float4(v[0], v[1], v[2], v[3]);
+  }
+};
+template <> struct Vec<true> {
+  static constexpr int N = 8;
+  __device__ static void load(const void* p, long i, float* v) {
+    const uint4 r = reinterpret_cast<const uint4*>(p)[i];
+    const unsigned w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      v[2 * k] = __uint_as_float(w[k] << 16);
+      v[2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u);
+    }
+  }
+  __device__ static unsigned rne(float f) {  // fp32 -> bf16 bits, round to nearest even
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;  // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+  }
+  __device__ static void store(void* p, long i, const float* v) {
+    uint4 r;
+    r.x = rne(v[0]) | (rne(v[1]) << 16);
+    r.y = rne(v[2]) | (rne(v[3]) << 16);
+    r.z = rne(v[4]) | (rne(v[5]) << 16);
+    r.w = rne(v[6]) | (rne(v[7]) << 16);
+    reinterpret_cast<uint4*>(p)[i] = r;
+  }
+};
+
+// workspace layout (floats): [0] arrival counter (int), [16, 16 + 4096) the
+// accumulators -- both zero between launches --, then 2*C constants of the
+// second pass
+constexpr int WS_ACC = 16, WS_CONST = 16 + 4096;
+
+// Sums of the per-thread accumulators over the threads that hold the same
+// channels (tid % lpp), added to the 2*C global accumulators; returns true in
+// the workgroup that arrived last, with the totals in `tot` (LDS, [2*C]).
+template <int NV>
+__device__ bool reduce_all(const float* a0, const float* a1, int lpp, int C,
+                           float* ws, float* tot) {
+  __shared__ float red[BN_THREADS * 2 * 8];
+  __shared__ int last;
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    red[tid * 2 * NV + k] = a0[k];
+    red[tid * 2 * NV + NV + k] = a1[k];
+  }
+  __syncthreads();
+  float* acc = ws + WS_ACC;
+  for (int t = tid; t < 2 * C; t += BN_THREADS) {
+    const int q = t / C, c = t - q * C;
+    const int lane = c / NV, k = c - lane * NV;
+    float s = 0.0f;
+    for (int r = lane; r < BN_THREADS; r += lpp) s += red[r * 2 * NV + q * NV + k];
+    __hip_atomic_fetch_add(acc + t, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __builtin_amdgcn_s_waitcnt(0);   // the adds are performed ...
+  __syncthreads();
+  if (tid == 0)                    // ... before this workgroup is counted
+    last = __hip_atomic_fetch_add(reinterpret_cast<int*>(ws), 1, __ATOMIC_RELAXED,
+                                  __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+  __syncthreads();
+  if (!last) return false;
+  for (int t = tid; t < 2 * C; t += BN_THREADS) {
+    // (read and clear in one atomic: the accumulators are zero again)
+    tot[t] = __hip_atomic_exchange(acc + t, 0.0f, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (tid == 0)
+    __hip_atomic_store(reinterpret_cast<int*>(ws), 0, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  return true;
+}
+
+// pass 1 of the forward: sums of (x - k) and (x - k)^2 per channel, k = the
+// channel's value at pixel 0
+template <bool BF16>
+__global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(
+    const void* __restrict__ x, const float* __restrict__ beta,
+    float* __restrict__ ws, float* __restrict__ mean_rstd, long npix, int C,
+    float eps) {
+  constexpr int NV = Vec<BF16>::N;
+  const int lpp = C / NV;                      // lanes per pixel
+  const int rows = BN_THREADS / lpp;           // pixels per workgroup step
+  const int lane = threadIdx.x % lpp, row = threadIdx.x / lpp;
+  float kk[NV], s[NV], q[NV];
+  Vec<BF16>::load(x, lane, kk);
+#pragma unroll
+  for (int k = 0; k < NV; ++k) { s[k] = 0.f; q[k] = 0.f; }
+  const long stride = (long)gridDim.x * rows;
+  long p = (long)blockIdx.x * rows + row;
+  for (; p + 3 * stride < npix; p += 4 * stride) {   // four loads in flight
+    float v[4][NV];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) Vec<BF16>::load(x, (p + u * stride) * lpp + lane, v[u]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int k = 0; k < NV; ++k) {
+        const float d = v[u][k] - kk[k];
+        s[k] += d; q[k] = __fmaf_rn(d, d, q[k]);
+      }
+  }
+  for (; p < npix; p += stride) {
+    float v[NV];
+    Vec<BF16>::load(x, p * lpp + lane, v);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const float d = v[k] - kk[k];
+      s[k] += d; q[k] = __fmaf_rn(d, d, q[k]);
+    }
+  }
+  __shared__ float tot[2 * 2048];
+  if (!reduce_all<NV>(s, q, lpp, C, ws, tot)) return;
+  // the last workgroup: mean, rstd, and y = x * a + b
+  float* ab = ws + WS_CONST;
+  for (int c = threadIdx.x; c < C; c += BN_THREADS) {
+    float k0[NV];
+    Vec<BF16>::load(x, c / NV, k0);
+    const double shift = (double)k0[c % NV];
+    const double m1 = (double)tot[c] / (double)npix;
+    double var = (double)tot[C + c] / (double)npix - m1 * m1;   // biased (tf.nn.moments)
+    if (var < 0.0) var = 0.0;
+    const double mean = shift + m1;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    mean_rstd[c] = (float)mean;
+    mean_rstd[C + c] = rstd;
+    ab[c] = rstd;
+    ab[C + c] = beta[c] - (float)mean * rstd;
+  }
+}
+
+// pass 2 of the forward: y = relu(x * a + b), a = rstd, b = beta - mean * rstd
+template <bool BF16>
+__global__ __launch_bounds__(BN_THREADS) void bn_norm_kernel(
+    const void* __restrict__ x, void* __restrict__ y, const float* __restrict__ ws,
+    long npix, int C, int relu) {
+  constexpr int NV = Vec<BF16>::N;
+  const int lpp = C / NV, rows = BN_THREADS / lpp;
+  const int lane = threadIdx.x % lpp, row = threadIdx.x / lpp;
+  const float* ab = ws + WS_CONST;
+  float a[NV], b[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) { a[k] = ab[lane * NV + k]; b[k] = ab[C + lane * NV + k]; }
+  const long stride = (long)gridDim.x * rows;
+  long p = (long)blockIdx.x * rows + row;
+  for (; p + 3 * stride < npix; p += 4 * stride) {
+    float v[4][NV];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) Vec<BF16>::load(x, (p + u * stride) * lpp + lane, v[u]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int k = 0; k < NV; ++k) {
+        const float z = __fmaf_rn(v[u][k], a[k], b[k]);
+        v[u][k] = relu ? fmaxf(z, 0.0f) : z;
+      }
+      Vec<BF16>::store(y, (p + u * stride) * lpp + lane, v[u]);
+    }
+  }
+  for (; p < npix; p += stride) {
+    float v[NV];
+    Vec<BF16>::load(x, p * lpp + lane, v);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const float z = __fmaf_rn(v[k], a[k], b[k]);
+      v[k] = relu ? fmaxf(z, 0.0f) : z;
+    }
+    Vec<BF16>::store(y, p * lpp + lane, v);
+  }
+}
+
+// pass 1 of the backward: sums of dz = dy * [z > 0] and of dz * xhat
+template <bool BF16>
+__global__ __launch_bounds__(BN_THREADS) void bn_bwd_stats_kernel(
+    const void* __restrict__ x, const void* __restrict__ dy,
+    const float* __restrict__ mean_rstd, const float* __restrict__ beta,
+    float* __restrict__ ws, float* __restrict__ dbeta, long npix, int C, int relu) {
+  constexpr int NV = Vec<BF16>::N;
+  const int lpp = C / NV, rows = BN_THREADS / lpp;
+  const int lane = threadIdx.x % lpp, row = threadIdx.x / lpp;
+  float mu[NV], rs[NV], be[NV], s[NV], q[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    mu[k] = mean_rstd[lane * NV + k]; rs[k] = mean_rstd[C + lane * NV + k];
+    // (the forward's z = x * rstd + (beta - mean * rstd): the same mask)
+    be[k] = beta[lane * NV + k] - mu[k] * rs[k]; s[k] = 0.f; q[k] = 0.f;
+  }
+  const long stride = (long)gridDim.x * rows;
+  long p = (long)blockIdx.x * rows + row;
+  auto acc = [&](const float* v, const float* g) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const float xh = (v[k] - mu[k]) * rs[k];
+      const float dz = (!relu || __fmaf_rn(v[k], rs[k], be[k]) > 0.0f) ? g[k] : 0.0f;
+      s[k] += dz;
+      q[k] = __fmaf_rn(dz, xh, q[k]);
+    }
+  };
+  for (; p + stride < npix; p += 2 * stride) {   // four loads in flight
+    float v[2][NV], g[2][NV];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      Vec<BF16>::load(x, (p + u * stride) * lpp + lane, v[u]);
+      Vec<BF16>::load(dy, (p + u * stride) * lpp + lane, g[u]);
+    }
+    acc(v[0], g[0]);
+    acc(v[1], g[1]);
+  }
+  for (; p < npix; p += stride) {
+    float v[NV], g[NV];
+    Vec<BF16>::load(x, p * lpp + lane, v);
+    Vec<BF16>::load(dy, p * lpp + lane, g);
+    acc(v, g);
+  }
+  __shared__ float tot[2 * 2048];
+  if (!reduce_all<NV>(s, q, lpp, C, ws, tot)) return;
+  float* c12 = ws + WS_CONST;
+  const float inv_m = (float)(1.0 / (double)npix);
+  for (int c = threadIdx.x; c < C; c += BN_THREADS) {
+    dbeta[c] = tot[c];
+    c12[c] = tot[c] * inv_m;
+    c12[C + c] = tot[C + c] * inv_m;
+  }
+}
+
+// pass 2 of the backward: dx = rstd * (dz - mean(dz) - xhat * mean(dz * xhat))
+template <bool BF16>
+__global__ __launch_bounds__(BN_THREADS) void bn_bwd_dx_kernel(
+    const void* __restrict__ x, const void* __restrict__ dy,
+    const float* __restrict__ mean_rstd, const float* __restrict__ beta,
+    const float* __restrict__ ws, void* __restrict__ dx, long npix, int C,
+    int relu) {
+  constexpr int NV = Vec<BF16>::N;
+  const int lpp = C / NV, rows = BN_THREADS / lpp;
+  const int lane = threadIdx.x % lpp, row = threadIdx.x / lpp;
+  const float* c12 = ws + WS_CONST;
+  float mu[NV], rs[NV], be[NV], c1[NV], c2[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int c = lane * NV + k;
+    mu[k] = mean_rstd[c]; rs[k] = mean_rstd[C + c];
+    be[k] = beta[c] - mu[k] * rs[k];
+    c1[k] = c12[c];
+    c2[k] = c12[C + c];
+  }
+  auto one = [&](float* v, const float* g) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const float xh = (v[k] - mu[k]) * rs[k];
+      const float dz = (!relu || __fmaf_rn(v[k], rs[k], be[k]) > 0.0f) ? g[k] : 0.0f;
+      v[k] = rs[k] * (dz - c1[k] - xh * c2[k]);
+    }
+  };
+  const long stride = (long)gridDim.x * rows;
+  long p = (long)blockIdx.x * rows + row;
+  for (; p + stride < npix; p += 2 * stride) {
+    float v[2][NV], g[2][NV];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      Vec<BF16>::load(x, (p + u * stride) * lpp + lane, v[u]);
+      Vec<BF16>::load(dy, (p + u * stride) * lpp + lane, g[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      one(v[u], g[u]);
+      Vec<BF16>::store(dx, (p + u * stride) * lpp + lane, v[u]);
+    }
+  }
+  for (; p < npix; p += stride) {
+    float v[NV], g[NV];
+    Vec<BF16>::load(x, p * lpp + lane, v);
+    Vec<BF16>::load(dy, p * lpp + lane, g);
+    one(v, g);
+    Vec<BF16>::store(dx, p * lpp + lane, v);
+  }
+}
+
+bool bn_shape_ok(long npix, int C, int bf16) {
+  const int nv = bf16 ? 8 : 4;
+  if (npix <= 0 || C <= 0 || C % nv) return false;
+  const int lpp = C / nv;
+  return lpp <= BN_THREADS && (lpp & (lpp - 1)) == 0 && C <= 2048;
+}
+
+int bn_grid(long npix, int C, int bf16) {
+  const int rows = BN_THREADS / (C / (bf16 ? 8 : 4));
+  long g = (npix + rows * 16 - 1) / (rows * 16);   // >= 16 steps per workgroup
+  if (g < 1) g = 1;
+  if (g > 2048) g = 2048;                           // 8 workgroups per CU
+  return (int)g;
+}
+
+bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+// workspace: see WS_ACC / WS_CONST above (shape independent)
+extern "C" size_t lsi_bn_workspace_floats(int64_t npix, int32_t C, int32_t bf16) {
+  if (!bn_shape_ok(npix, C, bf16)) return 0;
+  return (size_t)WS_CONST + 2 * (size_t)C;
+}
+
+extern "C" int lsi_bn_relu_fwd(const void* x, void* y, const float* beta,
+                               float* workspace, float* mean_rstd, int64_t npix,
+                               int32_t C, int32_t bf16, int32_t relu, float eps,
+                               lsi_stream_t stream_) {
+  if (!x || !y || !beta || !workspace || !mean_rstd) return LSI_ENULL;
+  if (!bn_shape_ok(npix, C, bf16) || !al16(x) || !al16(y)) return LSI_EINVAL;
+  hipStream_t st = (hipStream_t)stream_;
+  const int g = bn_grid(npix, C, bf16);
+  if (bf16) {
+    hipLaunchKernelGGL(bn_stats_kernel<true>, dim3(g), dim3(BN_THREADS), 0, st, x, beta,
+                       workspace, mean_rstd, (long)npix, C, eps);
+    hipLaunchKernelGGL(bn_norm_kernel<true>, dim3(g), dim3(BN_THREADS), 0, st, x, y,
+                       (const float*)workspace, (long)npix, C, relu);
+  } else {
+    hipLaunchKernelGGL(bn_stats_kernel<false>, dim3(g), dim3(BN_THREADS), 0, st, x, beta,
+                       workspace, mean_rstd, (long)npix, C, eps);
+    hipLaunchKernelGGL(bn_norm_kernel<false>, dim3(g), dim3(BN_THREADS), 0, st, x, y,
+                       (const float*)workspace, (long)npix, C, relu);
+  }
+  return hipGetLastError() == hipSuccess ? LSI_OK : LSI_ELAUNCH;
+}
+
+extern "C" int lsi_bn_relu_bwd(const void* x, const void* dy, const float* mean_rstd,
+                               const float* beta, void* dx, float* dbeta,
+                               float* workspace, int64_t npix, int32_t C,
+                               int32_t bf16, int32_t relu, lsi_stream_t stream_) {
+  if (!x || !dy || !mean_rstd || !beta || !dx || !dbeta || !workspace) return LSI_ENULL;
+  if (!bn_shape_ok(npix, C, bf16) || !al16(x) || !al16(dy) || !al16(dx)) return LSI_EINVAL;
+  hipStream_t st = (hipStream_t)stream_;
+  const int g = bn_grid(npix, C, bf16);
+  if (bf16) {
+    hipLaunchKernelGGL(bn_bwd_stats_kernel<true>, dim3(g), dim3(BN_THREADS), 0, st, x,
+                       dy, mean_rstd, beta, workspace, dbeta, (long)npix, C, relu);
+    hipLaunchKernelGGL(bn_bwd_dx_kernel<true>, dim3(g), dim3(BN_THREADS), 0, st, x, dy,
+                       mean_rstd, beta, (const float*)workspace, dx, (long)npix, C, relu);
+  } else {
+    hipLaunchKernelGGL(bn_bwd_stats_kernel<false>, dim3(g), dim3(BN_THREADS), 0, st, x,
+                       dy, mean_rstd, beta, workspace, dbeta, (long)npix, C, relu);
+    hipLaunchKernelGGL(bn_bwd_dx_kernel<false>, dim3(g), dim3(BN_THREADS), 0, st, x, dy,
+                       mean_rstd, beta, (const float*)workspace, dx, (long)npix, C, relu);
+  }
+  return hipGetLastError() == hipSuccess ? LSI_OK : LSI_ELAUNCH;
+}

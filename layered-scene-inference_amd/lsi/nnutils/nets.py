@@ -43,6 +43,19 @@ def _same_pad(n, k, stride):
 IMPLICIT_PAD = os.environ.get('LSI_IMPLICIT_PAD', '1') != '0'
 # bf16 batch norm on large maps under autocast (LSI_BF16_BN=0 restores fp32)
 BF16_BATCH_NORM = os.environ.get('LSI_BF16_BN', '1') != '0'
+# batch norm + ReLU of the conv layers as the fused HIP kernels (csrc/lsi_bn.hip)
+# for channels-last activations on the GPU; LSI_FUSED_BN=0 keeps MIOpen's
+FUSED_BN = os.environ.get('LSI_FUSED_BN', '1') != '0'
+
+
+def _bn_relu(bn, x):
+  """relu(bn(x)): two HIP passes forward, two backward (statistics, normalise +
+  ReLU + store in x's dtype) where the layout allows, else torch / MIOpen."""
+  if FUSED_BN and bn.is_training and x.is_cuda:
+    from lsi.nnutils import _hip_bn  # pylint: disable=g-import-not-at-top
+    if _hip_bn.supported(x):
+      return _hip_bn.batch_norm_relu(x, bn.beta, bn.eps, True)
+  return F.relu(bn(x))
 
 
 class SlimBatchNorm(nn.Module):
@@ -116,6 +129,8 @@ class SlimConv2d(nn.Module):
       if ph[0] or ph[1] or pw[0] or pw[1]:
         x = F.pad(x, (pw[0], pw[1], ph[0], ph[1]))
       x = self.conv(x)
+    if self.bn is not None and self.activation == 'relu':
+      return _bn_relu(self.bn, x)
     if self.bn is not None:
       x = self.bn(x)
     if self.activation == 'relu':
@@ -136,7 +151,7 @@ class SlimConvTranspose2d(nn.Module):
     self.bn = SlimBatchNorm(cout)
 
   def forward(self, x):
-    return F.relu(self.bn(self.conv(x)))
+    return _bn_relu(self.bn, self.conv(x))
 
 
 class SlimFC(nn.Module):

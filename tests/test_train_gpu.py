@@ -184,3 +184,79 @@ def test_compute_losses_six_scalars_match_the_oracle(tmp_path, built_lib):
     assert abs(float(got[key]) - float(v)) <= 2e-5 * abs(float(v)), (
         key, float(got[key]), float(v))
   assert abs(float(total) - float(want['total_loss'])) <= 2e-5 * abs(want['total_loss'])
+
+
+@pytest.mark.parametrize('dtype', ['float32', 'bfloat16'])
+@pytest.mark.parametrize('shape', [(4, 32, 64, 96), (2, 512, 2, 6), (2, 64, 1, 1),
+                                   (3, 128, 17, 23), (2, 256, 8, 24)])
+def test_fused_batch_norm_relu_matches_torch(shape, dtype, built_lib):
+  """csrc/lsi_bn.hip (batch statistics, beta, ReLU; slim.batch_norm defaults,
+  nets.py:44-67) against torch.nn.functional.batch_norm + relu in fp32 (fp64 for
+  the gradient reference): forward, dx and dbeta."""
+  from lsi.nnutils import _hip_bn
+  dev = torch.device('cuda:0')
+  dt = getattr(torch, dtype)
+  gen = torch.Generator(device='cpu').manual_seed(sum(shape))
+  n, c, h, w = shape
+  x = (torch.randn(shape, generator=gen) * 1.7 + 0.4).to(dev).to(dt)
+  x = x.contiguous(memory_format=torch.channels_last)
+  beta = (torch.randn(c, generator=gen) * 0.3).to(dev)
+  g = torch.randn(shape, generator=gen).to(dev).to(dt).contiguous(
+      memory_format=torch.channels_last)
+  assert _hip_bn.supported(x)
+  xq = x.detach().clone().requires_grad_(True)
+  bq = beta.detach().clone().requires_grad_(True)
+  y = _hip_bn.batch_norm_relu(xq, bq, 1e-3, True)
+  assert y.dtype == dt and y.is_contiguous(memory_format=torch.channels_last)
+  y.backward(g)
+  # reference on the SAME (possibly bf16-rounded) inputs, in fp64
+  xr = x.double().detach().requires_grad_(True)
+  br = beta.double().detach().requires_grad_(True)
+  yr = torch.relu(torch.nn.functional.batch_norm(
+      xr, None, None, torch.ones(c, dtype=torch.float64, device=dev), br, True,
+      0.0, 1e-3))
+  yr.backward(g.double())
+  if dtype == 'float32':
+    fwd_tol, grad_tol = 2e-5, 2e-4
+  else:     # outputs rounded to bf16 (8 bits): half an ulp of the largest value
+    fwd_tol, grad_tol = 2e-2, 3e-2
+  scale = float(yr.abs().max()) + 1e-6
+  assert float((y.double() - yr).abs().max()) <= fwd_tol * scale
+  # ReLU masks agree except within rounding of zero
+  differ = ((y > 0) != (yr > 0))
+  assert float(differ.float().mean()) < 1e-3
+  gs = float(xr.grad.abs().max()) + 1e-12
+  assert float((xq.grad.double() - xr.grad).abs().max()) <= grad_tol * gs, dtype
+  bs = float(br.grad.abs().max()) + 1e-12
+  assert float((bq.grad.double() - br.grad).abs().max()) <= grad_tol * bs
+  # run to run: the cross-workgroup sums are fp32 atomics (arrival order), the
+  # statistics agree to rounding
+  y2 = _hip_bn.batch_norm_relu(x, beta, 1e-3, True)
+  assert float((y2.double() - y.detach().double()).abs().max()) <= fwd_tol * scale
+
+
+def test_fused_batch_norm_is_what_the_network_runs(tmp_path, built_lib):
+  """The conv layers go through the fused kernels (channels-last, training
+  mode), and the step they produce equals the MIOpen-batch-norm step."""
+  import lsi.nnutils.nets as nets
+  from lsi.nnutils import _hip_bn
+  calls = []
+  orig = _hip_bn.batch_norm_relu
+  _hip_bn.batch_norm_relu = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+  try:
+    tr = _trainer(tmp_path / 'a')
+    batch = tr.feed()
+    tr.feed = lambda: batch
+    fused, _ = tr.train_step()
+  finally:
+    _hip_bn.batch_norm_relu = orig
+  assert len(calls) >= 40, len(calls)
+  nets.FUSED_BN = False
+  try:
+    tr2 = _trainer(tmp_path / 'b')
+    tr2.feed = lambda: batch
+    plain, _ = tr2.train_step()
+  finally:
+    nets.FUSED_BN = True
+  assert abs(float(fused) - float(plain)) <= 2e-3 * abs(float(plain)), (
+      float(fused), float(plain))

@@ -64,3 +64,16 @@ grid = np.linspace(0, np.nanmax(us[:, :, 6][act]), 41)
 busy = [(int(((us[:, :, 3] <= x) & (us[:, :, 4] > x) & act).sum())) for x in grid]
 print('waves inside the task loop over time (us: count):')
 print('  ' + '  '.join('%.0f:%d' % (x, n) for x, n in zip(grid, busy)))
+
+# where the slow workgroups are: by XCD (contiguous runs of workgroups), by band
+# position inside the image, by batch element
+end = np.nanmax(np.where(act, us[:, :, 6], np.nan), axis=1)
+nwg_ = len(end)
+if nwg_ % 8 == 0 and nwg_ >= 64:
+  per_xcd = end.reshape(8, -1)
+  print('WG end by XCD (mean / max):', ' '.join('%.1f/%.1f' % (a.mean(), a.max()) for a in per_xcd))
+nb = nwg_ // batch
+if nb * batch == nwg_ and nb > 1:
+  byband = end.reshape(batch, nb)
+  print('WG end by band position (mean over b):', ' '.join('%.1f' % v for v in byband.mean(axis=0)))
+  print('WG end by batch element (mean over bands):', ' '.join('%.1f' % v for v in byband.mean(axis=1)))
