@@ -577,7 +577,11 @@ def main():
   r.desc.reserved = args.debug_flags
   elapsed, ev_ms, launch_mode = timed_region(r, args.steps, args.warmup,
                                              args.launch, dist, dev)
+  ev_ms_rank = ev_ms
   elapsed, ev_ms = reduce_max([elapsed, ev_ms], dist, dev)
+  # per-rank average launch time: slowest and fastest rank (N > 1: which GPU
+  # holds the job back)
+  ev_min = -reduce_max([-ev_ms_rank], dist, dev)[0]
 
   if rank == 0:
     views = b_local * world * args.steps
@@ -610,9 +614,16 @@ def main():
             # inside the measured launch
             'kernel': ('splat_sweep_kernel (+ disp_range_kernel)'
                        if r.path_name == 'tile' else
-                       'splat_%s_kernel' % r.path_name),
+                       # compose mode, no mask, unit normaliser, channels-last,
+                       # rows of whole 256-pixel segments: the compact instance
+                       'splat_stream2_kernel' if (r.path_name == 'stream' and
+                                                  w % 256 == 0 and
+                                                  args.tex_layout == 'nhwc')
+                       else 'splat_%s_kernel' % r.path_name),
             'algorithmic_bytes_per_launch': alg,
             'avg_launch_us': kern_s * 1e6,
+            'avg_launch_us_per_rank': {
+                'max': ev_ms * 1e3 / args.steps, 'min': ev_min * 1e3 / args.steps},
         },
     }
     if world == 1 and not args.no_extra:

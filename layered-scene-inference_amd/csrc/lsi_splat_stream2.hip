@@ -59,9 +59,12 @@ struct S2Args {
   const float* M;
   float* out_img;
   float* out_wts;
+  float* out_img_c;  // BOTH: the composed view next to the L per-layer views
+  float* out_wts_c;
   int B, H, Ht, Wt, L, nseg;
   int tex_sl, tex_sb, tex_sy, disp_sl, disp_sb, disp_sy;  // element strides
   float s, max_disp, zA, zB, lbg;  // exp2(fma(clip(d), zA, zB)); L * bg weight
+  float bg;                        // bg weight of one layer's canvas
   int R, wmax, qcap, cap, ilv;     // band rows, window cells, queue, table, row interleave
   int nsplit, lsub;                // units handed out lsub layers per ticket
   float inv_gx, inv_nseg;
@@ -316,7 +319,10 @@ __device__ __noinline__ void s2_flush_queue(unsigned tile_off, unsigned locks_of
 
 struct Px { float4 d4, t0, t1, t2; };
 
-template <int NSETS, bool CELL, int MAXT>
+// BOTH: lsi_splat_fwd_both -- the per-layer views AND the composed one from one
+// sweep: one tile per layer in LDS, every item (one layer of a unit) merges its
+// window into its layer's tile, the epilogue writes L + 1 views.
+template <int NSETS, bool CELL, int MAXT, bool BOTH = false>
 __global__ __launch_bounds__(MAXT) void splat_stream2_kernel(S2Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -347,16 +353,17 @@ __global__ __launch_bounds__(MAXT) void splat_stream2_kernel(S2Args a) {
   const int WHS = ((WMAX / 2 + 15) & ~15) + 8;  // slots per window half
   const int WCELLS = 2 * WHS;
   float4* const rb_all = reinterpret_cast<float4*>(smem_raw);    // [NW][WCELLS]
-  float4* const tile4 = rb_all + NW * WCELLS;                     // [R][Wt]
-  Task* const task = reinterpret_cast<Task*>(tile4 + R * Wt);     // [cap]
+  const int NT = BOTH ? a.L : 1;                                  // tiles
+  float4* const tile4 = rb_all + NW * WCELLS;                     // [NT][R][Wt]
+  Task* const task = reinterpret_cast<Task*>(tile4 + NT * R * Wt);  // [cap]
   TaskX* const taskx = reinterpret_cast<TaskX*>(task + a.cap);    // [cap]
   int* const ctl = reinterpret_cast<int*>(taskx + a.cap);         // [4]: ticket
-  int* const locks = ctl + 4;                                     // [R]
+  int* const locks = ctl + 4;                                     // [NT * R]
   const int Q = a.qcap;
-  float4* const qv_all = reinterpret_cast<float4*>(ctl + ((4 + R + 3) & ~3));
+  float4* const qv_all = reinterpret_cast<float4*>(ctl + ((4 + NT * R + 3) & ~3));
   int* const qc_all = reinterpret_cast<int*>(qv_all + NW * Q);
   unsigned char* const sc_all = reinterpret_cast<unsigned char*>(qc_all + NW * Q);
-  int* const clk = reinterpret_cast<int*>(sc_all + ((NW * WMAX + 15) & ~15));  // CELL: [R*Wt]
+  int* const clk = reinterpret_cast<int*>(sc_all + ((NW * WMAX + 15) & ~15));  // CELL: [NT*R*Wt]
   const unsigned clk_addr = (unsigned)(uintptr_t)clk;
   float4* const rb = rb_all + wave * WCELLS;
   float4* const qv = qv_all + wave * Q;
@@ -426,10 +433,11 @@ __global__ __launch_bounds__(MAXT) void splat_stream2_kernel(S2Args a) {
   // ---- LDS init and the opening barrier: nothing here needs M ---------------
   {
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int i = tid; i < NW * WCELLS + rows * Wt; i += T) rb_all[i] = z4;  // windows + tile
-    if (tid < 4 + R) ctl[tid] = (tid == 0) ? NW : 0;  // tickets, arrivals, locks
+    const int ncl = BOTH ? NT * R * Wt : rows * Wt;
+    for (int i = tid; i < NW * WCELLS + ncl; i += T) rb_all[i] = z4;  // windows + tiles
+    for (int i = tid; i < 4 + NT * R; i += T) ctl[i] = (i == 0) ? NW : 0;  // tickets, arrivals, locks
     if (CELL)
-      for (int i = tid; i < rows * Wt; i += T) clk[i] = 0;
+      for (int i = tid; i < ncl; i += T) clk[i] = 0;
   }
   __syncthreads();
   float m[8];
@@ -654,6 +662,7 @@ __global__ __launch_bounds__(MAXT) void splat_stream2_kernel(S2Args a) {
   const float m3 = m[3];
   const float zA = a.zA, zB = a.zB, max_disp = a.max_disp;
   int slot = 0, t_row0 = 0, t_wlo = 0, t_wwin = 0, has_max = 0, rmax_row = 0;
+  int t_lay = 0;  // BOTH: first tile row of the item's layer (layer * R)
   int fast_ok = 0, fastA_ok = 0, win_ok = 0;
   unsigned wspan = 0u, wspanA = 0u;
   float tmin = 0.f, wy0 = 0.f, wy1 = 0.f, wymin = 0.f, wymax = 0.f, wlo_f = 0.f;
@@ -667,7 +676,8 @@ __global__ __launch_bounds__(MAXT) void splat_stream2_kernel(S2Args a) {
   auto flush = [&]() {
     s2_flush_queue<CELL>((unsigned)(uintptr_t)tile4, (unsigned)(uintptr_t)locks,
                          clk_addr, (unsigned)(uintptr_t)qv, (unsigned)(uintptr_t)qc,
-                         qn, lane, use_a ? t_row0 : -1, use_b ? t_row0 + 1 : -1);
+                         qn, lane, use_a ? t_lay + t_row0 : -1,
+                         use_b ? t_lay + t_row0 + 1 : -1);
     qn = 0;
   };
   auto push = [&](bool pred, int tcell, float4 val) {
@@ -704,7 +714,7 @@ __global__ __launch_bounds__(MAXT) void splat_stream2_kernel(S2Args a) {
       const int r = t_row0 + (k >> 1);
       const float c = ((k & 1) ? wx[1] : wx[0]) * ((k >> 1) ? wy[1] : wy[0]);
       const bool ok = pred && (c > 1.0e-3f) && r >= 0 && r < rows;
-      push(ok, r * Wt + ((k & 1) ? cx[1] : cx[0]),
+      push(ok, (t_lay + r) * Wt + ((k & 1) ? cx[1] : cx[0]),
            make_float4(V.x * c, V.y * c, V.z * c, V.w * c));
     }
   };
@@ -713,6 +723,7 @@ __global__ __launch_bounds__(MAXT) void splat_stream2_kernel(S2Args a) {
     const bool live = tg_ >= 0;
     if (live && (tg_ & (1 << 20))) {  // ---- the item starts a task ----------
       slot = tg_ & 0xfffff;
+      t_lay = BOTH ? s2_unit_of(a, bo, chunk0 + slot).l0 * R : 0;
       const Task ta = task[slot];
       const TaskX tx = taskx[slot];
       t_row0 = S2_RFL(ta.row0);
@@ -813,7 +824,7 @@ __global__ __launch_bounds__(MAXT) void splat_stream2_kernel(S2Args a) {
               const float kq = (c0 ? w0 : w1) * wymax;
               const int cellq = t_wlo + cl0 + dl[i] + (c0 ? 0 : 1);
               push((c0 || c1) && kq > 1.0e-3f && (unsigned)cellq < (unsigned)Wt,
-                   rmax_row * Wt + cellq,
+                   (t_lay + rmax_row) * Wt + cellq,
                    make_float4(V.x * kq, V.y * kq, V.z * kq, V.w * kq));
             }
             if (c0) w0 = 0.0f;
@@ -897,7 +908,7 @@ __global__ __launch_bounds__(MAXT) void splat_stream2_kernel(S2Args a) {
                 const float kq = (c0 ? w0 : w1) * wymax;
                 const int cellq = t_wlo + clv[i] + (c0 ? 0 : 1);
                 push((c0 || c1) && kq > 1.0e-3f && (unsigned)cellq < (unsigned)Wt,
-                     rmax_row * Wt + cellq,
+                     (t_lay + rmax_row) * Wt + cellq,
                      make_float4(V.x * kq, V.y * kq, V.z * kq, V.w * kq));
               }
               if (c0) w0 = 0.0f;
@@ -956,7 +967,7 @@ __global__ __launch_bounds__(MAXT) void splat_stream2_kernel(S2Args a) {
           const bool c1 = !(w1 * wymin > 1.0e-3f);
           if (has_max) {
             const float k0 = w0 * wymax, k1 = w1 * wymax;
-            const int cm = rmax_row * Wt + t_wlo + cl;
+            const int cm = (t_lay + rmax_row) * Wt + t_wlo + cl;
             push(inw && c0 && k0 > 1.0e-3f &&
                      (unsigned)(t_wlo + cl) < (unsigned)Wt, cm,
                  make_float4(V.x * k0, V.y * k0, V.z * k0, V.w * k0));
@@ -998,23 +1009,23 @@ __global__ __launch_bounds__(MAXT) void splat_stream2_kernel(S2Args a) {
         }
       }
 #endif
-      if (tg_ & (1 << 21)) {
-        // ---- last layer done: window -> the task's two tile rows ------------
+      if (BOTH || (tg_ & (1 << 21))) {
+        // ---- last layer done (BOTH: every layer): window -> two tile rows -----
 #ifndef S2X_NOLOCK
         if (!CELL) {  // ascending order: no deadlock
-          if (use_a) s2_lock_row(locks, t_row0, lane);
-          if (use_b) s2_lock_row(locks, t_row0 + 1, lane);
+          if (use_a) s2_lock_row(locks, t_lay + t_row0, lane);
+          if (use_b) s2_lock_row(locks, t_lay + t_row0 + 1, lane);
         }
 #endif
         if (qn != 0) {
           s2_apply_queue<CELL>(tile4, clk_addr, qv, qc, qn, lane);
           qn = 0;
         }
-        float4* const trow = tile4 + (long)t_row0 * Wt + t_wlo + lane;
+        float4* const trow = tile4 + (long)(t_lay + t_row0) * Wt + t_wlo + lane;
         float4* const wrow = rb + mslot;
         const int c_in = t_wlo + lane;
         if (CELL) {
-          const unsigned lrow = clk_addr + (unsigned)(t_row0 * Wt + t_wlo + lane) * 4u;
+          const unsigned lrow = clk_addr + (unsigned)((t_lay + t_row0) * Wt + t_wlo + lane) * 4u;
           for (int c = 0; c + lane < t_wwin; c += 64) {
             float4* wc = wrow + (c >> 1);
             const float4 v = *wc;
@@ -1062,11 +1073,12 @@ __global__ __launch_bounds__(MAXT) void splat_stream2_kernel(S2Args a) {
 #endif
           }
 #ifndef S2X_NOLOCK
-          if (use_b) s2_unlock_row(locks, t_row0 + 1, lane);
-          if (use_a) s2_unlock_row(locks, t_row0, lane);
+          if (use_b) s2_unlock_row(locks, t_lay + t_row0 + 1, lane);
+          if (use_a) s2_unlock_row(locks, t_lay + t_row0, lane);
 #endif
         }
       }
+      if (BOTH) t_lay += R;  // the unit's next item is its next layer
     }
     return next_tag;
   };
@@ -1095,7 +1107,33 @@ __global__ __launch_bounds__(MAXT) void splat_stream2_kernel(S2Args a) {
   S2_STAMP(5);
 
   // ---- epilogue: (tile + background) normalised, each output written once --
-  {
+  if (BOTH) {
+    // per layer (ldi.py:157-163, 176-177) and composed (:167-174): the sum of
+    // the layers' canvases, each with its own background
+    const float bg = a.bg;
+    const size_t P = (size_t)Ht * Wt;
+    const size_t o0 = (size_t)b * P + (size_t)row0 * Wt;
+    const int ncell = rows * Wt;
+    for (int i = tid; i < ncell; i += T) {
+      float4 C = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int l = 0; l < a.L; ++l) {
+        const float4 A = tile4[(size_t)l * R * Wt + i];
+        const float Wsum = A.w + bg;
+        const float rw = __builtin_amdgcn_rcpf(safe_den(Wsum));
+        const size_t o = (size_t)l * a.B * P + o0 + i;
+        a.out_img[3 * o + 0] = (A.x + bg) * rw;
+        a.out_img[3 * o + 1] = (A.y + bg) * rw;
+        a.out_img[3 * o + 2] = (A.z + bg) * rw;
+        a.out_wts[o] = Wsum;
+        C.x += A.x + bg; C.y += A.y + bg; C.z += A.z + bg; C.w += Wsum;
+      }
+      const float rw = __builtin_amdgcn_rcpf(safe_den(C.w));
+      a.out_img_c[3 * (o0 + i) + 0] = C.x * rw;
+      a.out_img_c[3 * (o0 + i) + 1] = C.y * rw;
+      a.out_img_c[3 * (o0 + i) + 2] = C.z * rw;
+      a.out_wts_c[o0 + i] = C.w;
+    }
+  } else {
     const float lbg = a.lbg;
     const size_t P = (size_t)Ht * Wt;
     float* const oi = a.out_img + ((size_t)b * P + (size_t)row0 * Wt) * 3;
@@ -1114,12 +1152,13 @@ __global__ __launch_bounds__(MAXT) void splat_stream2_kernel(S2Args a) {
   S2_STAMP(6);
 }
 
-size_t s2_lds_bytes(int R, int Wt, int nw, int wmax, int cap, int qcap, int cell) {
+size_t s2_lds_bytes(int R, int Wt, int nw, int wmax, int cap, int qcap, int cell,
+                    int nt = 1) {
   const int whs = ((wmax / 2 + 15) & ~15) + 8;
-  return (size_t)nw * 2 * whs * 16 + (size_t)R * Wt * 16 +
+  return (size_t)nw * 2 * whs * 16 + (size_t)nt * R * Wt * 16 +
          (size_t)cap * (sizeof(Task) + sizeof(TaskX)) +
-         (size_t)((4 + R + 3) & ~3) * 4 + (size_t)nw * qcap * 20 +
-         (size_t)((nw * wmax + 15) & ~15) + (cell ? (size_t)R * Wt * 4 : 0) + 16;
+         (size_t)((4 + nt * R + 3) & ~3) * 4 + (size_t)nw * qcap * 20 +
+         (size_t)((nw * wmax + 15) & ~15) + (cell ? (size_t)nt * R * Wt * 4 : 0) + 16;
 }
 
 struct S2Plan { int R, nw, cell, cap, qcap, ilv, nsplit, lsub; size_t lds; double est; };
@@ -1132,7 +1171,8 @@ struct S2Plan { int R, nw, cell, cap, qcap, ilv, nsplit, lsub; size_t lds; doubl
 // apart) and whole rounds of workgroups: so one workgroup per CU (the LDS tile
 // allows only one) in ONE round, as many waves as fit, the tallest band that
 // still gives every CU a workgroup.
-int s2_plan(const LsiSplatDesc* d, int wmax, int maxnw, S2Plan* out) {
+int s2_plan(const LsiSplatDesc* d, int wmax, int maxnw, bool both, S2Plan* out) {
+  const int nt = both ? d->L : 1;
   const int nseg = d->W / SEG;
   static const char* cap_env = getenv("LSI_STREAM_LDS_CAP");
   const size_t lds_cap = cap_env ? (size_t)atol(cap_env) : 160 * 1024;
@@ -1149,7 +1189,9 @@ int s2_plan(const LsiSplatDesc* d, int wmax, int maxnw, S2Plan* out) {
     const int ilv = srows >= 15 ? 1 : 0;
     const int nrow = ilv ? (srows + 4) / 5 * 5 : srows;
     const int nunit = nrow * nseg;
-    int cell = (R <= 8 && nunit <= 40) ? 1 : 0;
+    // (both outputs: every item merges, and a merge under cell locks costs more
+    // LDS operations than one under two row locks: 204 vs 184 us at config 3)
+    int cell = (R <= 8 && nunit <= 40 && !both) ? 1 : 0;
     if (force_cell == 1) cell = 0;
     if (force_cell == 2) cell = 1;
     for (int c = maxnw; c >= 2; --c) {
@@ -1166,6 +1208,7 @@ int s2_plan(const LsiSplatDesc* d, int wmax, int maxnw, S2Plan* out) {
       if (sub_override) lsub = sub_override < d->L ? sub_override : d->L;
       if (ls_env) lsub = atoi(ls_env);
       if (lsub < 1) lsub = 1;
+      if (both) lsub = d->L;  // (a unit's items merge one by one anyway)
       int nsplit = lsub < d->L ? nunit : 0;
       if (ns_env) nsplit = atoi(ns_env);
       if (nsplit > nunit) nsplit = nunit;
@@ -1173,9 +1216,9 @@ int s2_plan(const LsiSplatDesc* d, int wmax, int maxnw, S2Plan* out) {
       if (d->tune_threads <= 0 && c > tickets && c > 2) continue;
       const int cap = (tickets + 15) / 16 * 16;
       int q = 64;
-      while (q >= 16 && s2_lds_bytes(R, d->Wt, c, wmax, cap, q, cell) > lds_cap) q /= 2;
+      while (q >= 16 && s2_lds_bytes(R, d->Wt, c, wmax, cap, q, cell, nt) > lds_cap) q /= 2;
       if (q < 16) continue;
-      const size_t lds = s2_lds_bytes(R, d->Wt, c, wmax, cap, q, cell);
+      const size_t lds = s2_lds_bytes(R, d->Wt, c, wmax, cap, q, cell, nt);
       long k = (long)(160 * 1024 / lds);          // co-resident workgroups per CU
       if (k > maxnw / c) k = maxnw / c;
       if (k < 1) k = 1;
@@ -1227,10 +1270,11 @@ bool lsi_stream2_applies(const SplatArgs& a, bool simple, int layout) {
   if (d->reserved & 0x40000000) return false;  // tests: force the general kernel
   if (((d->reserved >> 16) & 3) == 2) return false;  // exchange bands asked for
   if (!simple || layout != 0) return false;
+  const bool both = a.out_img_c != nullptr;  // lsi_splat_fwd_both: per-layer + composed
   if ((d->flags & (LSI_COMPOSE | LSI_HAS_MASK | LSI_WANT_DISP | LSI_DETERMINISTIC)) !=
-      LSI_COMPOSE)
+      (both ? 0u : (unsigned)LSI_COMPOSE))
     return false;
-  if (a.out_img_c != nullptr) return false;
+  if (both && (d->L > 15 || !a.out_wts_c)) return false;
   if (d->W % SEG != 0 || d->H > 65535 || d->W / SEG > 32767) return false;
   if (d->tex_sx != 3 || d->tex_sc != 1 || d->disp_sx != 1) return false;
   return true;
@@ -1239,10 +1283,12 @@ bool lsi_stream2_applies(const SplatArgs& a, bool simple, int layout) {
 int lsi_stream2_launch(const SplatArgs& a, int wmax, hipStream_t stream) {
   const LsiSplatDesc* d = &a.d;
   S2Plan plan;
-  if (s2_plan(d, wmax, LSI_S2_MAXT / 64, &plan) != LSI_OK) return LSI_EINVAL;
+  const bool both = a.out_img_c != nullptr;
+  if (s2_plan(d, wmax, LSI_S2_MAXT / 64, both, &plan) != LSI_OK) return LSI_EINVAL;
   S2Args k;
   k.tex = a.tex; k.disp = a.disp; k.M = a.M;
   k.out_img = a.out_img; k.out_wts = a.out_wts;
+  k.out_img_c = a.out_img_c; k.out_wts_c = a.out_wts_c;
   k.B = d->B; k.H = d->H; k.Ht = d->Ht; k.Wt = d->Wt; k.L = d->L;
   k.nseg = d->W / SEG;
   k.tex_sl = (int)d->tex_sl; k.tex_sb = (int)d->tex_sb; k.tex_sy = (int)d->tex_sy;
@@ -1253,6 +1299,7 @@ int lsi_stream2_launch(const SplatArgs& a, int wmax, hipStream_t stream) {
   k.zA = (float)((double)d->zbuf_scale * l2e / (double)d->max_disp);
   k.zB = (float)(-0.5 * (double)d->zbuf_scale * l2e);
   k.lbg = (float)d->L * d->bg_wt;
+  k.bg = d->bg_wt;
   k.R = plan.R; k.wmax = wmax; k.qcap = plan.qcap; k.cap = plan.cap;
   k.ilv = plan.ilv;
   k.nsplit = plan.nsplit;
@@ -1266,9 +1313,15 @@ int lsi_stream2_launch(const SplatArgs& a, int wmax, hipStream_t stream) {
       a.ws_bytes >= (size_t)nbands * d->B * 16 * 8 * 8)
     k.stamps = reinterpret_cast<long long*>(a.canvas);
 #endif
-  const void* fn = plan.cell
-      ? (const void*)splat_stream2_kernel<LSI_S2_NSETS, true, LSI_S2_MAXT>
-      : (const void*)splat_stream2_kernel<LSI_S2_NSETS, false, LSI_S2_MAXT>;
+  const void* fn;
+  if (both)
+    fn = plan.cell
+        ? (const void*)splat_stream2_kernel<LSI_S2_NSETS, true, LSI_S2_MAXT, true>
+        : (const void*)splat_stream2_kernel<LSI_S2_NSETS, false, LSI_S2_MAXT, true>;
+  else
+    fn = plan.cell
+        ? (const void*)splat_stream2_kernel<LSI_S2_NSETS, true, LSI_S2_MAXT>
+        : (const void*)splat_stream2_kernel<LSI_S2_NSETS, false, LSI_S2_MAXT>;
   if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)plan.lds) != hipSuccess)
     return LSI_ELAUNCH;

@@ -220,7 +220,9 @@ class _ForwardSplatBoth(torch.autograd.Function):
     bg_wt = _C.bg_weight(cfg['bg_layer_disp'], cfg['max_disp'],
                          cfg['zbuf_scale'])
     desc = _desc(tex, mask, disp, ht, wt, float(s), float(cfg['max_disp']),
-                 float(cfg['zbuf_scale']), bg_wt, flags, 0)
+                 float(cfg['zbuf_scale']), bg_wt, flags, 0,
+                 cfg.get('band_rows', 0), cfg.get('threads', 0))
+    desc.reserved = int(cfg.get('experiment', 0))
     select_path(desc, mat_host, cfg.get('path', 'auto'))
     img = torch.empty((nl, b, ht, wt, 3), dtype=torch.float32, device=dev)
     wts = torch.empty((nl, b, ht, wt, 1), dtype=torch.float32, device=dev)
@@ -282,7 +284,8 @@ class _ForwardSplatBoth(torch.autograd.Function):
 
 def forward_splat_both(ldi_src, src2trg_mat, trg_downsampling=1,
                        bg_layer_disp=0, max_disp=1, zbuf_scale=10,
-                       mat_host=None, path='auto', deterministic=False):
+                       mat_host=None, path='auto', deterministic=False,
+                       band_rows=0, threads=0, experiment=0):
   """The two renderings the reference's training step makes of every LDI --
   per layer (compose_layers=False) and composed (compose_layers=True),
   reference ldi_enc_dec.py:302-334 -- from ONE sweep over the source pixels
@@ -296,7 +299,8 @@ def forward_splat_both(ldi_src, src2trg_mat, trg_downsampling=1,
   mat = src2trg_mat.detach().to(tex.device, torch.float32)
   cfg = dict(trg_downsampling=trg_downsampling, bg_layer_disp=bg_layer_disp,
              max_disp=max_disp, zbuf_scale=zbuf_scale, path=path,
-             deterministic=bool(deterministic))
+             deterministic=bool(deterministic), band_rows=band_rows,
+             threads=threads, experiment=experiment)
   return _ForwardSplatBoth.apply(tex, mask, disp, mat, mat_host, cfg)
 
 

@@ -613,6 +613,46 @@ def test_stream_compact_instance_routes(kind, shape, dev, ref_cpu):
     np.testing.assert_allclose(wts.cpu().numpy(), want['wts'], rtol=WTS_RTOL)
 
 
+@pytest.mark.parametrize('kind', ['smooth', 'iid', 'outside', 'clampy'])
+@pytest.mark.parametrize('shape', [(2, 2, 64, 256), (4, 1, 24, 768), (3, 1, 130, 256)])
+def test_stream_compact_instance_both_outputs(kind, shape, dev, ref_cpu):
+  """lsi_splat_fwd_both on the compact STREAM instance (one tile per layer in
+  LDS, every item merged into its layer's tile, L + 1 views written by the
+  epilogue): per-layer and composed views against the C oracle and against the
+  general stream kernel, several band heights, both merge exclusions."""
+  from lsi.geometry import ldi
+  nl, b, h, w = shape
+  rs = np.random.RandomState(nl * 100 + w + h)
+  tex, disp, mat = _stream_case(rs, nl, b, h, w, kind if kind != 'clampy' else 'smooth')
+  if kind == 'clampy':
+    m03 = float(mat[0, 0, 3])
+    xx = np.arange(w, dtype=np.float32)
+    frac = rs.choice(np.array([0.004, 0.0040001, 0.0039999, 0.001333, 0.0013334,
+                               0.996, 0.5], np.float32), size=(nl, b, h, w))
+    want_x = np.floor(xx / 2)[None, None, None, :] + frac - 3.0
+    disp = np.clip((((want_x + 0.5) * 2.0 - xx - 0.5) / m03)[..., None], 1e-4,
+                   0.5).astype(np.float32)
+  want_i = ref_cpu.forward_splat(tex, None, disp, mat, 0.5, 1e-3, 0.4, 50, False)
+  want_c = ref_cpu.forward_splat(tex, None, disp, mat, 0.5, 1e-3, 0.4, 50, True)
+  ldi_src = [torch.tensor(tex, device=dev), None, torch.tensor(disp, device=dev)]
+
+  def run(**kw):
+    return ldi.forward_splat_both(ldi_src, torch.tensor(mat), trg_downsampling=0.5,
+                                  bg_layer_disp=1e-3, max_disp=0.4, zbuf_scale=50,
+                                  path='stream', **kw)
+
+  gen = run(experiment=GENERAL_STREAM)
+  for rows in (0, 1, 2, 4):
+    for locks in (1, 2):
+      img, wts, img_c, wts_c = run(band_rows=rows, experiment=locks << 18)
+      np.testing.assert_allclose(img.cpu().numpy(), want_i['img'], rtol=0, atol=IMG_ATOL)
+      np.testing.assert_allclose(wts.cpu().numpy(), want_i['wts'], rtol=WTS_RTOL)
+      np.testing.assert_allclose(img_c.cpu().numpy(), want_c['img'], rtol=0, atol=IMG_ATOL)
+      np.testing.assert_allclose(wts_c.cpu().numpy(), want_c['wts'], rtol=WTS_RTOL)
+      assert float((img - gen[0]).abs().max()) <= IMG_ATOL
+      assert float((img_c - gen[2]).abs().max()) <= IMG_ATOL
+
+
 def test_stream_compact_instance_queue_overflow(dev, ref_cpu):
   """Every pixel outside its task's window (disparities far beyond max_disp):
   all corners go through the per-wave queue, which overflows many times per

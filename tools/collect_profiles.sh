@@ -8,7 +8,7 @@
 #    combined with other trace domains) of the stream and sweep kernels.
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 timeout 900 python $R/bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
@@ -30,9 +30,13 @@ for tag, d in (('default_cfg3', 'kt'), ('cfg4', 'kt4')):
 json.dump(out, open("$OUT/rocprof_summary.json", "w"), indent=1)
 print(json.dumps(out, indent=1)[:2500])
 PY
-bash $R/tools/pmc_quick.sh splat_stream_kernel --workload cfg3 > $OUT/pmc_sq_stream_cfg3.txt 2>&1
+bash $R/tools/pmc_quick.sh splat_stream2_kernel --workload cfg3 > $OUT/pmc_sq_stream_cfg3.txt 2>&1
+bash $R/tools/pmc_quick.sh splat_stream2_kernel --workload cfg3 --shard-of 8 > $OUT/pmc_sq_stream_cfg3_shard_of_8.txt 2>&1
 bash $R/tools/pmc_quick.sh splat_sweep_kernel --workload cfg4 > $OUT/pmc_sq_sweep_cfg4.txt 2>&1
-cat $OUT/pmc_sq_stream_cfg3.txt $OUT/pmc_sq_sweep_cfg4.txt
+cat $OUT/pmc_sq_stream_cfg3.txt $OUT/pmc_sq_stream_cfg3_shard_of_8.txt $OUT/pmc_sq_sweep_cfg4.txt
+for d in rough stress; do timeout 200 python $R/bench.py --disp $d --no-cpu-baseline --no-extra --traffic off > $OUT/bench_cfg3_$d.json 2>> $OUT/bench_default.err; done
+LSI_HIP_LIB=stamps python $R/tools/phase_probe2.py cfg3 > $OUT/timeline_cfg3.txt 2>&1
+LSI_HIP_LIB=stamps python $R/tools/phase_probe2.py cfg3 0 0 8 > $OUT/timeline_cfg3_shard_of_8.txt 2>&1
 rm -rf $OUT/kt/*/ $OUT/kt4/*/ 2>/dev/null
 find $OUT -name "*.csv" -size +2M -delete
 cat $OUT/bench_default.json
