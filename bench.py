@@ -9,14 +9,17 @@ tensors that are already resident in HBM.  Prints ONE JSON line (rank 0).
 
 Workloads (BASELINE.json `configs`):
   cfg3  KITTI, 4-layer, 256x768, batch 32 -- the configuration north_star's
-        target is quoted on; default.  One GPU renders the whole batch; N > 1
-        ranks split it (32/N views per GPU: strong scaling).
-  cfg2  KITTI stereo, 2-layer, 256x768, batch 4 per GPU (weak scaling)
-  cfg4  synthetic 3-layer 256x256, batch 64 total, general poses (strong)
-  cfg5  KITTI 4-layer 512x1536, batch 8 total (strong)
-Multi-GPU: the batch shards along B with NO data-path collective (replicas of
-an embarrassingly parallel renderer); RCCL is used only for the barrier and
-the max-over-ranks of the elapsed time.  `python bench.py --gpus N` from a bare
+        target is quoted on; default
+  cfg2  KITTI stereo, 2-layer, 256x768, batch 4
+  cfg4  synthetic 3-layer 256x256, batch 64, general poses
+  cfg5  KITTI 4-layer 512x1536, batch 8
+Multi-GPU: independent LDIs, NO data-path collective (replicas of an
+embarrassingly parallel renderer); RCCL is used only for the barrier and the
+max-over-ranks of the elapsed time.  Default `--scaling weak`: every rank
+renders the workload's whole batch -- the per-GPU minibatch of a data-parallel
+training run, per-GPU work fixed as N grows.  `--scaling strong` splits the
+batch B/N over the ranks instead (cfg2 is per GPU either way); `--shard-of N`
+times one such shard on a single GPU.  `python bench.py --gpus N` from a bare
 shell re-launches itself under torch.distributed.run (one rank per GPU).
 
 Inputs smaller than the 256 MiB Infinity Cache would be served from it when one
@@ -171,11 +174,14 @@ class Renderer(object):
       _C.check(rc, 'lsi_splat_fwd')
 
 
-def shard_batch(workload, world):
+def shard_batch(workload, world, scaling='weak'):
   """Per-rank batch and scaling mode: independent LDIs shard along B with no
-  data-path collective."""
+  data-path collective.  'weak' (default): every rank renders
+  the workload's whole batch (data-parallel replicas, what a DDP training run
+  does with its per-GPU minibatch); 'strong': the workload's batch is split
+  B/N over the ranks."""
   nl, h, w, batch, per_gpu, cams, max_disp, bg = WORKLOADS[workload]
-  if per_gpu:
+  if per_gpu or scaling == 'weak':
     return batch, 'weak'
   if batch % world:
     raise SystemExit('batch %d does not split over %d ranks' % (batch, world))
@@ -515,6 +521,10 @@ def main():
                   help='LsiSplatDesc.reserved: planner experiments (bits 12+) work '
                   'with any build; the kernel timing hooks (bits 0-9) need '
                   'LSI_HIP_LIB=hooks (build.py --hooks)')
+  ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
+                  help='N > 1: weak = every rank renders the whole batch of the '
+                  'workload (per-GPU work fixed; default), strong = the batch is '
+                  'split B/N over the ranks')
   ap.add_argument('--shard-of', type=int, default=1,
                   help='N=1 only: time the per-rank shard of an N-rank run (what '
                   'one GPU of --gpus N renders); the JSON line is then about that '
@@ -548,7 +558,10 @@ def main():
       dist.init_process_group('nccl', rank=rank, world_size=world,
                               device_id=torch.device('cuda', local_rank))
   nl, h, w, batch, per_gpu, cams, max_disp, bg = WORKLOADS[args.workload]
-  b_local, scaling = shard_batch(args.workload, max(world, args.shard_of))
+  # (--shard-of N times what one GPU of a strong-scaling N-rank run renders)
+  b_local, scaling = shard_batch(
+      args.workload, max(world, args.shard_of),
+      'strong' if args.shard_of > 1 else args.scaling)
 
   if selftest:
     # the rank plumbing without a GPU: shard, barrier, max-over-ranks, one line
