@@ -16,7 +16,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, 'csrc')
 SO = os.path.join(PKG, 'liblsi_hip.so')
 SOURCES = ['lsi_splat.hip', 'lsi_splat_stream.hip', 'lsi_splat_stream2.hip',
-           'lsi_splat_tile.hip',
+           'lsi_splat_tile.hip', 'lsi_splat_bwd_stream.hip',
            'lsi_splat_sweep.hip',
            'lsi_sampling.hip', 'lsi_loss.hip', 'lsi_bn.hip']
 HEADERS = [os.path.join(CSRC, 'lsi_common.h'),

@@ -25,6 +25,10 @@ struct SplatArgs {
   float* out_wts_c;
 };
 
+// lsi_stream_ok's return value (kept in LsiSplatDesc.tune_window): window cells,
+// plus this bit when every batch element has M rows 2, 3 = (0,0,1,0), (0,0,0,1).
+constexpr int LSI_STREAM_SIMPLE_BIT = 1 << 20;
+
 // LSI_PATH_STREAM launcher and workspace need (lsi_splat_stream.hip).
 size_t lsi_stream_workspace_bytes(const LsiSplatDesc* d);
 int lsi_stream_launch(const SplatArgs& a, hipStream_t stream);
@@ -32,6 +36,24 @@ int lsi_stream_launch(const SplatArgs& a, hipStream_t stream);
 // unit normaliser, channels-last textures, rows of whole 256-pixel segments.
 bool lsi_stream2_applies(const SplatArgs& a, bool simple, int layout);
 int lsi_stream2_launch(const SplatArgs& a, int wmax, hipStream_t stream);
+
+// The streamed backward for rectified pairs (lsi_splat_bwd_stream.hip).  It
+// derives the gradient canvas from the forward's outputs and their incoming
+// gradients itself (no pre-pass): `ci` the per-layer (or the only) canvases,
+// `cc` lsi_splat_bwd_both's composed one; either may be NULL / have g_img NULL.
+struct LsiBwdCanvas {
+  const float* img;
+  const float* wts;
+  const float* g_img;
+  const float* g_wts;  // may be NULL
+};
+bool lsi_bwd_stream_applies(const LsiSplatDesc* d, const float* tex,
+                            const float* disp, const float* g_tex,
+                            const float* g_disp);
+int lsi_bwd_stream_launch(const LsiSplatDesc* d, const float* tex,
+                          const float* disp, const float* M,
+                          const LsiBwdCanvas* ci, const LsiBwdCanvas* cc,
+                          float* g_tex, float* g_disp, hipStream_t stream);
 
 // LSI_PATH_TILE launcher and workspace need (lsi_splat_tile.hip).
 size_t lsi_tile_workspace_bytes(const LsiSplatDesc* d);

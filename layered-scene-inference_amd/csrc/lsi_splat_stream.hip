@@ -85,9 +85,6 @@ constexpr int SEG = 256;   // source pixels per task (64 lanes x 4)
 #define LSI_STREAM_MAXT 768
 #endif
 constexpr int MAXNW = LSI_STREAM_MAXT / 64;
-// lsi_stream_ok's return value: window cells, plus this bit when every batch
-// element has normaliser == 1 and M row 3 == (0,0,0,1) (division-free kernel)
-constexpr int LSI_STREAM_SIMPLE_BIT = 1 << 20;
 
 // Per-task table entries, filled for a whole chunk of tasks at once (one task
 // per lane: by wave 0 in the prologue, by all threads for later chunks) so that

@@ -1047,3 +1047,103 @@ def test_both_outputs_at_config3_shard_size(dev, ref_cpu):
     np.testing.assert_allclose(img.cpu().numpy(), want['img'], rtol=0,
                                atol=IMG_ATOL)
     np.testing.assert_allclose(wts.cpu().numpy(), want['wts'], rtol=WTS_RTOL)
+
+
+def _rectified_case(seed, nl, b, h, w, row_scale=1.0, row_shift=0.0, x_shift=0.0,
+                    odd_values=False):
+  """Inputs the STREAM path accepts with the SIMPLE bit: M rows 2, 3 =
+  (0,0,1,0), (0,0,0,1), no x / disparity term in row 1."""
+  rs = np.random.RandomState(seed)
+  tex = rs.rand(nl, b, h, w, 3).astype(np.float32)
+  disp = rs.uniform(-0.03, 0.45, (nl, b, h, w, 1)).astype(np.float32)
+  dropped = np.zeros(disp.shape, bool)
+  if odd_values:
+    dropped = rs.rand(*disp.shape) < 0.02
+    disp[dropped] = np.where(rs.rand(int(dropped.sum())) < 0.5, np.nan, np.inf)
+  mats = []
+  for _ in range(b):
+    m = np.eye(4)
+    m[0, 0] = rs.uniform(0.9, 1.1); m[0, 1] = rs.normal(0, 0.02)
+    m[0, 2] = x_shift + rs.uniform(-2, 2); m[0, 3] = rs.uniform(-40, 40)
+    m[1, 1] = row_scale; m[1, 2] = row_shift + rs.uniform(-1.5, 1.5)
+    mats.append(m)
+  return tex, disp, dropped, np.stack(mats).astype(np.float32)
+
+
+@pytest.mark.parametrize('both', [False, True])
+@pytest.mark.parametrize('kind', ['plain', 'odd', 'zoom_in', 'flipped',
+                                  'leaving', 'rows8'])
+def test_streamed_backward_matches_autograd_and_the_gather_kernel(kind, both, dev,
+                                                                  monkeypatch):
+  """lsi_splat_bwd[_both] on rectified pairs runs the streamed kernel
+  (lsi_splat_bwd_stream.hip).  Checked against fp64 autograd of the reference's
+  op graph and against the one-thread-per-pixel gather kernel
+  (LSI_BWD_STREAM=0), for compose / per-layer / both outputs, NaN and Inf
+  disparities (zero gradient), a vertical zoom whose canvas rows do not fit the
+  LDS tile (global gathers), decreasing rows, and most of the image leaving
+  the target."""
+  import lsi_torch_ref as TR
+  from lsi.geometry import ldi
+  kw = dict(plain={}, odd=dict(odd_values=True),
+            zoom_in=dict(row_scale=9.0, row_shift=-40.0),
+            flipped=dict(row_scale=-1.0, row_shift=24.0),
+            leaving=dict(x_shift=-300.0), rows8={})[kind]
+  nl, b, h, w = 3, 2, 24, 256
+  tex, disp, dropped, mat = _rectified_case(40 + len(kind), nl, b, h, w, **kw)
+  if kind == 'rows8':
+    monkeypatch.setenv('LSI_BWD_STREAM_ROWS', '8')
+  s, bg, md, zb = 0.5, 1e-3, 0.4, 50.0
+  gen = torch.Generator().manual_seed(7)
+
+  def run(stream):
+    monkeypatch.setenv('LSI_BWD_STREAM', '1' if stream else '0')
+    t32 = [torch.tensor(x, device=dev, requires_grad=True) for x in (tex, disp)]
+    g = torch.Generator().manual_seed(7)
+    if both:
+      img, wts, img_c, wts_c = ldi.forward_splat_both(
+          [t32[0], None, t32[1]], torch.tensor(mat), trg_downsampling=s,
+          bg_layer_disp=bg, max_disp=md, zbuf_scale=zb)
+      outs = [img, wts, img_c, wts_c]
+    else:
+      outs = list(ldi.forward_splat_matrix(
+          [t32[0], None, t32[1]], torch.tensor(mat), compose_layers=(kind != 'odd'),
+          trg_downsampling=s, bg_layer_disp=bg, max_disp=md, zbuf_scale=zb))
+    loss = 0
+    coefs = []
+    for o in outs:
+      c = torch.rand(o.shape, generator=g, dtype=torch.float64)
+      coefs.append(c)
+      if o.shape[-1] == 3:
+        loss = loss + (o * c.float().to(dev)).sum()
+      else:
+        loss = loss + (torch.log(o) * (1e-3 * c).float().to(dev)).sum()
+    loss.backward()
+    return [t.grad.cpu().double().numpy() for t in t32], coefs
+
+  got, coefs = run(True)
+  old, _ = run(False)
+  for a, o, name in zip(got, old, ('tex', 'disp')):
+    assert np.isfinite(a).all(), name
+    scale = np.abs(o).max() + 1e-30
+    assert np.abs(a - o).max() <= 2e-5 * scale, (name, np.abs(a - o).max() / scale)
+  assert (got[1][dropped] == 0).all() and (got[0][dropped[..., 0]] == 0).all()
+
+  # fp64 autograd of the op graph (dropped pixels: masked out)
+  clean = np.where(dropped, 0.0, disp)
+  kill = torch.tensor(np.where(dropped, 0.0, 1.0))
+  t64 = [torch.tensor(x, dtype=torch.float64, requires_grad=True)
+         for x in (tex, clean)]
+  m64 = torch.tensor(mat, dtype=torch.float64)
+  loss = 0
+  modes = [False, True] if both else [kind != 'odd']
+  k = 0
+  for compose in modes:
+    img, wts, _ = TR.forward_splat(t64[0], kill, t64[1], m64, s, bg, md, zb, compose)
+    loss = loss + (img * coefs[k]).sum() + (torch.log(wts) * 1e-3 * coefs[k + 1]).sum()
+    k += 2
+  loss.backward()
+  for a, b_, name in zip(got, t64, ('tex', 'disp')):
+    want = b_.grad.numpy()
+    scale = np.abs(want).max() + 1e-30
+    bad = np.abs(a - want) > 2e-4 * scale + 1e-3 * np.abs(want)
+    assert bad.mean() < 0.005, (name, bad.mean(), np.abs(a - want).max() / scale)
