@@ -53,6 +53,15 @@ extern "C" {
                              /* fixed order (slower); TILE is always          */
                              /* reproducible, ATOMIC / ROWBAND never are      */
 
+#define LSI_PACKED_RGBD 32u  /* the caller asserts: tex and disp are views of   */
+                             /* ONE buffer of RGBD pixels -- disp == tex + 3   */
+                             /* floats, tex_sc == 1, tex_sx == disp_sx == 4,   */
+                             /* equal layer / batch / row strides, 16-byte     */
+                             /* aligned (what a channels-last conv head with   */
+                             /* 4 outputs writes).  One 16-byte load then      */
+                             /* fetches a pixel's colour and disparity.  The   */
+                             /* entry points verify it (LSI_EINVAL if not).    */
+
 /* LsiSplatDesc.path: which kernel family renders the splat.                  */
 #define LSI_PATH_AUTO 0      /* library decides from the descriptor          */
 #define LSI_PATH_ATOMIC 1    /* source-parallel, global fp32 atomics; any M   */

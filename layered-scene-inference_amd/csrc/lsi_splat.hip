@@ -637,6 +637,16 @@ int check_desc(const LsiSplatDesc* d) {
   return LSI_OK;
 }
 
+// LSI_PACKED_RGBD is the caller's statement about its pointers: verified here
+bool packed_ok(const LsiSplatDesc* d, const float* tex, const float* disp) {
+  if (!(d->flags & LSI_PACKED_RGBD)) return true;
+  return disp == tex + 3 && d->tex_sc == 1 && d->tex_sx == 4 && d->disp_sx == 4 &&
+         d->tex_sl == d->disp_sl && d->tex_sb == d->disp_sb &&
+         d->tex_sy == d->disp_sy && d->tex_sl % 4 == 0 && d->tex_sb % 4 == 0 &&
+         d->tex_sy % 4 == 0 && (reinterpret_cast<uintptr_t>(tex) & 15) == 0 &&
+         !(d->flags & LSI_HAS_MASK);
+}
+
 int canvas_channels(const LsiSplatDesc* d) {
   return (d->flags & LSI_WANT_DISP) ? 5 : 4;
 }
@@ -714,6 +724,7 @@ int lsi_splat_fwd(const LsiSplatDesc* d, const float* tex, const float* disp,
   int rc = check_desc(d);
   if (rc != LSI_OK) return rc;
   if (!tex || !disp || !M || !out_img || !out_wts) return LSI_ENULL;
+  if (!packed_ok(d, tex, disp)) return LSI_EINVAL;
   if ((d->flags & LSI_WANT_DISP) && !out_disp) return LSI_ENULL;
   if ((d->flags & LSI_HAS_MASK) && !mask) return LSI_ENULL;
   hipStream_t stream = (hipStream_t)stream_;
@@ -815,6 +826,7 @@ int lsi_splat_bwd(const LsiSplatDesc* d, const float* tex, const float* disp,
       !g_disp_in || !workspace)
     return LSI_ENULL;
   if ((d->flags & LSI_HAS_MASK) && !mask) return LSI_ENULL;
+  if (!packed_ok(d, tex, disp)) return LSI_EINVAL;
   if (workspace_bytes < lsi_splat_bwd_workspace_bytes(d)) return LSI_EWORKSPACE;
   hipStream_t stream = (hipStream_t)stream_;
   // rectified pairs rendered by STREAM: the streamed gather (16-byte loads and
@@ -851,6 +863,7 @@ int lsi_splat_fwd_both(const LsiSplatDesc* d, const float* tex,
   if (rc != LSI_OK) return rc;
   if (d->flags & (LSI_COMPOSE | LSI_WANT_DISP)) return LSI_EINVAL;
   if (!out_img_c || !out_wts_c || !out_img || !out_wts) return LSI_ENULL;
+  if (tex && disp && !packed_ok(d, tex, disp)) return LSI_EINVAL;
   hipStream_t stream = (hipStream_t)stream_;
   if (d->path == LSI_PATH_STREAM) {
     // one sweep: every layer's tile is written out and added to a second tile
@@ -888,6 +901,7 @@ int lsi_splat_bwd_both(const LsiSplatDesc* d, const float* tex,
   if (rc != LSI_OK) return rc;
   if (d->flags & LSI_COMPOSE) return LSI_EINVAL;
   if (!tex || !disp || !M || !g_tex || !g_disp_in || !workspace) return LSI_ENULL;
+  if (!packed_ok(d, tex, disp)) return LSI_EINVAL;
   if (g_img && (!out_img || !out_wts)) return LSI_ENULL;
   if (g_img_c && (!out_img_c || !out_wts_c)) return LSI_ENULL;
   if ((d->flags & LSI_HAS_MASK) && !mask) return LSI_ENULL;

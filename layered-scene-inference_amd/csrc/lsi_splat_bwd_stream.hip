@@ -131,12 +131,29 @@ __device__ __forceinline__ void bs_cell4(const BSCanvas& c, size_t o, float4 (&g
   }
 }
 
+// One item's inputs: 4 disparities + 4 x rgb, or (PACK) 4 RGBD pixels, in which
+// case d4, t0, t1, t2 hold the lane's pixels 0 .. 3 as (r, g, b, d).
+template <bool PACK>
+__device__ __forceinline__ void bs_load(BSIn& o, const float* pd, const float* pt) {
+  if (PACK) {
+    o.d4 = *reinterpret_cast<const float4*>(pt);
+    o.t0 = *reinterpret_cast<const float4*>(pt + 4);
+    o.t1 = *reinterpret_cast<const float4*>(pt + 8);
+    o.t2 = *reinterpret_cast<const float4*>(pt + 12);
+  } else {
+    o.d4 = *reinterpret_cast<const float4*>(pd);
+    o.t0 = *reinterpret_cast<const float4*>(pt);
+    o.t1 = *reinterpret_cast<const float4*>(pt + 4);
+    o.t2 = *reinterpret_cast<const float4*>(pt + 8);
+  }
+}
+
 typedef float __attribute__((ext_vector_type(4))) bs_f4v;
 typedef const __attribute__((address_space(3))) bs_f4v bs_lds_f4;
 
 // The wave's items, two register sets of loads in flight.  IN_LDS: the band's
 // canvas rows glo .. are in the LDS tile `gt`; else gathered from Gb.
-template <bool IN_LDS>
+template <bool IN_LDS, bool PACK>
 __device__ __forceinline__ void bs_run(const BSArgs& a, const float (&m)[8],
                                        BSIn (&set)[2], const float4* gt,
                                        size_t obi, size_t obc, int b,
@@ -147,7 +164,7 @@ __device__ __forceinline__ void bs_run(const BSArgs& a, const float (&m)[8],
   const float xmax = (float)Wt - 1.0f, ymax = (float)a.Ht - 1.0f;
   const float inv_md = div_rn(1.0f, a.max_disp);
   const float zs_md = a.zscale * inv_md;
-  const float* const g_tex_in = a.tex + (long)b * a.tex_sb + (long)l_lo * a.tex_sl + 12 * lane;
+  const float* const g_tex_in = a.tex + (long)b * a.tex_sb + (long)l_lo * a.tex_sl + (PACK ? 16 : 12) * lane;
   const float* const g_disp_in = a.disp + (long)b * a.disp_sb + (long)l_lo * a.disp_sl + 4 * lane;
   float* const o_tex = a.g_tex + ((size_t)l_lo * a.B + b) * ((size_t)a.H * a.W) * 3 + 12 * lane;
   float* const o_disp = a.g_disp + ((size_t)l_lo * a.B + b) * ((size_t)a.H * a.W) + 4 * lane;
@@ -164,12 +181,8 @@ __device__ __forceinline__ void bs_run(const BSArgs& a, const float (&m)[8],
   };
   auto load_item = [&](BSIn& o, const Pos& p, bool live) {
     const Pos q = live ? p : Pos{0, 0, 0};  // past the end: a harmless re-read
-    const float* pd = g_disp_in + (long)q.l * a.disp_sl + (long)(ys + q.r) * a.disp_sy + q.sg * BS_SEG;
-    const float* pt = g_tex_in + (long)q.l * a.tex_sl + (long)(ys + q.r) * a.tex_sy + 3 * q.sg * BS_SEG;
-    o.d4 = *reinterpret_cast<const float4*>(pd);
-    o.t0 = *reinterpret_cast<const float4*>(pt);
-    o.t1 = *reinterpret_cast<const float4*>(pt + 4);
-    o.t2 = *reinterpret_cast<const float4*>(pt + 8);
+    bs_load<PACK>(o, g_disp_in + (long)q.l * a.disp_sl + (long)(ys + q.r) * a.disp_sy + q.sg * BS_SEG,
+                  g_tex_in + (long)q.l * a.tex_sl + (long)(ys + q.r) * a.tex_sy + (PACK ? 4 : 3) * q.sg * BS_SEG);
   };
   auto item = [&](const BSIn& in, const Pos& p) {
     const int y = ys + p.r, sg = p.sg, l = p.l;
@@ -180,9 +193,14 @@ __device__ __forceinline__ void bs_run(const BSArgs& a, const float (&m)[8],
     const bool yok = finite_f(Y);
     const int r0 = yok ? (int)ay.c0s : glo, r1 = yok ? (int)ay.c1s : glo;
     const float pym01 = py * m[1];
-    const float dv[4] = {in.d4.x, in.d4.y, in.d4.z, in.d4.w};
-    const float tx[12] = {in.t0.x, in.t0.y, in.t0.z, in.t0.w, in.t1.x, in.t1.y,
-                          in.t1.z, in.t1.w, in.t2.x, in.t2.y, in.t2.z, in.t2.w};
+    const float dvn[4] = {in.d4.x, in.d4.y, in.d4.z, in.d4.w};
+    const float dvp[4] = {in.d4.w, in.t0.w, in.t1.w, in.t2.w};
+    const float txn[12] = {in.t0.x, in.t0.y, in.t0.z, in.t0.w, in.t1.x, in.t1.y,
+                           in.t1.z, in.t1.w, in.t2.x, in.t2.y, in.t2.z, in.t2.w};
+    const float txp[12] = {in.d4.x, in.d4.y, in.d4.z, in.t0.x, in.t0.y, in.t0.z,
+                           in.t1.x, in.t1.y, in.t1.z, in.t2.x, in.t2.y, in.t2.z};
+    const float (&dv)[4] = PACK ? dvp : dvn;
+    const float (&tx)[12] = PACK ? txp : txn;
     float ot[12], od[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -261,6 +279,7 @@ __device__ __forceinline__ void bs_run(const BSArgs& a, const float (&m)[8],
   }
 }
 
+template <bool PACK>
 __global__ __launch_bounds__(BS_T, LSI_BS_WPE) void splat_bwd_stream_kernel(BSArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float4* const gt = reinterpret_cast<float4*>(smem);  // [GR][Wt]
@@ -277,7 +296,7 @@ __global__ __launch_bounds__(BS_T, LSI_BS_WPE) void splat_bwd_stream_kernel(BSAr
   // ---- loads of the wave's first two items, before anything else -------------
   BSIn set[2];
   {
-    const float* const g_tex_in = a.tex + (long)b * a.tex_sb + (long)l_lo * a.tex_sl + 12 * lane;
+    const float* const g_tex_in = a.tex + (long)b * a.tex_sb + (long)l_lo * a.tex_sl + (PACK ? 16 : 12) * lane;
     const float* const g_disp_in = a.disp + (long)b * a.disp_sb + (long)l_lo * a.disp_sl + 4 * lane;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
@@ -285,12 +304,8 @@ __global__ __launch_bounds__(BS_T, LSI_BS_WPE) void splat_bwd_stream_kernel(BSAr
       const int itc = it < nitem ? it : 0;
       const int rs = itc / NL, l = itc - rs * NL;
       const int r = rs / nseg, sg = rs - r * nseg;
-      const float* pd = g_disp_in + (long)l * a.disp_sl + (long)(ys + r) * a.disp_sy + sg * BS_SEG;
-      const float* pt = g_tex_in + (long)l * a.tex_sl + (long)(ys + r) * a.tex_sy + 3 * sg * BS_SEG;
-      set[k].d4 = *reinterpret_cast<const float4*>(pd);
-      set[k].t0 = *reinterpret_cast<const float4*>(pt);
-      set[k].t1 = *reinterpret_cast<const float4*>(pt + 4);
-      set[k].t2 = *reinterpret_cast<const float4*>(pt + 8);
+      bs_load<PACK>(set[k], g_disp_in + (long)l * a.disp_sl + (long)(ys + r) * a.disp_sy + sg * BS_SEG,
+                    g_tex_in + (long)l * a.tex_sl + (long)(ys + r) * a.tex_sy + (PACK ? 4 : 3) * sg * BS_SEG);
     }
   }
 
@@ -341,9 +356,9 @@ __global__ __launch_bounds__(BS_T, LSI_BS_WPE) void splat_bwd_stream_kernel(BSAr
   __syncthreads();
   if (nitem <= 0) return;
   if (in_lds)
-    bs_run<true>(a, m, set, gt, obi, obc, b, l_lo, NL, ys, nitem, glo, wave, lane);
+    bs_run<true, PACK>(a, m, set, gt, obi, obc, b, l_lo, NL, ys, nitem, glo, wave, lane);
   else
-    bs_run<false>(a, m, set, gt, obi, obc, b, l_lo, NL, ys, nitem, glo, wave, lane);
+    bs_run<false, PACK>(a, m, set, gt, obi, obc, b, l_lo, NL, ys, nitem, glo, wave, lane);
 }
 
 bool aligned16b(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -362,11 +377,14 @@ bool lsi_bwd_stream_applies(const LsiSplatDesc* d, const float* tex,
     return false;
   if (d->flags & (LSI_HAS_MASK | LSI_WANT_DISP)) return false;
   if (d->W % BS_SEG != 0 || d->L < 1) return false;
-  if (d->tex_sc != 1 || d->tex_sx != 3 || d->disp_sx != 1) return false;
+  // (LSI_PACKED_RGBD: the entry points have verified the caller's statement)
+  const bool pack = (d->flags & LSI_PACKED_RGBD) != 0;
+  if (!pack && (d->tex_sc != 1 || d->tex_sx != 3 || d->disp_sx != 1)) return false;
   const int64_t st[] = {d->tex_sl, d->tex_sb, d->tex_sy, d->disp_sl, d->disp_sb, d->disp_sy};
   for (int64_t v : st)
     if (v < 0 || v > 0x7fffffffLL || v % 4) return false;
-  if (!aligned16b(tex) || !aligned16b(disp) || !aligned16b(g_tex) || !aligned16b(g_disp))
+  if (!aligned16b(tex) || (!pack && !aligned16b(disp)) || !aligned16b(g_tex) ||
+      !aligned16b(g_disp))
     return false;
   if ((long)d->B > 65535 || (long)d->L > 65535) return false;
   return true;
@@ -413,11 +431,15 @@ int lsi_bwd_stream_launch(const LsiSplatDesc* d, const float* tex,
   a.GR = rows_for(rs);
   size_t lds = bytes_for(rs);
   if (lds > cap) { a.GR = 0; lds = 0; }
-  if (hipFuncSetAttribute((const void*)splat_bwd_stream_kernel,
-                          hipFuncAttributeMaxDynamicSharedMemorySize,
+  const void* fn = (d->flags & LSI_PACKED_RGBD)
+                       ? (const void*)splat_bwd_stream_kernel<true>
+                       : (const void*)splat_bwd_stream_kernel<false>;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)(lds > 0 ? lds : 16)) != hipSuccess)
     return LSI_ELAUNCH;
   const dim3 grid((d->H + rs - 1) / rs, d->B, a.compose ? 1 : d->L);
-  hipLaunchKernelGGL(splat_bwd_stream_kernel, grid, dim3(BS_T), lds, stream, a);
+  void* kargs[1] = {&a};
+  if (hipLaunchKernel(fn, grid, dim3(BS_T), kargs, lds, stream) != hipSuccess)
+    return LSI_ELAUNCH;
   return hipGetLastError() == hipSuccess ? LSI_OK : LSI_ELAUNCH;
 }

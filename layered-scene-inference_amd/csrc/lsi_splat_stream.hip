@@ -1612,11 +1612,16 @@ size_t stream_lds_bytes(const LsiSplatDesc* d, int tile_rows, int nw, int wmax,
          16;
 }
 
-// layout class of the texture strides: 0 channels-last, 1 planar, -1 neither
+// layout class of the texture strides: 0 channels-last, 1 planar, 2 RGBD
+// pixels (LSI_PACKED_RGBD: colour and disparity interleaved), -1 none of them
 int tex_layout(const LsiSplatDesc* d) {
   const bool al = (d->tex_sl % 4 == 0) && (d->tex_sb % 4 == 0) &&
                   (d->tex_sy % 4 == 0);
   if (!al) return -1;
+  if ((d->flags & LSI_PACKED_RGBD) && d->tex_sc == 1 && d->tex_sx == 4 &&
+      d->disp_sx == 4 && d->tex_sl == d->disp_sl && d->tex_sb == d->disp_sb &&
+      d->tex_sy == d->disp_sy)
+    return 2;
   if (d->tex_sc == 1 && d->tex_sx == 3) return 0;
   if (d->tex_sx == 1 && d->tex_sc % 4 == 0) return 1;
   return -1;
@@ -1639,8 +1644,15 @@ extern "C" int lsi_stream_ok(const LsiSplatDesc* d, const float* M) {
     for (int64_t v : st)
       if (v < 0 || v > 0x7fffffffLL) return 0;
   }
-  if (tex_layout(d) < 0) return 0;
-  if (d->disp_sx != 1 || d->disp_sy % 4 || d->disp_sb % 4 || d->disp_sl % 4)
+  const int layout = tex_layout(d);
+  if (layout < 0) return 0;
+  if (layout != 2 &&
+      (d->disp_sx != 1 || d->disp_sy % 4 || d->disp_sb % 4 || d->disp_sl % 4))
+    return 0;
+  // RGBD pixels: only the compact instance reads them (rows of whole segments,
+  // no mask, unit normaliser: checked below) -- else the any-stride TILE path
+  if (layout == 2 && (d->W % SEG != 0 || d->L > 15 ||
+                      (d->flags & (LSI_HAS_MASK | LSI_DETERMINISTIC))))
     return 0;
   if ((d->flags & LSI_HAS_MASK) &&
       (d->mask_sx != 1 || d->mask_sy % 4 || d->mask_sb % 4 || d->mask_sl % 4))
@@ -1663,6 +1675,7 @@ extern "C" int lsi_stream_ok(const LsiSplatDesc* d, const float* M) {
     if (!(span == span)) return 0;
     need = fmaxf(need, span);
   }
+  if (layout == 2 && !simple) return 0;
   int win = (int)ceilf(need) + 8;  // the window's margin: 1 cell left, 4 right
   win = (win + 15) / 16 * 16;
   if (win < 64) win = 64;
@@ -1812,13 +1825,16 @@ int lsi_stream_launch(const SplatArgs& a, hipStream_t stream) {
   const int layout = tex_layout(d);
   if (layout < 0 || (d->flags & LSI_WANT_DISP) || d->W % 4 != 0)
     return LSI_EINVAL;
-  if (!aligned16(a.tex) || !aligned16(a.disp) ||
+  if (!aligned16(a.tex) || (layout != 2 && !aligned16(a.disp)) ||
       ((d->flags & LSI_HAS_MASK) && !aligned16(a.mask)))
     return LSI_EINVAL;
   if ((d->tune_window & ~LSI_STREAM_SIMPLE_BIT) <= 0)
     return LSI_EINVAL;  // from lsi_stream_ok
   if (lsi_stream2_applies(a, (d->tune_window & LSI_STREAM_SIMPLE_BIT) != 0, layout))
     return lsi_stream2_launch(a, d->tune_window & ~LSI_STREAM_SIMPLE_BIT, stream);
+  // (RGBD pixels outside the compact instance's cases, e.g. per-layer outputs
+  // alone: the any-stride path)
+  if (layout == 2) return lsi_tile_launch(a, stream);
   const int NB = (d->Wt + 63) / 64;
   StreamCfg cfg;
   cfg.wmax = d->tune_window & ~LSI_STREAM_SIMPLE_BIT;

@@ -322,7 +322,7 @@ struct Px { float4 d4, t0, t1, t2; };
 // BOTH: lsi_splat_fwd_both -- the per-layer views AND the composed one from one
 // sweep: one tile per layer in LDS, every item (one layer of a unit) merges its
 // window into its layer's tile, the epilogue writes L + 1 views.
-template <int NSETS, bool CELL, int MAXT, bool BOTH = false>
+template <int NSETS, bool CELL, int MAXT, bool BOTH = false, bool PACK = false>
 __global__ __launch_bounds__(MAXT) void splat_stream2_kernel(S2Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -384,7 +384,8 @@ __global__ __launch_bounds__(MAXT) void splat_stream2_kernel(S2Args a) {
   // of order: waiting for any kernel argument would wait for M as well).
   const float m_lane = a.M[16 * b + (lane & 7)];
   // ---- loader state ---------------------------------------------------------
-  const float* const g_tex = a.tex + (long)b * a.tex_sb + 12 * lane;
+  // (PACK: RGBD pixels, 16 floats per lane; the disparity pointer is unused)
+  const float* const g_tex = a.tex + (long)b * a.tex_sb + (PACK ? 16 : 12) * lane;
   const float* const g_disp = a.disp + (long)b * a.disp_sb + 4 * lane;
   const int tex_sl = a.tex_sl, disp_sl = a.disp_sl;
   const float* p_disp = g_disp;
@@ -392,14 +393,21 @@ __global__ __launch_bounds__(MAXT) void splat_stream2_kernel(S2Args a) {
   int ld_left = 0, ld_done = 0, ld_slot = 0, ld_first = 0;
   auto aim = [&](int y, int sg, int l0) {
     p_disp = g_disp + (long)l0 * disp_sl + (long)y * a.disp_sy + sg * SEG;
-    p_tex = g_tex + (long)l0 * tex_sl + (long)y * a.tex_sy + 3 * sg * SEG;
+    p_tex = g_tex + (long)l0 * tex_sl + (long)y * a.tex_sy + (PACK ? 4 : 3) * sg * SEG;
   };
   auto load_layer = [&](Px& o) {
-    o.d4 = *reinterpret_cast<const float4*>(p_disp);
-    o.t0 = *reinterpret_cast<const float4*>(p_tex);
-    o.t1 = *reinterpret_cast<const float4*>(p_tex + 4);
-    o.t2 = *reinterpret_cast<const float4*>(p_tex + 8);
-    p_disp += disp_sl;
+    if (PACK) {  // d4, t0, t1, t2 = the lane's pixels 0 .. 3 as (r, g, b, d)
+      o.d4 = *reinterpret_cast<const float4*>(p_tex);
+      o.t0 = *reinterpret_cast<const float4*>(p_tex + 4);
+      o.t1 = *reinterpret_cast<const float4*>(p_tex + 8);
+      o.t2 = *reinterpret_cast<const float4*>(p_tex + 12);
+    } else {
+      o.d4 = *reinterpret_cast<const float4*>(p_disp);
+      o.t0 = *reinterpret_cast<const float4*>(p_tex);
+      o.t1 = *reinterpret_cast<const float4*>(p_tex + 4);
+      o.t2 = *reinterpret_cast<const float4*>(p_tex + 8);
+      p_disp += disp_sl;
+    }
     p_tex += tex_sl;
   };
   // ---- the wave's own first unit, aimed BEFORE the projection matrix is here --
@@ -758,10 +766,16 @@ __global__ __launch_bounds__(MAXT) void splat_stream2_kernel(S2Args a) {
     float4 Vv[4];  // route A: the lane's 4 cell sums; else V of its 4 pixels
     int cl0 = 0, routeA = 0;
     if (live) {
-      const float dv[4] = {cur.d4.x, cur.d4.y, cur.d4.z, cur.d4.w};
-      const float tx_[12] = {cur.t0.x, cur.t0.y, cur.t0.z, cur.t0.w,
+      const float dvn[4] = {cur.d4.x, cur.d4.y, cur.d4.z, cur.d4.w};
+      const float dvp[4] = {cur.d4.w, cur.t0.w, cur.t1.w, cur.t2.w};
+      const float txn[12] = {cur.t0.x, cur.t0.y, cur.t0.z, cur.t0.w,
                              cur.t1.x, cur.t1.y, cur.t1.z, cur.t1.w,
                              cur.t2.x, cur.t2.y, cur.t2.z, cur.t2.w};
+      const float txp[12] = {cur.d4.x, cur.d4.y, cur.d4.z, cur.t0.x,
+                             cur.t0.y, cur.t0.z, cur.t1.x, cur.t1.y,
+                             cur.t1.z, cur.t2.x, cur.t2.y, cur.t2.z};
+      const float (&dv)[4] = PACK ? dvp : dvn;
+      const float (&tx_)[12] = PACK ? txp : txn;
       float pwv[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -1193,7 +1207,7 @@ int s2_plan(const LsiSplatDesc* d, int wmax, int maxnw, bool both, S2Plan* out) 
     // LDS operations than one under two row locks: 204 vs 184 us at config 3)
     int cell = (R <= 8 && nunit <= 40 && !both) ? 1 : 0;
     if (force_cell == 1) cell = 0;
-    if (force_cell == 2) cell = 1;
+    if (force_cell == 2 && !both) cell = 1;  // (both outputs: row locks only)
     for (int c = maxnw; c >= 2; --c) {
       if (d->tune_threads > 0 && c != (d->tune_threads + 63) / 64) continue;
       // A unit is all L layers of a row segment on one wave (one merge per
@@ -1269,14 +1283,14 @@ bool lsi_stream2_applies(const SplatArgs& a, bool simple, int layout) {
   if (off && off[0] == '0') return false;
   if (d->reserved & 0x40000000) return false;  // tests: force the general kernel
   if (((d->reserved >> 16) & 3) == 2) return false;  // exchange bands asked for
-  if (!simple || layout != 0) return false;
+  if (!simple || (layout != 0 && layout != 2)) return false;
   const bool both = a.out_img_c != nullptr;  // lsi_splat_fwd_both: per-layer + composed
   if ((d->flags & (LSI_COMPOSE | LSI_HAS_MASK | LSI_WANT_DISP | LSI_DETERMINISTIC)) !=
       (both ? 0u : (unsigned)LSI_COMPOSE))
     return false;
   if (both && (d->L > 15 || !a.out_wts_c)) return false;
   if (d->W % SEG != 0 || d->H > 65535 || d->W / SEG > 32767) return false;
-  if (d->tex_sx != 3 || d->tex_sc != 1 || d->disp_sx != 1) return false;
+  if (layout == 0 && (d->tex_sx != 3 || d->tex_sc != 1 || d->disp_sx != 1)) return false;
   return true;
 }
 
@@ -1313,15 +1327,17 @@ int lsi_stream2_launch(const SplatArgs& a, int wmax, hipStream_t stream) {
       a.ws_bytes >= (size_t)nbands * d->B * 16 * 8 * 8)
     k.stamps = reinterpret_cast<long long*>(a.canvas);
 #endif
+  const bool pack = (d->flags & LSI_PACKED_RGBD) != 0;  // (verified by the caller)
   const void* fn;
-  if (both)
-    fn = plan.cell
-        ? (const void*)splat_stream2_kernel<LSI_S2_NSETS, true, LSI_S2_MAXT, true>
-        : (const void*)splat_stream2_kernel<LSI_S2_NSETS, false, LSI_S2_MAXT, true>;
+  if (both)  // (row locks: s2_plan never picks cell locks with both outputs)
+    fn = pack ? (const void*)splat_stream2_kernel<LSI_S2_NSETS, false, LSI_S2_MAXT, true, true>
+              : (const void*)splat_stream2_kernel<LSI_S2_NSETS, false, LSI_S2_MAXT, true>;
+  else if (plan.cell)
+    fn = pack ? (const void*)splat_stream2_kernel<LSI_S2_NSETS, true, LSI_S2_MAXT, false, true>
+              : (const void*)splat_stream2_kernel<LSI_S2_NSETS, true, LSI_S2_MAXT>;
   else
-    fn = plan.cell
-        ? (const void*)splat_stream2_kernel<LSI_S2_NSETS, true, LSI_S2_MAXT>
-        : (const void*)splat_stream2_kernel<LSI_S2_NSETS, false, LSI_S2_MAXT>;
+    fn = pack ? (const void*)splat_stream2_kernel<LSI_S2_NSETS, false, LSI_S2_MAXT, false, true>
+              : (const void*)splat_stream2_kernel<LSI_S2_NSETS, false, LSI_S2_MAXT>;
   if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)plan.lds) != hipSuccess)
     return LSI_ELAUNCH;

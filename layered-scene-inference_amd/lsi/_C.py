@@ -19,6 +19,7 @@ SO_PATH = os.path.join(_PKG, 'liblsi_hip_%s.so' % os.environ['LSI_HIP_LIB'] if
 LSI_OK = 0
 LSI_COMPOSE, LSI_WANT_DISP, LSI_HAS_MASK, LSI_WS_KEEP = 1, 2, 4, 8
 LSI_DETERMINISTIC = 16
+LSI_PACKED_RGBD = 32
 LSI_PATH_AUTO, LSI_PATH_ATOMIC, LSI_PATH_ROWBAND, LSI_PATH_STREAM = 0, 1, 2, 3
 LSI_PATH_TILE = 4
 PATH_NAMES = {1: 'atomic', 2: 'rowband', 3: 'stream', 4: 'tile'}

@@ -42,6 +42,13 @@ def _desc(tex, mask, disp, ht, wt, s, max_disp, zbuf_scale, bg_wt, flags, path,
     (d.mask_sl, d.mask_sb, d.mask_sy, d.mask_sx) = mask.stride()[:4]
   d.trg_downsampling, d.max_disp, d.zbuf_scale = s, max_disp, zbuf_scale
   d.bg_wt = bg_wt
+  # colour and disparity interleaved as RGBD pixels in one buffer (the 4-channel
+  # output of a channels-last conv head, sliced): one 16-byte load per pixel
+  if (mask is None and tex.stride()[3:] == (4, 1) and disp.stride()[3] == 4 and
+      tex.stride()[:3] == disp.stride()[:3] and
+      disp.data_ptr() == tex.data_ptr() + 12 and tex.data_ptr() % 16 == 0 and
+      all(st % 4 == 0 for st in tex.stride()[:3])):
+    flags |= _C.LSI_PACKED_RGBD
   d.flags, d.path = flags, path
   d.tune_rows, d.tune_threads = band_rows, threads
   return d

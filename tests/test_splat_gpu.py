@@ -1147,3 +1147,80 @@ def test_streamed_backward_matches_autograd_and_the_gather_kernel(kind, both, de
     scale = np.abs(want).max() + 1e-30
     bad = np.abs(a - want) > 2e-4 * scale + 1e-3 * np.abs(want)
     assert bad.mean() < 0.005, (name, bad.mean(), np.abs(a - want).max() / scale)
+
+
+@pytest.mark.parametrize('w', [256, 512, 384])
+def test_packed_rgbd_pixels_render_like_separate_tensors(w, dev):
+  """Colour and disparity given as views of ONE [L,B,H,W,4] buffer (what a
+  channels-last conv head writes, sliced): the descriptor carries
+  LSI_PACKED_RGBD, the compact STREAM instance and the streamed backward read
+  whole RGBD pixels with 16-byte loads (W % 256 == 0; other widths go to the
+  any-stride path) -- outputs and gradients as for separate contiguous
+  tensors."""
+  from lsi import _C
+  from lsi.geometry import ldi
+  nl, b, h = 3, 2, 24
+  rs = np.random.RandomState(77 + w)
+  pred_np = rs.rand(nl, b, h, w, 4).astype(np.float32)
+  pred_np[..., 3] = pred_np[..., 3] * 0.5 - 0.03
+  _, _, _, mat = _rectified_case(5, nl, b, h, w)
+  s, bg, md, zb = 0.5, 1e-3, 0.4, 50.0
+  kw = dict(trg_downsampling=s, bg_layer_disp=bg, max_disp=md, zbuf_scale=zb)
+
+  def run(packed, both):
+    pred = torch.tensor(pred_np, device=dev, requires_grad=True)
+    tex, disp = pred[..., 0:3], pred[..., 3:4]
+    if not packed:
+      tex, disp = tex.contiguous(), disp.contiguous()
+    d = ldi._desc(tex, None, disp, h // 2, w // 2, s, md, zb, 0.1, 0, 0)
+    assert bool(d.flags & _C.LSI_PACKED_RGBD) == packed
+    if both:
+      outs = list(ldi.forward_splat_both([tex, None, disp], torch.tensor(mat), **kw))
+    else:
+      outs = list(ldi.forward_splat_matrix([tex, None, disp], torch.tensor(mat),
+                                           compose_layers=True, **kw))
+    g = torch.Generator().manual_seed(1)
+    loss = 0
+    for o in outs:
+      c = torch.rand(o.shape, generator=g).to(dev)
+      loss = loss + ((o if o.shape[-1] == 3 else torch.log(o) * 1e-3) * c).sum()
+    loss.backward()
+    return [o.detach().cpu().numpy() for o in outs], pred.grad.cpu().numpy()
+
+  for both in (False, True):
+    outs_p, g_p = run(True, both)
+    outs_c, g_c = run(False, both)
+    for a, c in zip(outs_p, outs_c):
+      if a.shape[-1] == 3:
+        assert np.abs(a - c).max() <= 4e-6
+      else:
+        np.testing.assert_allclose(a, c, rtol=2e-6, atol=0)
+    scale = np.abs(g_c).max()
+    assert np.abs(g_p - g_c).max() <= 2e-5 * scale
+
+
+def test_packed_rgbd_flag_is_verified_by_the_entry_points(dev):
+  """LSI_PACKED_RGBD is the caller's statement about its pointers; a descriptor
+  carrying it with tensors that are not one RGBD buffer is LSI_EINVAL."""
+  import ctypes
+  from lsi import _C
+  from lsi.geometry import ldi
+  nl, b, h, w = 1, 1, 8, 256
+  pred = torch.rand(nl, b, h, w, 4, device=dev)
+  tex, disp = pred[..., 0:3], pred[..., 3:4]
+  d = ldi._desc(tex, None, disp, h // 2, w // 2, 0.5, 0.4, 50.0, 0.1,
+                _C.LSI_COMPOSE, _C.LSI_PATH_TILE)
+  assert d.flags & _C.LSI_PACKED_RGBD
+  other = torch.rand(nl, b, h, w, 4, device=dev)[..., 3:4]   # same strides, other buffer
+  img = torch.empty(1, b, h // 2, w // 2, 3, device=dev)
+  wts = torch.empty(1, b, h // 2, w // 2, 1, device=dev)
+  mat = torch.eye(4, device=dev).expand(b, 4, 4).contiguous()
+  lib = _C.lib()
+  ws_bytes = int(lib.lsi_splat_workspace_bytes(ctypes.byref(d)))
+  ws = torch.zeros(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
+  args = lambda dp: (ctypes.byref(d), _C.ptr(tex), _C.ptr(dp), None, _C.ptr(mat),
+                     _C.ptr(img), _C.ptr(wts), None, _C.ptr(ws), ws_bytes,
+                     _C.stream_ptr(dev))
+  assert lib.lsi_splat_fwd(*args(other)) == -1   # LSI_EINVAL
+  assert lib.lsi_splat_fwd(*args(disp)) == 0
+  torch.cuda.synchronize()
