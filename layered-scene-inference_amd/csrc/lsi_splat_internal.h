@@ -35,7 +35,10 @@ int lsi_stream_launch(const SplatArgs& a, hipStream_t stream);
 // The compact STREAM instance (lsi_splat_stream2.hip): compose mode, no mask,
 // unit normaliser, channels-last textures, rows of whole 256-pixel segments.
 bool lsi_stream2_applies(const SplatArgs& a, bool simple, int layout);
-int lsi_stream2_launch(const SplatArgs& a, int wmax, hipStream_t stream);
+// disp_pass: the per-layer-tile instance as the disparity pass (only output:
+// a.out_disp = max over layers of each layer's normalised splatted disparity)
+int lsi_stream2_launch(const SplatArgs& a, int wmax, hipStream_t stream,
+                       bool disp_pass = false);
 
 // The streamed backward for rectified pairs (lsi_splat_bwd_stream.hip).  It
 // derives the gradient canvas from the forward's outputs and their incoming

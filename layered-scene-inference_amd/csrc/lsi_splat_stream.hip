@@ -1634,7 +1634,10 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 extern "C" int lsi_stream_ok(const LsiSplatDesc* d, const float* M) {
   if (!d || !M) return 0;
   if (!lsi_rowband_ok(d, M)) return 0;
-  if (d->flags & LSI_WANT_DISP) return 0;
+  // the disparity output: composed, by the compact instance only (checked with
+  // the layout below)
+  const bool want_disp = (d->flags & LSI_WANT_DISP) != 0;
+  if (want_disp && !(d->flags & LSI_COMPOSE)) return 0;
   if (d->W % 4 != 0) return 0;
   if (d->Wt > 32767) return 0;  // window origin is kept in 16 bits
   {  // the kernel keeps element strides in 32 bits
@@ -1651,8 +1654,10 @@ extern "C" int lsi_stream_ok(const LsiSplatDesc* d, const float* M) {
     return 0;
   // RGBD pixels: only the compact instance reads them (rows of whole segments,
   // no mask, unit normaliser: checked below) -- else the any-stride TILE path
-  if (layout == 2 && (d->W % SEG != 0 || d->L > 15 ||
-                      (d->flags & (LSI_HAS_MASK | LSI_DETERMINISTIC))))
+  if ((layout == 2 || want_disp) &&
+      (layout == 1 || d->W % SEG != 0 || d->L > 15 ||
+       (d->flags & (LSI_HAS_MASK | LSI_DETERMINISTIC)) ||
+       (layout == 0 && (d->tex_sx != 3 || d->tex_sc != 1))))
     return 0;
   if ((d->flags & LSI_HAS_MASK) &&
       (d->mask_sx != 1 || d->mask_sy % 4 || d->mask_sb % 4 || d->mask_sl % 4))
@@ -1675,7 +1680,7 @@ extern "C" int lsi_stream_ok(const LsiSplatDesc* d, const float* M) {
     if (!(span == span)) return 0;
     need = fmaxf(need, span);
   }
-  if (layout == 2 && !simple) return 0;
+  if ((layout == 2 || want_disp) && !simple) return 0;
   int win = (int)ceilf(need) + 8;  // the window's margin: 1 cell left, 4 right
   win = (win + 15) / 16 * 16;
   if (win < 64) win = 64;
@@ -1823,13 +1828,27 @@ static int stream_plan(const LsiSplatDesc* d, int wmax, bool both,
 int lsi_stream_launch(const SplatArgs& a, hipStream_t stream) {
   const LsiSplatDesc* d = &a.d;
   const int layout = tex_layout(d);
-  if (layout < 0 || (d->flags & LSI_WANT_DISP) || d->W % 4 != 0)
-    return LSI_EINVAL;
+  if (layout < 0 || d->W % 4 != 0) return LSI_EINVAL;
   if (!aligned16(a.tex) || (layout != 2 && !aligned16(a.disp)) ||
       ((d->flags & LSI_HAS_MASK) && !aligned16(a.mask)))
     return LSI_EINVAL;
   if ((d->tune_window & ~LSI_STREAM_SIMPLE_BIT) <= 0)
     return LSI_EINVAL;  // from lsi_stream_ok
+  if (d->flags & LSI_WANT_DISP) {
+    // composed view by the compact instance, then its per-layer-tile variant as
+    // the disparity pass (ldi.py:147-180: each layer's splatted disparity over
+    // its own weight, maximum over the layers)
+    if (!a.out_disp) return LSI_ENULL;
+    SplatArgs a1 = a;
+    a1.d.flags &= ~LSI_WANT_DISP;
+    a1.out_disp = nullptr;
+    if (!lsi_stream2_applies(a1, (d->tune_window & LSI_STREAM_SIMPLE_BIT) != 0, layout))
+      return LSI_EINVAL;  // (lsi_stream_ok admits nothing else)
+    const int wmax = d->tune_window & ~LSI_STREAM_SIMPLE_BIT;
+    const int rc = lsi_stream2_launch(a1, wmax, stream);
+    if (rc != LSI_OK) return rc;
+    return lsi_stream2_launch(a, wmax, stream, true);
+  }
   if (lsi_stream2_applies(a, (d->tune_window & LSI_STREAM_SIMPLE_BIT) != 0, layout))
     return lsi_stream2_launch(a, d->tune_window & ~LSI_STREAM_SIMPLE_BIT, stream);
   // (RGBD pixels outside the compact instance's cases, e.g. per-layer outputs

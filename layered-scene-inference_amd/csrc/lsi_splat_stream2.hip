@@ -61,6 +61,9 @@ struct S2Args {
   float* out_wts;
   float* out_img_c;  // BOTH: the composed view next to the L per-layer views
   float* out_wts_c;
+  // BOTH instance as the disparity pass (compute_trg_disp, ldi.py:147-180): the
+  // per-layer tiles sum (d * w, -, -, w); the only output is out_disp
+  float* out_disp;
   int B, H, Ht, Wt, L, nseg;
   int tex_sl, tex_sb, tex_sy, disp_sl, disp_sb, disp_sy;  // element strides
   float s, max_disp, zA, zB, lbg;  // exp2(fma(clip(d), zA, zB)); L * bg weight
@@ -775,7 +778,19 @@ __global__ __launch_bounds__(MAXT) void splat_stream2_kernel(S2Args a) {
                              cur.t0.y, cur.t0.z, cur.t1.x, cur.t1.y,
                              cur.t1.z, cur.t2.x, cur.t2.y, cur.t2.z};
       const float (&dv)[4] = PACK ? dvp : dvn;
-      const float (&tx_)[12] = PACK ? txp : txn;
+      const float (&tx0_)[12] = PACK ? txp : txn;
+      float tx_[12];
+#pragma unroll
+      for (int k = 0; k < 12; ++k) tx_[k] = tx0_[k];
+      if (BOTH && a.out_disp) {  // the disparity pass: the "colour" is (d, 0, 0)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          // (a pixel with zero weight or a non-finite disparity adds nothing:
+          // never NaN * 0)
+          tx_[3 * i] = (dv[i] > 0.0f && dv[i] < __builtin_inff()) ? dv[i] : 0.0f;
+          tx_[3 * i + 1] = 0.f; tx_[3 * i + 2] = 0.f;
+        }
+      }
       float pwv[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -1121,7 +1136,23 @@ __global__ __launch_bounds__(MAXT) void splat_stream2_kernel(S2Args a) {
   S2_STAMP(5);
 
   // ---- epilogue: (tile + background) normalised, each output written once --
-  if (BOTH) {
+  if (BOTH && a.out_disp) {
+    // the disparity pass: every layer's splatted disparity normalised by its own
+    // canvas weight, then the maximum over the layers (ldi.py:157-158, 170)
+    const float bg = a.bg;
+    const size_t P = (size_t)Ht * Wt;
+    const size_t o0 = (size_t)b * P + (size_t)row0 * Wt;
+    const int ncell = rows * Wt;
+    for (int i = tid; i < ncell; i += T) {
+      float dmax = 0.0f;
+      for (int l = 0; l < a.L; ++l) {
+        const float4 A = tile4[(size_t)l * R * Wt + i];
+        const float dl = div_rn(A.x, safe_den(A.w + bg));
+        dmax = l == 0 ? dl : fmaxf(dmax, dl);
+      }
+      a.out_disp[o0 + i] = dmax;
+    }
+  } else if (BOTH) {
     // per layer (ldi.py:157-163, 176-177) and composed (:167-174): the sum of
     // the layers' canvases, each with its own background
     const float bg = a.bg;
@@ -1294,15 +1325,17 @@ bool lsi_stream2_applies(const SplatArgs& a, bool simple, int layout) {
   return true;
 }
 
-int lsi_stream2_launch(const SplatArgs& a, int wmax, hipStream_t stream) {
+int lsi_stream2_launch(const SplatArgs& a, int wmax, hipStream_t stream,
+                       bool disp_pass) {
   const LsiSplatDesc* d = &a.d;
   S2Plan plan;
-  const bool both = a.out_img_c != nullptr;
+  const bool both = disp_pass || a.out_img_c != nullptr;
   if (s2_plan(d, wmax, LSI_S2_MAXT / 64, both, &plan) != LSI_OK) return LSI_EINVAL;
   S2Args k;
   k.tex = a.tex; k.disp = a.disp; k.M = a.M;
   k.out_img = a.out_img; k.out_wts = a.out_wts;
   k.out_img_c = a.out_img_c; k.out_wts_c = a.out_wts_c;
+  k.out_disp = disp_pass ? a.out_disp : nullptr;
   k.B = d->B; k.H = d->H; k.Ht = d->Ht; k.Wt = d->Wt; k.L = d->L;
   k.nseg = d->W / SEG;
   k.tex_sl = (int)d->tex_sl; k.tex_sb = (int)d->tex_sb; k.tex_sy = (int)d->tex_sy;

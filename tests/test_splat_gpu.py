@@ -1224,3 +1224,48 @@ def test_packed_rgbd_flag_is_verified_by_the_entry_points(dev):
   assert lib.lsi_splat_fwd(*args(other)) == -1   # LSI_EINVAL
   assert lib.lsi_splat_fwd(*args(disp)) == 0
   torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize('packed', [False, True])
+@pytest.mark.parametrize('w', [256, 512])
+def test_stream_renders_the_target_disparity_of_rectified_pairs(w, packed, dev):
+  """forward_splat(compose_layers=True, compute_trg_disp=True) -- what the
+  evaluation script asks for (ldi_pred_eval.py:340-353) -- on a rectified pair:
+  the compact STREAM instance renders the composed view and, in a second
+  launch with one tile per layer, each layer's splatted disparity over its own
+  weight, maximum over the layers (ldi.py:147-180).  Against the NumPy oracle
+  and the any-pose path."""
+  from lsi import _C
+  from lsi.geometry import ldi
+  nl, b, h = 3, 2, 24
+  rs = np.random.RandomState(31 + w)
+  pred_np = rs.rand(nl, b, h, w, 4).astype(np.float32)
+  pred_np[..., 3] = pred_np[..., 3] * 0.5 - 0.03
+  bad = rs.rand(nl, b, h, w) < 0.01   # dropped pixels: NaN / Inf disparities
+  pred_np[..., 3][bad] = np.where(rs.rand(int(bad.sum())) < 0.5, np.nan, np.inf)
+  _, _, _, mat = _rectified_case(9, nl, b, h, w)
+  s, bg, md, zb = 0.5, 1e-3, 0.4, 50.0
+  pred = torch.tensor(pred_np, device=dev)
+  tex, disp = pred[..., 0:3], pred[..., 3:4]
+  if not packed:
+    tex, disp = tex.contiguous(), disp.contiguous()
+  d = ldi._desc(tex, None, disp, h // 2, w // 2, s, md, zb, 0.1,
+                _C.LSI_COMPOSE | _C.LSI_WANT_DISP, 0)
+  assert ldi.select_path(d, torch.tensor(mat), 'auto') == _C.LSI_PATH_STREAM
+  kw = dict(compose_layers=True, compute_trg_disp=True, trg_downsampling=s,
+            bg_layer_disp=bg, max_disp=md, zbuf_scale=zb)
+  got = [t.cpu().numpy() for t in
+         ldi.forward_splat_matrix([tex, None, disp], torch.tensor(mat), **kw)]
+  ref = [t.cpu().numpy() for t in
+         ldi.forward_splat_matrix([tex, None, disp], torch.tensor(mat),
+                                  path='tile', **kw)]
+  # (oracle: the dropped pixels masked out, their disparities made finite)
+  want = O.forward_splat(pred_np[..., 0:3], (~bad)[..., None].astype(np.float32),
+                         np.where(bad[..., None], 0.1, pred_np[..., 3:4]), mat,
+                         trg_downsampling=s,
+                         bg_layer_disp=bg, max_disp=md, zbuf_scale=zb,
+                         compose_layers=True)
+  for other in (ref, (want['img'], want['wts'], want['disp'])):
+    np.testing.assert_allclose(got[0], other[0], rtol=0, atol=IMG_ATOL)
+    np.testing.assert_allclose(got[1], other[1], rtol=WTS_RTOL, atol=0)
+    np.testing.assert_allclose(got[2], other[2], rtol=DSP_RTOL, atol=1e-7)
