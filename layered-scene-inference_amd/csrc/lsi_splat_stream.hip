@@ -151,6 +151,12 @@ __device__ __forceinline__ int div_small(int n, int d, float rcp) {
   return q;
 }
 
+// Memory order of the arrival counter of the boundary-row exchange (see the
+// hand-off in the epilogue; DESIGN.md 4.1 for the measurement)
+#ifndef LSI_XCHG_ORDER
+#define LSI_XCHG_ORDER __ATOMIC_RELAXED
+#endif
+
 // Device-coherent accesses for the boundary-row exchange: agent-scope relaxed
 // atomics are write-through / cache-bypassing (sc1), so no L2 write-back or
 // invalidate (a full agent-scope fence costs tens of microseconds here).
@@ -1547,12 +1553,12 @@ __global__ __launch_bounds__(MAXT) void splat_stream_kernel(SplatArgs a,
       if (tid == 0) {
         ctl[4] = top_shared
                      ? __hip_atomic_fetch_add(&ea.xcount[xb + band], 1,
-                                              __ATOMIC_RELAXED,
+                                              LSI_XCHG_ORDER,
                                               __HIP_MEMORY_SCOPE_AGENT)
                      : 0;
         ctl[5] = bot_shared
                      ? __hip_atomic_fetch_add(&ea.xcount[xb + band + 1], 1,
-                                              __ATOMIC_RELAXED,
+                                              LSI_XCHG_ORDER,
                                               __HIP_MEMORY_SCOPE_AGENT)
                      : 0;
       }
