@@ -88,6 +88,9 @@ def build_parser():
   a('--n_obj_max', type=int, default=4)
   a('--n_box_planes', type=int, default=5)
   a('--bf16', type=_bool, default=False, help='bf16 autocast for the convs')
+  a('--flat_grads', type=_bool, default=False,
+    help='data parallel without the DDP wrapper: one flat gradient buffer, one '
+    'all-reduce per step (implied by --hip_graph with more than one rank)')
   a('--channels_last', type=_bool, default=True)
   a('--cpu', type=_bool, default=False,
     help='keep the model on the CPU (plumbing tests only: the renderer and the '

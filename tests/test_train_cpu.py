@@ -154,13 +154,16 @@ def _free_port():
   return port
 
 
-def _ddp_worker(rank, world, port, tmpdir, out):
+def _ddp_worker(rank, world, port, tmpdir, out, flat='false'):
   os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
                     RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
   torch.set_num_threads(2)
-  script, opts = _opts(tmpdir, num_iter=1)
+  script, opts = _opts(tmpdir, num_iter=1, flat_grads=flat)
   tr = _plumbing_trainer(script, opts)
   tr.setup(backend='gloo')
+  from torch.nn.parallel import DistributedDataParallel as DDP
+  assert isinstance(tr.train_model, DDP) == (flat == 'false')
+  tr.train_step()
   tr.train_step()
   flat = torch.cat([p.detach().reshape(-1) for p in tr.model.parameters()])
   out[rank] = (float(flat.double().sum()), float(flat.abs().double().sum()),
@@ -177,6 +180,14 @@ def test_ddp_gradient_allreduce_two_gloo_ranks(tmp_path):
   # different data shards, identical parameters after the all-reduced step
   assert out[0][2] != out[1][2]
   assert out[0][0] == out[1][0] and out[0][1] == out[1][1]
+  # --flat_grads (the data-parallel step --hip_graph replays: no DDP wrapper,
+  # every gradient a view of one buffer, one all-reduce): the same parameters
+  out2 = mgr.dict()
+  mp.spawn(_ddp_worker, args=(world, _free_port(), str(tmp_path / 'flat'), out2,
+                              'true'), nprocs=world, join=True)
+  assert out2[0][0] == out2[1][0] and out2[0][1] == out2[1][1]
+  assert abs(out2[0][0] - out[0][0]) <= 1e-6 * abs(out[0][1])
+  assert abs(out2[0][1] - out[0][1]) <= 1e-6 * abs(out[0][1])
 
 
 def test_resume_picks_the_newest_checkpoint_and_pretrain_restore(tmp_path):

@@ -57,18 +57,27 @@ def test_hip_graph_step_follows_the_eager_trajectory(tmp_path, built_lib):
   HIP splats and their backward, losses, Adam) is one captured graph.  Same
   batch, same seed: the graphed run must reproduce the eager run's losses."""
   runs = {}
-  for mode in ('false', 'true'):
-    tr = _trainer(tmp_path / mode, hip_graph=mode)
+  for mode in ('false', 'true', 'flat'):
+    # 'flat': the data-parallel form of the graphed step (what --hip_graph runs
+    # with more than one rank): gradients in one flat buffer, graph A (forward,
+    # losses, backward), the all-reduce (none to do on one rank), graph B (Adam)
+    kw = dict(hip_graph='true', flat_grads='true') if mode == 'flat' else \
+        dict(hip_graph=mode)
+    tr = _trainer(tmp_path / mode, **kw)
     batch = tr.feed()
     tr.feed = lambda batch=batch: batch
     runs[mode] = [float(tr.train_step()[0]) for _ in range(8)]
-    if mode == 'true':
+    if mode != 'false':
       assert tr._graph is not None              # steps 4.. were replays
-  eager, graphed = runs['false'], runs['true']
-  assert graphed[-1] < graphed[0]
-  for a, b in zip(eager, graphed):
-    assert abs(a - b) <= 2e-2 * abs(a), (eager, graphed)  # MIOpen wrw is not
-    # run-to-run deterministic; the trajectories agree to a fraction of a step
+    if mode == 'flat':
+      assert tr._graph_b is not None
+      assert all(p.grad.data_ptr() >= tr._flat.data_ptr() for p in tr.model.parameters())
+  eager = runs['false']
+  for graphed in (runs['true'], runs['flat']):
+    assert graphed[-1] < graphed[0]
+    for a, b in zip(eager, graphed):
+      assert abs(a - b) <= 2e-2 * abs(a), (eager, graphed)  # MIOpen wrw is not
+      # run-to-run deterministic; the trajectories agree to a fraction of a step
 
 
 def test_debug_synth_texture_sanity_check(tmp_path):

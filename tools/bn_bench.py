@@ -1,0 +1,48 @@
+"""Per-shape timing of the fused BN+ReLU kernels (csrc/lsi_bn.hip) on the U-Net's
+activation shapes at batch 4, 256 x 768: microseconds and GB/s of the forward
+(two passes: 2 reads + 1 write of the activation) and the backward (two passes:
+4 reads + 1 write).   python tools/bn_bench.py [--bf16 true]"""
+import argparse, json, os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'layered-scene-inference_amd'))
+from lsi.nnutils import _hip_bn
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--bf16', default='true')
+args = ap.parse_args()
+dt = torch.bfloat16 if args.bf16 == 'true' else torch.float32
+es = 2 if dt == torch.bfloat16 else 4
+dev = torch.device('cuda', 0)
+SHAPES = [(32, 256, 768), (32, 128, 384), (64, 128, 384), (64, 64, 192), (128, 64, 192),
+          (128, 32, 96), (256, 16, 48), (512, 8, 24), (512, 4, 12), (512, 2, 6)]
+rows = []
+for c, h, w in SHAPES:
+  # rotate over enough tensors to exceed the Infinity Cache
+  nbuf = max(2, int(600e6 // (4 * c * h * w * es)) + 1)
+  nbuf = min(nbuf, 64)
+  xs = [torch.randn(4, c, h, w, device=dev, dtype=dt).contiguous(memory_format=torch.channels_last).requires_grad_(True) for _ in range(nbuf)]
+  beta = torch.zeros(c, device=dev, requires_grad=True)
+  gy = torch.randn(4, c, h, w, device=dev, dtype=dt).contiguous(memory_format=torch.channels_last)
+  def fwd(i):
+    return _hip_bn.batch_norm_relu(xs[i % nbuf], beta)
+  for i in range(3):
+    fwd(i).backward(gy)
+  torch.cuda.synchronize()
+  iters = 40
+  e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+  ys = []
+  e[0].record()
+  for i in range(iters):
+    ys.append(fwd(i))
+  e[1].record()
+  for i in range(iters):
+    ys[i].backward(gy)
+  e[2].record()
+  torch.cuda.synchronize()
+  tf = e[0].elapsed_time(e[1]) * 1e3 / iters
+  tb = e[1].elapsed_time(e[2]) * 1e3 / iters
+  nb = 4 * c * h * w * es
+  rows.append({'C': c, 'hw': [h, w], 'MB': nb / 1e6, 'fwd_us': tf, 'bwd_us': tb,
+               'fwd_GBps': 3 * nb / tf / 1e3, 'bwd_GBps': 5 * nb / tb / 1e3})
+  print(json.dumps(rows[-1]))
