@@ -406,18 +406,20 @@ def measure_traffic(args, timeout_s=150):
       subprocess.run(cmd, cwd='/tmp', env=env, timeout=timeout_s,
                      stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
                      check=True)
-      got = []
+      got = {}
       for f in glob.glob(os.path.join(out, '**', '*counter_collection.csv'),
                          recursive=True):
         for row in csv.DictReader(open(f)):
-          if ('splat_' in row['Kernel_Name'] and '_kernel' in row['Kernel_Name']
-              and 'bwd' not in row['Kernel_Name']
-              and row['Counter_Name'] == counter):
-            got.append(float(row['Counter_Value']))
+          name = row['Kernel_Name']
+          if ((('splat_' in name and '_kernel' in name) or 'disp_range' in name)
+              and 'bwd' not in name and row['Counter_Name'] == counter):
+            got.setdefault(name, []).append(float(row['Counter_Value']))
       if not got:
         return None
-      got = got[len(got) // 2:]  # later launches: caches in steady state
-      vals[counter] = sum(got) / len(got)
+      # (the any-pose path is two kernels per launch: their averages add up;
+      # later launches only: caches in steady state)
+      vals[counter] = sum(sum(v[len(v) // 2:]) / len(v[len(v) // 2:])
+                          for v in got.values())
     except Exception:  # pylint: disable=broad-except
       return None
     finally:
@@ -693,8 +695,8 @@ def main():
           other[wl] = {'error': str(e)}
       extra['other_workloads'] = other
       out['extra'] = extra
-      if args.traffic == 'measure':
-        out['roofline']['traffic'] = measure_traffic(args)
+    if world == 1 and args.traffic == 'measure':
+      out['roofline']['traffic'] = measure_traffic(args)
     if world == 1 and not args.no_cpu_baseline:
       out['cpu_baseline'] = cpu_baseline(nl, b_local, h, w, cams, max_disp, bg)
     print(json.dumps(out))

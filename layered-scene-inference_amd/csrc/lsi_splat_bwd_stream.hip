@@ -72,7 +72,7 @@ struct BSArgs {
   float* g_disp;
   int B, H, W, Ht, Wt, L, nseg;
   int tex_sb, tex_sl, tex_sy, disp_sb, disp_sl, disp_sy;
-  float s, max_disp, zscale;
+  float s, max_disp, zscale, zA, zB;
   int compose;  // 1: one canvas for all layers (grid.z = 1), 0: grid.z = layer
   int RS;       // source rows per band
   int GR;       // canvas rows the LDS tile holds (0: always gather from global)
@@ -160,6 +160,7 @@ __device__ __forceinline__ void bs_run(const BSArgs& a, const float (&m)[8],
                                        int l_lo, int NL, int ys, int nitem,
                                        int glo, int wave, int lane) {
   const int Wt = a.Wt, nseg = a.nseg;
+  const int half = (Wt + 1) >> 1;
   const float s = a.s;
   const float xmax = (float)Wt - 1.0f, ymax = (float)a.Ht - 1.0f;
   const float inv_md = div_rn(1.0f, a.max_disp);
@@ -219,9 +220,13 @@ __device__ __forceinline__ void bs_run(const BSArgs& a, const float (&m)[8],
       const int c0 = ok ? (int)ax.c0s : 0, c1 = ok ? (int)ax.c1s : 0;
       float4 g0, g1, g2, g3;
       if (IN_LDS) {
+        // (cells of a row are stored even ones first, odd ones in the second
+        // half: lanes two cells apart -- 4 pixels at s = 0.5 -- read
+        // consecutive 16-byte slots instead of every other one)
         bs_lds_f4* ra = gt3 + (r0 - glo) * Wt;
         bs_lds_f4* rb = gt3 + (r1 - glo) * Wt;
-        const bs_f4v v0 = ra[c0], v1 = ra[c1], v2 = rb[c0], v3 = rb[c1];
+        const int s0 = (c0 >> 1) + (c0 & 1) * half, s1 = (c1 >> 1) + (c1 & 1) * half;
+        const bs_f4v v0 = ra[s0], v1 = ra[s1], v2 = rb[s0], v3 = rb[s1];
         g0 = make_float4(v0.x, v0.y, v0.z, v0.w); g1 = make_float4(v1.x, v1.y, v1.z, v1.w);
         g2 = make_float4(v2.x, v2.y, v2.z, v2.w); g3 = make_float4(v3.x, v3.y, v3.z, v3.w);
       } else {  // (the band's canvas rows exceed the tile: from the arrays)
@@ -231,7 +236,12 @@ __device__ __forceinline__ void bs_run(const BSArgs& a, const float (&m)[8],
         g2 = bs_G(a, obi + rb + c0, obc + rb + c0);
         g3 = bs_G(a, obi + rb + c1, obc + rb + c1);
       }
-      const float zw = zbuffer_weight(d * inv_md, a.zscale);
+      // exp((clip(d/max,0,1) - 0.5)*scale) [d/max > 0] = exp2(clip(d,0,max)*zA + zB)
+      // (the forward compact instance's form; ~1e-6 relative)
+      const float xn = d * inv_md;
+      const float ez = __builtin_amdgcn_exp2f(
+          __fmaf_rn(__builtin_amdgcn_fmed3f(d, 0.0f, a.max_disp), a.zA, a.zB));
+      const float zw = xn > 0.0f ? ez : 0.0f;
       // S_k = <tex, G_k.rgb> + G_k.w : gradient w.r.t. the corner's weight / pw
       const float S0 = __fmaf_rn(t0, g0.x, __fmaf_rn(t1, g0.y, __fmaf_rn(t2, g0.z, g0.w)));
       const float S1 = __fmaf_rn(t0, g1.x, __fmaf_rn(t1, g1.y, __fmaf_rn(t2, g1.z, g1.w)));
@@ -248,7 +258,6 @@ __device__ __forceinline__ void bs_run(const BSArgs& a, const float (&m)[8],
       const float k2 = w2 != 0.0f ? zw * S2 : 0.0f, k3 = w3 != 0.0f ? zw * S3 : 0.0f;
       // corner weights -> X: d wx0/dX = -v0, d wx1/dX = +v1
       const float gX = -ax.v0 * (k0 * ay.w0 + k2 * ay.w1) + ax.v1 * (k1 * ay.w0 + k3 * ay.w1);
-      const float xn = d * inv_md;
       const float inr = (xn >= 0.0f && xn <= 1.0f) ? 1.0f : 0.0f;
       const float gD = gpw * zw * zs_md * inr;
       // (M[1][3] == 0: the row coordinate does not move with the disparity)
@@ -340,17 +349,28 @@ __global__ __launch_bounds__(BS_T, LSI_BS_WPE) void splat_bwd_stream_kernel(BSAr
     const size_t c0 = (size_t)glo * Wt;
     const int n = grow * Wt;
     if (a.vec4) {
+      const int half = (Wt + 1) >> 1;
+      const float inv_wt = 1.0f / (float)Wt;
       for (int i = 4 * tid; i < n; i += 4 * BS_T) {
         float4 g[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) g[k] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (a.cc.g_img) bs_cell4(a.cc, obc + c0 + i, g, false);
         if (a.ci.g_img) bs_cell4(a.ci, obi + c0 + i, g, a.cc.g_img != nullptr);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) gt[i + k] = g[k];
+        // (Wt % 4 == 0: the four cells are in one row; slot = even/odd halves)
+        int row = (int)((float)i * inv_wt);  // i < 2^22: exact after one fix-up
+        int c = i - row * Wt;
+        if (c >= Wt) { ++row; c -= Wt; }
+        if (c < 0) { --row; c += Wt; }
+        float4* dst = gt + row * Wt + (c >> 1);
+        dst[0] = g[0]; dst[half] = g[1]; dst[1] = g[2]; dst[half + 1] = g[3];
       }
     } else {
-      for (int i = tid; i < n; i += BS_T) gt[i] = bs_G(a, obi + c0 + i, obc + c0 + i);
+      const int half = (Wt + 1) >> 1;
+      for (int i = tid; i < n; i += BS_T) {
+        const int row = i / Wt, c = i - row * Wt;
+        gt[row * Wt + (c >> 1) + (c & 1) * half] = bs_G(a, obi + c0 + i, obc + c0 + i);
+      }
     }
   }
   __syncthreads();
@@ -411,6 +431,9 @@ int lsi_bwd_stream_launch(const LsiSplatDesc* d, const float* tex,
   a.tex_sb = (int)d->tex_sb; a.tex_sl = (int)d->tex_sl; a.tex_sy = (int)d->tex_sy;
   a.disp_sb = (int)d->disp_sb; a.disp_sl = (int)d->disp_sl; a.disp_sy = (int)d->disp_sy;
   a.s = d->trg_downsampling; a.max_disp = d->max_disp; a.zscale = d->zbuf_scale;
+  const double l2e = 1.4426950408889634;
+  a.zA = (float)((double)d->zbuf_scale * l2e / (double)d->max_disp);
+  a.zB = (float)(-0.5 * (double)d->zbuf_scale * l2e);
   a.compose = (d->flags & LSI_COMPOSE) ? 1 : 0;
   // Source rows per band: the largest of 32 / 16 / 8 whose canvas rows
   // (RS * s + 3: the same-intrinsics estimate; the kernel checks the real

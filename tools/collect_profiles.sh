@@ -12,9 +12,11 @@ TAG=${1:-r03}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 timeout 900 python $R/bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
-for wl in cfg2 cfg4 cfg5; do
+for wl in cfg2 cfg5; do
   timeout 300 python $R/bench.py --workload $wl --no-cpu-baseline --no-extra --traffic off > $OUT/bench_$wl.json 2>> $OUT/bench_default.err
 done
+# (cfg4: with the FETCH / WRITE traffic passes of the any-pose path)
+timeout 600 python $R/bench.py --workload cfg4 --no-cpu-baseline --no-extra > $OUT/bench_cfg4.json 2>> $OUT/bench_default.err
 for n in 2 4 8; do
   timeout 300 python $R/bench.py --shard-of $n --no-cpu-baseline --no-extra --traffic off > $OUT/bench_cfg3_shard_of_$n.json 2>> $OUT/bench_default.err
 done
@@ -34,6 +36,13 @@ bash $R/tools/pmc_quick.sh splat_stream2_kernel --workload cfg3 > $OUT/pmc_sq_st
 bash $R/tools/pmc_quick.sh splat_stream2_kernel --workload cfg3 --shard-of 8 > $OUT/pmc_sq_stream_cfg3_shard_of_8.txt 2>&1
 bash $R/tools/pmc_quick.sh splat_sweep_kernel --workload cfg4 > $OUT/pmc_sq_sweep_cfg4.txt 2>&1
 cat $OUT/pmc_sq_stream_cfg3.txt $OUT/pmc_sq_stream_cfg3_shard_of_8.txt $OUT/pmc_sq_sweep_cfg4.txt
+# training-relevant entry points: timings, then counters of their kernels
+timeout 300 python $R/tools/time_bwd.py > $OUT/bwd_both_disp_cfg3.json 2>> $OUT/bench_default.err
+LSI_BWD_STREAM=0 timeout 300 python $R/tools/time_bwd.py > $OUT/bwd_both_disp_cfg3_gather_kernel.json 2>> $OUT/bench_default.err
+timeout 300 python $R/tools/time_bwd.py --workload cfg2 > $OUT/bwd_both_disp_cfg2.json 2>> $OUT/bench_default.err
+bash $R/tools/pmc_cmd.sh splat_bwd_stream_kernel python $R/tools/time_bwd.py > $OUT/pmc_bwd_stream_cfg3.txt 2>&1
+bash $R/tools/pmc_cmd.sh "768, true" python $R/tools/time_bwd.py > $OUT/pmc_fwd_both_cfg3.txt 2>&1
+cat $OUT/bwd_both_disp_cfg3.json $OUT/pmc_bwd_stream_cfg3.txt $OUT/pmc_fwd_both_cfg3.txt
 for d in rough stress; do timeout 200 python $R/bench.py --disp $d --no-cpu-baseline --no-extra --traffic off > $OUT/bench_cfg3_$d.json 2>> $OUT/bench_default.err; done
 LSI_HIP_LIB=stamps python $R/tools/phase_probe2.py cfg3 > $OUT/timeline_cfg3.txt 2>&1
 LSI_HIP_LIB=stamps python $R/tools/phase_probe2.py cfg3 0 0 8 > $OUT/timeline_cfg3_shard_of_8.txt 2>&1

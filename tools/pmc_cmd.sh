@@ -1,0 +1,20 @@
+#!/bin/bash
+# usage: tools/pmc_cmd.sh <kernel-name-substring> <command...>
+# Per-launch averages of SQ counters and of the HBM traffic counters for one
+# kernel of an arbitrary command (PMC passes only: never combined with other
+# trace domains).  Traffic = (2 * FETCH_SIZE + WRITE_SIZE) KiB as
+# MI355X_MICROARCH.md prescribes for gfx950.
+cd /tmp && export TMPDIR=/tmp
+KN=$1; shift
+for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_WAVES" "SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
+  rm -rf /tmp/pqc
+  timeout 300 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d /tmp/pqc -o p -- "$@" > /dev/null 2>&1
+  python3 - <<PY
+import csv,glob,collections
+a=collections.defaultdict(list)
+for f in glob.glob("/tmp/pqc/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "$KN" in r["Kernel_Name"]: a[r["Counter_Name"]].append(float(r["Counter_Value"]))
+print({k: round(sum(v[len(v)//2:])/len(v[len(v)//2:])) for k,v in a.items()}, 'launches', {k: len(v) for k,v in a.items()}.popitem()[1] if a else 0)
+PY
+done
