@@ -69,6 +69,11 @@ class _ZbufComp(torch.autograd.Function):
 
 def zbuffer_composition_loss(layer_imgs, layer_masks, layer_disps, trg_imgs,
                              bg_layer_disp, max_disp, zbuf_scale):
+  # the target images are data (ldi_enc_dec.py:269-294): the kernels produce no
+  # gradient for them, and silently dropping one would be wrong
+  if torch.is_tensor(trg_imgs) and trg_imgs.requires_grad:
+    raise RuntimeError('zbuffer_composition_loss: trg_imgs is not '
+                       'differentiable on the HIP path (pass trg_imgs.detach())')
   return _ZbufComp.apply(_f32(layer_imgs),
                          None if layer_masks is None else _f32(layer_masks),
                          _f32(layer_disps), _f32(trg_imgs), bg_layer_disp,

@@ -156,6 +156,12 @@ def test_compose_variants_match_goldens(dev):
     layers.compose(imgs.clone().requires_grad_(True), masks, dmaps)
   with pytest.raises(RuntimeError, match='forward-only'):
     layers.compose_depth(masks, dmaps.clone().requires_grad_(True))
+  # the target images of the self-consistency loss are data: asking for their
+  # gradient is an error, not a silent None
+  from lsi.loss import _hip
+  with pytest.raises(RuntimeError, match='not differentiable'):
+    _hip.zbuffer_composition_loss(imgs, masks, dmaps,
+                                  imgs[0].clone().requires_grad_(True), 1e-3, 1.0, 10.0)
 
 
 def test_losses_and_composition_have_no_cpu_path():
