@@ -203,6 +203,23 @@ def reduce_max(values, dist, device):
   return [float(v) for v in t]
 
 
+class stdout_to_stderr(object):
+  """File descriptor 1 points at descriptor 2 inside the block (also for
+  native libraries that write to stdout directly)."""
+
+  def __enter__(self):
+    sys.stdout.flush()
+    self.saved = os.dup(1)
+    os.dup2(2, 1)
+    return self
+
+  def __exit__(self, *exc):
+    sys.stdout.flush()
+    os.dup2(self.saved, 1)
+    os.close(self.saved)
+    return False
+
+
 def free_port():
   s = socket.socket()
   s.bind(('127.0.0.1', 0))
@@ -456,7 +473,10 @@ def timed_region(r, steps, warmup, launch_mode, dist, dev):
     if launch_mode == 'graph':
       try:
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=stream):
+        # (thread_local: the RCCL watchdog thread of an N > 1 run may query its
+        # events while this thread captures)
+        with torch.cuda.graph(graph, stream=stream,
+                              capture_error_mode='thread_local'):
           for _ in range(steps):
             r.launch()
         graph.replay()          # one untimed replay (graph upload)
@@ -557,8 +577,13 @@ def main():
       dist.init_process_group(args.selftest_backend, rank=rank,
                               world_size=world)
     else:
-      dist.init_process_group('nccl', rank=rank, world_size=world,
-                              device_id=torch.device('cuda', local_rank))
+      # (RCCL prints a version banner on stdout when its communicator comes up:
+      # stdout is kept for the one JSON line, the banner goes to stderr)
+      with stdout_to_stderr():
+        dist.init_process_group('nccl', rank=rank, world_size=world,
+                                device_id=torch.device('cuda', local_rank))
+        dist.barrier()
+        torch.cuda.synchronize()
   nl, h, w, batch, per_gpu, cams, max_disp, bg = WORKLOADS[args.workload]
   # (--shard-of N times what one GPU of a strong-scaling N-rank run renders)
   b_local, scaling = shard_batch(

@@ -83,7 +83,11 @@ class Trainer(object):
       # igemm_bwd kernels the search tries was seen to fault (GPU memory access
       # fault inside MIOpen's search, depending on where buffers happen to lie).
       torch.backends.cudnn.benchmark = bool(getattr(opts, 'miopen_search', False))
-    if self.world > 1:
+    # (a one-rank job launched by torch.distributed.run gets its process group
+    # too: the collectives of the data-parallel step then run -- over one rank
+    # -- which is how the step is exercised on a single-GPU box)
+    if self.world > 1 or (getattr(opts, 'flat_grads', False) and
+                          'RANK' in os.environ and 'MASTER_ADDR' in os.environ):
       import torch.distributed as dist
       if not dist.is_initialized():
         dist.init_process_group(backend or ('nccl' if use_gpu else 'gloo'))
@@ -145,9 +149,10 @@ class Trainer(object):
       off += p.numel()
 
   def _reduce_flat(self):
-    if self.dist is not None and self.world > 1:
+    if self.dist is not None:
       self.dist.all_reduce(self._flat)
-      self._flat.div_(self.world)
+      if self.world > 1:
+        self._flat.div_(self.world)
 
   @staticmethod
   def latest_checkpoint(checkpoint_dir):
@@ -254,17 +259,21 @@ class Trainer(object):
         if not self.flat_grads:
           self.optim.zero_grad(set_to_none=True)
           graph = torch.cuda.CUDAGraph()
-          with torch.cuda.graph(graph, stream=self._stream):
+          with torch.cuda.graph(graph, stream=self._stream,
+                                capture_error_mode='thread_local'):
             self._graph_out = self._eager_step(self._static)
         else:
           # graph A: gradients into the flat buffer; graph B: Adam.  The
           # all-reduce between them stays an ordinary RCCL call.
           graph = torch.cuda.CUDAGraph()
-          with torch.cuda.graph(graph, stream=self._stream):
+          # (thread_local: RCCL's watchdog thread queries its events meanwhile)
+          with torch.cuda.graph(graph, stream=self._stream,
+                                capture_error_mode='thread_local'):
             self._graph_out = self._grad_part(self._static)
           self._graph_b = torch.cuda.CUDAGraph()
           with torch.cuda.graph(self._graph_b, stream=self._stream,
-                                pool=graph.pool()):
+                                pool=graph.pool(),
+                                capture_error_mode='thread_local'):
             self.optim.step()
         self._graph = graph
         out = None

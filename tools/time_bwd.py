@@ -28,9 +28,10 @@ nl, h, w = bench.WORKLOADS[args.workload][:3]
 bwd = min(bench.time_backward(r) for _ in range(3))
 both = [min(x) for x in zip(*[bench.time_both(r) for _ in range(3)])]
 
-def time_disp(path):
+def time_disp(path, indep=False):
   """forward_splat(compose_layers=True, compute_trg_disp=True): the evaluation
-  script's call; path = the renderer's own (STREAM: two launches) or TILE."""
+  script's call; path = the renderer's own (STREAM: two launches) or TILE.
+  indep: compose_layers=False without the disparity output instead."""
   import ctypes
   from lsi import _C
   lib = _C.lib()
@@ -38,6 +39,12 @@ def time_disp(path):
   desc.flags = r.desc.flags | _C.LSI_WANT_DISP
   desc.path = path
   out_disp = torch.empty_like(r.wts)
+  img_o, wts_o = r.img, r.wts
+  if indep:
+    desc.flags = r.desc.flags & ~(_C.LSI_COMPOSE | _C.LSI_WANT_DISP)
+    nl_ = r.tex.shape[0]
+    img_o = torch.empty((nl_,) + tuple(r.img.shape[1:]), device=dev)
+    wts_o = torch.empty((nl_,) + tuple(r.wts.shape[1:]), device=dev)
   ws_bytes = int(lib.lsi_splat_workspace_bytes(ctypes.byref(desc)))
   ws = torch.zeros((max(ws_bytes, 16),), dtype=torch.uint8, device=dev)
   turn = [0]
@@ -45,7 +52,7 @@ def time_disp(path):
     tex, disp = r.sets[turn[0]]
     turn[0] = (turn[0] + 1) % len(r.sets)
     rc = lib.lsi_splat_fwd(ctypes.byref(desc), _C.ptr(tex), _C.ptr(disp), None,
-                           _C.ptr(r.mat), _C.ptr(r.img), _C.ptr(r.wts),
+                           _C.ptr(r.mat), _C.ptr(img_o), _C.ptr(wts_o),
                            _C.ptr(out_disp), _C.ptr(ws), ws_bytes, _C.stream_ptr(dev))
     _C.check(rc, 'lsi_splat_fwd')
   for _ in range(3):
@@ -62,8 +69,9 @@ def time_disp(path):
 from lsi import _C as _Cm
 disp_stream = time_disp(r.desc.path) if r.desc.path == _Cm.LSI_PATH_STREAM else None
 disp_tile = time_disp(_Cm.LSI_PATH_TILE)
+indep_us = time_disp(r.desc.path, indep=True)
 print(json.dumps({'workload': args.workload, 'batch': b_local,
-                  'fwd_with_disp_us': disp_stream, 'fwd_with_disp_tile_us': disp_tile,
+                  'fwd_per_layer_us': indep_us, 'fwd_with_disp_us': disp_stream, 'fwd_with_disp_tile_us': disp_tile,
                   'lib': os.environ.get('LSI_HIP_LIB', ''),
                   'bwd_stream': os.environ.get('LSI_BWD_STREAM', '1'),
                   'rows': os.environ.get('LSI_BWD_STREAM_ROWS', ''),
