@@ -1,0 +1,71 @@
+"""bench.py as the driver runs it on a GPU box: one JSON line on stdout, also
+when it is a rank of a torch.distributed.run job (RCCL process group alive while
+the timed steps are captured into a HIP graph)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+  s = socket.socket()
+  s.bind(('127.0.0.1', 0))
+  port = s.getsockname()[1]
+  s.close()
+  return port
+
+
+def _one_json_line(out):
+  lines = [l for l in out.stdout.splitlines() if l.strip()]
+  assert len(lines) == 1, out.stdout[-2000:] + out.stderr[-2000:]
+  return json.loads(lines[0])
+
+
+def test_bench_line_from_a_bare_shell(built_lib):
+  if not torch.cuda.is_available():
+    pytest.fail('gpu test selected but no ROCm device is visible')
+  env = {k: v for k, v in os.environ.items()
+         if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+  out = subprocess.run(
+      [sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '5', '--warmup',
+       '2', '--workload', 'cfg2', '--no-cpu-baseline', '--no-extra', '--traffic', 'off'],
+      env=env, capture_output=True, text=True, timeout=600)
+  assert out.returncode == 0, out.stderr[-2000:]
+  rec = _one_json_line(out)
+  assert rec['n_gpus'] == 1 and rec['steps'] == 5 and rec['warmup'] == 2
+  assert rec['unit'] == 'views/s' and rec['value'] > 0
+  rf = rec['roofline']
+  assert rf['bound'] == 'hbm' and rf['kernel'] == 'splat_stream2_kernel'
+  assert abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-9
+  assert rec['config']['launch'] == 'graph'
+
+
+def test_bench_line_as_a_rank_of_torch_distributed_run(built_lib):
+  """The driver's N > 1 command with N = 1 (one GPU here): RCCL comes up, its
+  banner stays off stdout, the barriers and the max-over-ranks run, the steps
+  are captured into a HIP graph with the process group alive."""
+  if not torch.cuda.is_available():
+    pytest.fail('gpu test selected but no ROCm device is visible')
+  env = {k: v for k, v in os.environ.items()
+         if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+  out = subprocess.run(
+      [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+       '--nproc-per-node', '1', '--master-addr', '127.0.0.1', '--master-port',
+       str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps',
+       '5', '--warmup', '2', '--workload', 'cfg2', '--no-cpu-baseline',
+       '--no-extra', '--traffic', 'off'],
+      env=env, capture_output=True, text=True, timeout=900)
+  assert out.returncode == 0, out.stderr[-2000:]
+  rec = _one_json_line(out)
+  assert rec['n_gpus'] == 1 and rec['scaling'] == 'weak'
+  assert rec['config']['launch'] == 'graph'
+  per_rank = rec['roofline']['avg_launch_us_per_rank']
+  assert per_rank['min'] <= per_rank['max']
