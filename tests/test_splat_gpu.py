@@ -1269,3 +1269,40 @@ def test_stream_renders_the_target_disparity_of_rectified_pairs(w, packed, dev):
     np.testing.assert_allclose(got[0], other[0], rtol=0, atol=IMG_ATOL)
     np.testing.assert_allclose(got[1], other[1], rtol=WTS_RTOL, atol=0)
     np.testing.assert_allclose(got[2], other[2], rtol=DSP_RTOL, atol=1e-7)
+
+
+@pytest.mark.parametrize('shape', [(1, 1, 37, 256, 1.0), (2, 3, 18, 768, 0.5),
+                                   (4, 1, 40, 512, 0.25), (2, 2, 8, 256, 0.5)])
+def test_streamed_backward_shapes_and_scales(shape, dev, monkeypatch):
+  """The streamed backward against the gather kernel over target scales 1 /
+  0.5 / 0.25, one to three row segments, band remainders (H not a multiple of
+  the band height), one layer, several batch elements with their own matrices;
+  compose and both-output modes."""
+  from lsi.geometry import ldi
+  nl, b, h, w, s = shape
+  tex, disp, _, mat = _rectified_case(200 + h, nl, b, h, w)
+  bg, md, zb = 1e-3, 0.4, 50.0
+  kw = dict(trg_downsampling=s, bg_layer_disp=bg, max_disp=md, zbuf_scale=zb)
+
+  def run(stream, both):
+    monkeypatch.setenv('LSI_BWD_STREAM', '1' if stream else '0')
+    t32 = [torch.tensor(x, device=dev, requires_grad=True) for x in (tex, disp)]
+    g = torch.Generator().manual_seed(3)
+    if both:
+      outs = list(ldi.forward_splat_both([t32[0], None, t32[1]], torch.tensor(mat), **kw))
+    else:
+      outs = list(ldi.forward_splat_matrix([t32[0], None, t32[1]], torch.tensor(mat),
+                                           compose_layers=True, **kw))
+    loss = 0
+    for o in outs:
+      c = torch.rand(o.shape, generator=g).to(dev)
+      loss = loss + ((o if o.shape[-1] == 3 else torch.log(o) * 1e-3) * c).sum()
+    loss.backward()
+    return [t.grad.cpu().double().numpy() for t in t32]
+
+  for both in (False, True):
+    got, old = run(True, both), run(False, both)
+    for a, o, name in zip(got, old, ('tex', 'disp')):
+      assert np.isfinite(a).all(), name
+      scale = np.abs(o).max() + 1e-30
+      assert np.abs(a - o).max() <= 2e-5 * scale, (name, both, np.abs(a - o).max() / scale)
