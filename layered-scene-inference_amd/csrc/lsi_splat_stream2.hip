@@ -90,10 +90,12 @@ __device__ __forceinline__ int s2_div_small(int n, int d, float rcp) {
 // so that the units in flight merge into different tile rows; short bands keep
 // the natural order).
 struct BandOrder {
-  int nsrc, nrow_pad, q5, nunit, nsplit, nfull, lsub, ntask;
+  int nsrc, nrow_pad, q5, nunit, nsplit, nfull, lsub, ntask, rot;
   float inv_nsplit;
 };
-__device__ __forceinline__ BandOrder s2_band_order(const S2Args& a, int nsrc) {
+// `wg`: a number that differs between workgroups (S2X_STAGGER builds: every
+// workgroup walks its units from another starting point)
+__device__ __forceinline__ BandOrder s2_band_order(const S2Args& a, int nsrc, int wg = 0) {
   BandOrder o;
   o.nsrc = nsrc;
   o.nrow_pad = a.ilv ? (nsrc + 4) / 5 * 5 : nsrc;
@@ -104,11 +106,21 @@ __device__ __forceinline__ BandOrder s2_band_order(const S2Args& a, int nsrc) {
   o.lsub = max(a.lsub, 1);
   o.ntask = o.nfull + o.nsplit * ((a.L + o.lsub - 1) / o.lsub);
   o.inv_nsplit = __builtin_amdgcn_rcpf((float)max(o.nsplit, 1));
+#ifdef S2X_STAGGER
+  o.rot = o.nfull > 0 ? (int)((unsigned)wg % (unsigned)o.nfull) : 0;
+#else
+  o.rot = 0;
+#endif
   return o;
 }
 __device__ __forceinline__ Unit s2_unit_of(const S2Args& a, const BandOrder& o, int tg) {
   Unit un;
-  if (tg < o.nfull) { un.u = tg; un.l0 = 0; un.nl = a.L; return un; }
+  if (tg < o.nfull) {
+    un.u = tg + o.rot;
+    if (un.u >= o.nfull) un.u -= o.nfull;
+    un.l0 = 0; un.nl = a.L;
+    return un;
+  }
   const int j = tg - o.nfull;
   const int part = s2_div_small(j, o.nsplit, o.inv_nsplit);
   un.u = o.nfull + (j - part * o.nsplit);
@@ -427,7 +439,7 @@ __global__ __launch_bounds__(MAXT) void splat_stream2_kernel(S2Args a) {
     const float inv_s = __builtin_amdgcn_rcpf(a.s);
     const int ylo_g = (int)fminf(fmaxf(ceilf(((float)k_lo + 0.5f) * inv_s - 0.5f), 0.0f), (float)H);
     const int yhi_g = (int)fminf(fmaxf(ceilf(((float)k_hi + 1.5f) * inv_s - 0.5f), 0.0f), (float)H) - 1;
-    const BandOrder bg = s2_band_order(a, max(0, yhi_g - ylo_g + 1));
+    const BandOrder bg = s2_band_order(a, max(0, yhi_g - ylo_g + 1), b * 29 + band * 13);
     g_aim = s2_own_unit(a, bg, wave);
     g_y = ylo_g + g_aim.yr;
     if (g_aim.nl) aim(g_y, g_aim.sg, g_aim.l0);
@@ -517,7 +529,7 @@ __global__ __launch_bounds__(MAXT) void splat_stream2_kernel(S2Args a) {
   }
   y_lo = S2_RFL(y_lo); y_hi = S2_RFL(y_hi);
   const int nsrc = (y_hi >= y_lo) ? (y_hi - y_lo + 1) : 0;
-  const BandOrder bo = s2_band_order(a, nsrc);
+  const BandOrder bo = s2_band_order(a, nsrc, b * 29 + band * 13);
   const int ntask = bo.ntask;
   // the table holds a.cap tickets: one chunk unless the band has more source
   // rows than the planner assumed (it does not see the matrices)

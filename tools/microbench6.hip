@@ -15,7 +15,8 @@ template <int DEPTH>
 __global__ __launch_bounds__(1024) void rd(const float* __restrict__ tex,
                                            const float* __restrict__ disp, float* out,
                                            int L, int B, int H, int W, int rows_per_band,
-                                           int halo, int alu, int order, int b0, int touch) {
+                                           int halo, int alu, int order, int b0, int touch,
+                                           int stagger, int padpx) {
   extern __shared__ char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, NW = blockDim.x >> 6;
   const int nbands = H / rows_per_band;
@@ -31,13 +32,18 @@ __global__ __launch_bounds__(1024) void rd(const float* __restrict__ tex,
   const int nitem_w = ((ntask - wave + NW - 1) / NW) * L;  // this wave's items
   auto issue = [&](Set& s, int j) {
     if (j >= nitem_w) j = 0;  // harmless re-read
-    const int t = wave + NW * (j / L), l = j % L;
+    int t = wave + NW * (j / L);
+    const int l = j % L;
+    // stagger: every workgroup walks its tasks from another starting point, so
+    // that the 256 workgroups do not read the same offset of their images at
+    // the same time (addresses 2^k * 9 bytes apart: the same HBM channels?)
+    if (stagger) t = (t + (b * 29 + band * 13) * stagger) % ntask;
     int r = t / nseg, sg = t % nseg;
     if (order) {  // rows a fifth of the band apart
       const int q5 = (nrow + 4) / 5;
       r = min((r % 5) * q5 + r / 5, nrow - 1);
     }
-    const long px = (((long)l * 32 + b) * H + (ya + r)) * W + sg * 256 + 4 * lane;
+    const long px = ((long)l * 32 + b) * ((long)H * W + padpx) + (long)(ya + r) * W + sg * 256 + 4 * lane;
     const float4* pd = reinterpret_cast<const float4*>(disp + px);
     const float4* pt = reinterpret_cast<const float4*>(tex + 3 * px);
     s.d = pd[0]; s.t0 = pt[0]; s.t1 = pt[1]; s.t2 = pt[2];
@@ -87,7 +93,7 @@ __global__ __launch_bounds__(1024) void rd(const float* __restrict__ tex,
 static const size_t npx_set = (size_t)4 * 32 * 256 * 768;
 template <int DEPTH>
 void run(const float* tex, const float* disp, float* out, int B, int threads, int rpb, int halo,
-         int alu, int order, int lds, int touch = 0) {
+         int alu, int order, int lds, int touch = 0, int stagger = 0, int padpx = 0) {
   const int L = 4, H = 256, W = 768;
   const int grid = B * (H / rpb);
   const double bytes = (double)L * B * H * W * 16;
@@ -99,16 +105,17 @@ void run(const float* tex, const float* disp, float* out, int B, int threads, in
   const int nrot = 2 * 32 / B;
   for (int rep = 0; rep < (B == 32 ? 5 : 24); ++rep) {
     const int r = rep % nrot;
-    const float* tx = tex + (size_t)(r * B / 32) * npx_set * 3;
-    const float* dp = disp + (size_t)(r * B / 32) * npx_set;
+    const size_t set_px = npx_set + (size_t)4 * 32 * padpx;
+    const float* tx = tex + (size_t)(r * B / 32) * set_px * 3;
+    const float* dp = disp + (size_t)(r * B / 32) * set_px;
     (void)hipEventRecord(e0);
-    rd<DEPTH><<<grid, threads, lds>>>(tx, dp, out, L, B, H, W, rpb, halo, alu, order, (r * B) % 32, touch);
+    rd<DEPTH><<<grid, threads, lds>>>(tx, dp, out, L, B, H, W, rpb, halo, alu, order, (r * B) % 32, touch, stagger, padpx);
     (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
     float ms; (void)hipEventElapsedTime(&ms, e0, e1);
     if (rep > 1 && ms < best) best = ms;
   }
-  printf("B %2d depth %d touch %2d threads %4d rows/band %2d halo %d alu %3d order %d lds %3dK: %7.1f us  %5.2f TB/s (useful)\n",
-         B, DEPTH, touch, threads, rpb, halo, alu, order, lds / 1024, best * 1e3, bytes / (best * 1e-3) / 1e12);
+  printf("B %2d depth %d touch %2d threads %4d rows/band %2d halo %d alu %3d order %d lds %3dK stagger %d pad %5d: %7.1f us  %5.2f TB/s (useful)\n",
+         B, DEPTH, touch, threads, rpb, halo, alu, order, lds / 1024, stagger, padpx, best * 1e3, bytes / (best * 1e-3) / 1e12);
 }
 
 int main() {
@@ -116,10 +123,30 @@ int main() {
   const size_t npx = (size_t)L * Bmax * H * W;
   // two input sets so that consecutive launches do not hit the Infinity Cache
   float *tex, *disp, *out;
-  (void)hipMalloc(&tex, npx * 12 * 2 + (1 << 20)); (void)hipMalloc(&disp, npx * 4 * 2 + (1 << 20));
+  const size_t padmax = (size_t)L * Bmax * 8192;  // room for padded batch strides
+  (void)hipMalloc(&tex, (npx + padmax) * 12 * 2 + (1 << 20)); (void)hipMalloc(&disp, (npx + padmax) * 4 * 2 + (1 << 20));
   (void)hipMalloc(&out, 4096);
   (void)hipMemset(tex, 0, npx * 12 * 2); (void)hipMemset(disp, 0, npx * 4 * 2);
   const int K = 1024;
+  if (getenv("MB6_STAGGER")) {
+    printf("--- staggered task order / padded batch stride, B=32\n");
+    for (int rep = 0; rep < 2; ++rep)
+      for (int alu : {0, 40, 75}) {
+        run<2>(tex, disp, out, 32, 768, 32, 1, alu, 1, 100 * K, 0, 0, 0);
+        run<2>(tex, disp, out, 32, 768, 32, 1, alu, 1, 100 * K, 0, 1, 0);
+        run<2>(tex, disp, out, 32, 768, 32, 1, alu, 1, 100 * K, 0, 3, 0);
+        run<2>(tex, disp, out, 32, 768, 32, 1, alu, 1, 100 * K, 0, 0, 1088);
+        run<2>(tex, disp, out, 32, 768, 32, 1, alu, 1, 100 * K, 0, 0, 4160);
+        run<2>(tex, disp, out, 32, 768, 32, 1, alu, 1, 100 * K, 0, 1, 4160);
+      }
+    printf("--- B=4\n");
+    for (int alu : {0, 40}) {
+      run<2>(tex, disp, out, 4, 768, 4, 1, alu, 0, 100 * K, 0, 0, 0);
+      run<2>(tex, disp, out, 4, 768, 4, 1, alu, 0, 100 * K, 0, 1, 0);
+      run<2>(tex, disp, out, 4, 768, 4, 1, alu, 0, 100 * K, 0, 0, 4160);
+    }
+    return 0;
+  }
   if (getenv("MB6_TOUCH")) {
     printf("--- touch prefetch, B=4, 4 rows per band + halo (256 WGs)\n");
     for (int alu : {0, 40, 75}) {
