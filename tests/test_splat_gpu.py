@@ -1306,3 +1306,17 @@ def test_streamed_backward_shapes_and_scales(shape, dev, monkeypatch):
       assert np.isfinite(a).all(), name
       scale = np.abs(o).max() + 1e-30
       assert np.abs(a - o).max() <= 2e-5 * scale, (name, both, np.abs(a - o).max() / scale)
+
+
+def test_differential_fuzz_of_the_round3_kernels(dev):
+  """tools/fuzz_compact.py, 60 random rectified configurations: compact STREAM
+  instance (compose / both / compose + disparity; separate tensors or RGBD
+  pixels; folds, NaN / Inf, flipped rows, shifts past the window) against the
+  any-pose path, streamed backward against the gather kernel."""
+  import subprocess
+  import sys
+  from conftest import ROOT
+  out = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'fuzz_compact.py'),
+                        '60', '1234'], capture_output=True, text=True, timeout=900)
+  assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+  assert 'fuzz_compact: 60 cases' in out.stdout

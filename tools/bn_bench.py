@@ -26,23 +26,34 @@ for c, h, w in SHAPES:
   gy = torch.randn(4, c, h, w, device=dev, dtype=dt).contiguous(memory_format=torch.channels_last)
   def fwd(i):
     return _hip_bn.batch_norm_relu(xs[i % nbuf], beta)
-  for i in range(3):
-    fwd(i).backward(gy)
-  torch.cuda.synchronize()
-  iters = 40
-  e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-  ys = []
-  e[0].record()
-  for i in range(iters):
-    ys.append(fwd(i))
-  e[1].record()
-  for i in range(iters):
-    ys[i].backward(gy)
-  e[2].record()
-  torch.cuda.synchronize()
-  tf = e[0].elapsed_time(e[1]) * 1e3 / iters
-  tb = e[1].elapsed_time(e[2]) * 1e3 / iters
+  iters = 20
+  side = torch.cuda.Stream(dev)
+  side.wait_stream(torch.cuda.current_stream(dev))
+  with torch.cuda.stream(side):
+    for i in range(3):
+      fwd(i).backward(gy)
+    side.synchronize()
+    # GPU time only: the calls captured into HIP graphs (eager calls are
+    # host-bound at these sizes)
+    g_f, g_fb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g_f, stream=side):
+      for i in range(iters):
+        fwd(i)
+    with torch.cuda.graph(g_fb, stream=side):
+      for i in range(iters):
+        fwd(i).backward(gy)
+    times = []
+    for g in (g_f, g_fb):
+      g.replay(); side.synchronize()
+      e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+      e0.record(side)
+      for _ in range(5):
+        g.replay()
+      e1.record(side)
+      side.synchronize()
+      times.append(e0.elapsed_time(e1) * 1e3 / (5 * iters))
+  tf, tb = times[0], times[1] - times[0]
   nb = 4 * c * h * w * es
-  rows.append({'C': c, 'hw': [h, w], 'MB': nb / 1e6, 'fwd_us': tf, 'bwd_us': tb,
-               'fwd_GBps': 3 * nb / tf / 1e3, 'bwd_GBps': 5 * nb / tb / 1e3})
+  rows.append({'C': c, 'hw': [h, w], 'MB': round(nb / 1e6, 2), 'fwd_us': round(tf, 2), 'bwd_us': round(tb, 2),
+               'fwd_GBps': round(3 * nb / tf / 1e3), 'bwd_GBps': round(5 * nb / tb / 1e3)})
   print(json.dumps(rows[-1]))

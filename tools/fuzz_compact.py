@@ -1,0 +1,111 @@
+"""Differential fuzz of the round-3 kernels over random rectified configurations:
+  * compact STREAM instance (compose / both outputs / compose + target
+    disparity; separate tensors or RGBD pixels) against the any-pose TILE path;
+  * streamed backward (compose and both-output modes) against the
+    one-thread-per-pixel gather kernel (LSI_BWD_STREAM=0).
+Bars as in tests/test_splat_gpu.py.   python tools/fuzz_compact.py [n] [seed]"""
+import os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'layered-scene-inference_amd'))
+from lsi import _C
+from lsi.geometry import ldi
+dev = torch.device('cuda:0')
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 97)
+IMG_ATOL, WTS_RTOL, DSP_RTOL = 2e-5, 1e-4, 1e-4
+worst = dict(img=0.0, wts=0.0, dsp=0.0, grad=0.0)
+stream_hits = 0
+for it in range(n):
+  nl = int(rs.choice([1, 2, 3, 4, 6]))
+  b = int(rs.choice([1, 2, 3, 5]))
+  s = float(rs.choice([0.5, 0.5, 1.0, 0.25]))
+  inv = int(round(1 / s))
+  h = int(rs.choice([4, 12, 36, 64, 100, 256])) // inv * inv
+  h = max(h, inv)
+  w = int(rs.choice([256, 256, 512, 768, 1024]))
+  dmax = float(rs.choice([0.4, 1.0]))
+  pred = rs.rand(nl, b, h, w, 4).astype(np.float32)
+  kind = rs.choice(['noise', 'smooth', 'const', 'steep'])
+  if kind == 'noise':
+    pred[..., 3] = pred[..., 3] * dmax * rs.choice([0.6, 1.0, 1.3]) - rs.choice([0.0, 0.05])
+  elif kind == 'smooth':
+    yy, xx = np.mgrid[0:h, 0:w]
+    base = 0.5 + 0.4 * np.sin(xx / rs.uniform(20, 200) + rs.uniform(0, 6)) * np.cos(yy / rs.uniform(10, 100))
+    pred[..., 3] = (base[None, None] * dmax * (0.2 + 0.8 * rs.rand(nl, b, 1, 1))).astype(np.float32)
+  elif kind == 'const':
+    pred[..., 3] = (0.1 + 0.8 * rs.rand(nl, b, 1, 1)) * dmax
+  else:  # folds: the target column runs back and forth every few pixels
+    pred[..., 3] = dmax * (0.5 + 0.5 * np.sin(np.arange(w) / rs.uniform(0.7, 3.0)))[None, None, None, :]
+  bad = np.zeros((nl, b, h, w), bool)
+  if rs.rand() < 0.3:
+    bad = rs.rand(nl, b, h, w) < 0.01
+    pred[..., 3][bad] = np.where(rs.rand(int(bad.sum())) < 0.5, np.nan, np.inf)
+  mats = []
+  for _ in range(b):
+    m = np.eye(4)
+    m[0, 0] = rs.uniform(0.8, 1.25); m[0, 1] = rs.normal(0, 0.03)
+    m[0, 2] = rs.uniform(-30, 30); m[0, 3] = rs.uniform(-1, 1) * rs.choice([5, 60, 300])
+    m[1, 1] = rs.choice([1.0, 1.0, rs.uniform(0.7, 1.4), -1.0]); m[1, 2] = rs.uniform(-3, 3) + (h if m[1, 1] < 0 else 0)
+    mats.append(m)
+  mat = torch.tensor(np.stack(mats).astype(np.float32))
+  zb = float(rs.choice([10.0, 50.0])); bg = float(rs.choice([1e-3, 0.2]) * dmax)
+  kw = dict(trg_downsampling=s, bg_layer_disp=bg, max_disp=dmax, zbuf_scale=zb)
+  packed = rs.rand() < 0.5
+  mode = rs.choice(['compose', 'both', 'disp'])
+
+  def inputs(requires_grad):
+    p = torch.tensor(pred, device=dev, requires_grad=requires_grad)
+    tex, disp = p[..., 0:3], p[..., 3:4]
+    if not packed:
+      tex, disp = tex.contiguous(), disp.contiguous()
+    return p, tex, disp
+
+  def render(path, tex, disp):
+    if mode == 'both':
+      return list(ldi.forward_splat_both([tex, None, disp], mat, path=path, **kw))
+    return list(ldi.forward_splat_matrix([tex, None, disp], mat, compose_layers=True,
+                                         compute_trg_disp=(mode == 'disp'), path=path, **kw))
+
+  _, tex, disp = inputs(False)
+  d = ldi._desc(tex, None, disp, int(h * s), int(w * s), s, dmax, zb, 0.1,
+                _C.LSI_COMPOSE if mode != 'both' else 0, 0)
+  if mode == 'disp':
+    d.flags |= _C.LSI_WANT_DISP
+  is_stream = ldi.select_path(d, mat, 'auto') == _C.LSI_PATH_STREAM
+  stream_hits += int(is_stream)
+  got = [t.cpu().numpy() for t in render('auto', tex, disp)]
+  ref = [t.cpu().numpy() for t in render('tile', tex, disp)]
+  tag = 'it %d L%d B%d %dx%d s%g %s %s packed=%d stream=%d' % (it, nl, b, h, w, s, kind, mode, packed, is_stream)
+  for k, (a, r) in enumerate(zip(got, ref)):
+    assert np.isfinite(a).all(), tag
+    if a.shape[-1] == 3:
+      e = float(np.abs(a - r).max()); worst['img'] = max(worst['img'], e)
+      assert e <= IMG_ATOL, (tag, 'img', e)
+    elif mode == 'disp' and k == 2:
+      e = float((np.abs(a - r) / (np.abs(r) + 1e-7 / DSP_RTOL)).max()); worst['dsp'] = max(worst['dsp'], e)
+      assert e <= DSP_RTOL, (tag, 'disp', e)
+    else:
+      e = float((np.abs(a - r) / np.abs(r)).max()); worst['wts'] = max(worst['wts'], e)
+      assert e <= WTS_RTOL, (tag, 'wts', e)
+  if mode == 'disp':
+    continue
+  grads = {}
+  for stream in ('1', '0'):
+    os.environ['LSI_BWD_STREAM'] = stream
+    p, tex, disp = inputs(True)
+    outs = render('auto', tex, disp)
+    g = torch.Generator().manual_seed(it)
+    loss = 0
+    for o in outs:
+      c = torch.rand(o.shape, generator=g).to(dev)
+      loss = loss + ((o if o.shape[-1] == 3 else torch.log(o) * 1e-3) * c).sum()
+    loss.backward()
+    grads[stream] = p.grad.cpu().double().numpy()
+  os.environ['LSI_BWD_STREAM'] = '1'
+  assert np.isfinite(grads['1']).all(), tag
+  scale = np.abs(grads['0']).max() + 1e-30
+  e = float(np.abs(grads['1'] - grads['0']).max() / scale); worst['grad'] = max(worst['grad'], e)
+  assert e <= 2e-5, (tag, 'grad', e)
+  assert (grads['1'][..., 3][bad] == 0).all(), tag
+print('fuzz_compact: %d cases (%d on STREAM) ok; worst' % (n, stream_hits), worst)
