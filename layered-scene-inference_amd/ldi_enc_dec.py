@@ -88,6 +88,9 @@ def build_parser():
   a('--n_obj_max', type=int, default=4)
   a('--n_box_planes', type=int, default=5)
   a('--bf16', type=_bool, default=False, help='bf16 autocast for the convs')
+  a('--batched_pairs', type=_bool, default=True,
+    help='source and target images go through the network in one pass, every '
+    'batch norm with separate statistics per view (same arithmetic as two passes)')
   a('--flat_grads', type=_bool, default=False,
     help='data parallel without the DDP wrapper: one flat gradient buffer, one '
     'all-reduce per step (implied by --hip_graph with more than one rank)')
@@ -145,15 +148,27 @@ class LdiNet(torch.nn.Module):
         skip_channels=self.enc_dec.skip_channels,
         pred_masks=opts.pred_ldi_masks)
     self.max_disp = opts.max_disp
+    # (the `fc` stack of the complete TF parameter set sees the batch as one)
+    self.batched_pairs = bool(getattr(opts, 'batched_pairs', True))
 
   def predict(self, imgs):
     _, feat_dec, skip_feat, _ = self.enc_dec(imgs)
-    tex, masks, disps = self.ldi_tex_disp(feat_dec, skip_feat)
-    return [tex.float(), None if masks is None else masks.float(),
-            disps.float() * self.max_disp]
+    # float32 LDI, disparities scaled by max_disp (ldi_enc_dec.py:203-205)
+    return self.ldi_tex_disp(feat_dec, skip_feat, disp_scale=self.max_disp)
 
   def forward(self, imgs_src, imgs_trg):
-    return self.predict(imgs_src), self.predict(imgs_trg)
+    if not self.batched_pairs or imgs_src.shape != imgs_trg.shape:
+      return self.predict(imgs_src), self.predict(imgs_trg)
+    # One pass over [src; trg]: every batch norm keeps separate statistics for
+    # the two halves (nets.bn_groups), so the result is the reference's two
+    # passes (ldi_enc_dec.py:175-228) with half the kernel launches and the
+    # convolutions at twice the batch.  The halves come back as views.
+    b = imgs_src.shape[0]
+    with nets.bn_groups(2):
+      tex, masks, disps = self.predict(torch.cat([imgs_src, imgs_trg], dim=0))
+    half = lambda t, k: None if t is None else t[:, k * b:(k + 1) * b]
+    return ([half(tex, 0), half(masks, 0), half(disps, 0)],
+            [half(tex, 1), half(masks, 1), half(disps, 1)])
 
 
 class SyntheticPairs(object):

@@ -24,12 +24,14 @@ def _workspace(dev, need):
   return ws
 
 
-def supported(x):
+def supported(x, groups=1):
   """Channels-last 4-D fp32 / bf16 CUDA tensor whose channel count the kernels
-  take (lsi_hip.h)."""
+  take (lsi_hip.h); `groups` sub-batches along N with their own statistics."""
   if not (x.is_cuda and x.dim() == 4 and x.dtype in (torch.float32, torch.bfloat16)):
     return False
   n, c, h, w = x.shape
+  if groups < 1 or n % groups:
+    return False
   nv = 8 if x.dtype == torch.bfloat16 else 4
   if c % nv or c > 2048:
     return False
@@ -42,24 +44,28 @@ def supported(x):
 class _BnRelu(torch.autograd.Function):
 
   @staticmethod
-  def forward(ctx, x, beta, eps, relu):
+  def forward(ctx, x, beta, eps, relu, groups):
     if not x.is_cuda:
       raise RuntimeError('fused batch norm needs a tensor on a ROCm GPU')
     dev = x.device
     n, c, h, w = x.shape
-    npix = n * h * w
+    npix = (n // groups) * h * w          # per group: its own statistics
     bf16 = int(x.dtype == torch.bfloat16)
     lib = _C.lib()
     ws = _workspace(dev, int(lib.lsi_bn_workspace_floats(npix, c, bf16)))
     y = torch.empty_like(x, memory_format=torch.channels_last)
-    mean_rstd = torch.empty((2, c), dtype=torch.float32, device=dev)
+    mean_rstd = torch.empty((groups, 2, c), dtype=torch.float32, device=dev)
     beta_f = beta.detach().float().contiguous()
-    rc = lib.lsi_bn_relu_fwd(_C.ptr(x), _C.ptr(y), _C.ptr(beta_f), _C.ptr(ws),
-                             _C.ptr(mean_rstd), npix, c, bf16, int(relu),
-                             float(eps), _C.stream_ptr(dev))
-    _C.check(rc, 'lsi_bn_relu_fwd')
+    step = npix * c * x.element_size()    # bytes of one group (N-major storage)
+    for g in range(groups):
+      rc = lib.lsi_bn_relu_fwd(x.data_ptr() + g * step, y.data_ptr() + g * step,
+                               _C.ptr(beta_f), _C.ptr(ws), _C.ptr(mean_rstd[g]),
+                               npix, c, bf16, int(relu), float(eps),
+                               _C.stream_ptr(dev))
+      _C.check(rc, 'lsi_bn_relu_fwd')
     ctx.save_for_backward(x, beta_f, mean_rstd)
     ctx.relu = int(relu)
+    ctx.groups = groups
     return y
 
   @staticmethod
@@ -67,21 +73,27 @@ class _BnRelu(torch.autograd.Function):
     x, beta_f, mean_rstd = ctx.saved_tensors
     dev = x.device
     n, c, h, w = x.shape
-    npix = n * h * w
+    groups = ctx.groups
+    npix = (n // groups) * h * w
     bf16 = int(x.dtype == torch.bfloat16)
     dy = dy.to(x.dtype).contiguous(memory_format=torch.channels_last)
     lib = _C.lib()
     ws = _workspace(dev, int(lib.lsi_bn_workspace_floats(npix, c, bf16)))
     dx = torch.empty_like(x, memory_format=torch.channels_last)
-    dbeta = torch.empty((c,), dtype=torch.float32, device=dev)
-    rc = lib.lsi_bn_relu_bwd(_C.ptr(x), _C.ptr(dy), _C.ptr(mean_rstd),
-                             _C.ptr(beta_f), _C.ptr(dx), _C.ptr(dbeta), _C.ptr(ws),
-                             npix, c, bf16, ctx.relu, _C.stream_ptr(dev))
-    _C.check(rc, 'lsi_bn_relu_bwd')
-    return dx, dbeta, None, None
+    dbeta = torch.empty((groups, c), dtype=torch.float32, device=dev)
+    step = npix * c * x.element_size()
+    for g in range(groups):
+      rc = lib.lsi_bn_relu_bwd(x.data_ptr() + g * step, dy.data_ptr() + g * step,
+                               _C.ptr(mean_rstd[g]), _C.ptr(beta_f),
+                               dx.data_ptr() + g * step, _C.ptr(dbeta[g]),
+                               _C.ptr(ws), npix, c, bf16, ctx.relu,
+                               _C.stream_ptr(dev))
+      _C.check(rc, 'lsi_bn_relu_bwd')
+    return dx, (dbeta.sum(0) if groups > 1 else dbeta[0]), None, None, None
 
 
-def batch_norm_relu(x, beta, eps=1e-3, relu=True):
+def batch_norm_relu(x, beta, eps=1e-3, relu=True, groups=1):
   """relu(batch_norm(x) + beta) with batch statistics (slim.batch_norm,
-  scale=False) for a channels-last N x C x H x W tensor; same dtype out."""
-  return _BnRelu.apply(x, beta, eps, relu)
+  scale=False) for a channels-last N x C x H x W tensor; same dtype out.
+  groups > 1: N is that many sub-batches, each normalised on its own."""
+  return _BnRelu.apply(x, beta, eps, relu, groups)

@@ -48,13 +48,49 @@ BF16_BATCH_NORM = os.environ.get('LSI_BF16_BN', '1') != '0'
 FUSED_BN = os.environ.get('LSI_FUSED_BN', '1') != '0'
 
 
+# Batch-statistics groups: the reference runs the network once on the source and
+# once on the target images (ldi_enc_dec.py:175-228), so every batch norm sees
+# one view's images only.  Inside `bn_groups(g)` a batch is g such sub-batches
+# stacked along N, and every batch norm normalises each with its own statistics:
+# the two passes become one (half the kernel launches, convolutions at twice the
+# batch) with the same arithmetic.
+_BN_GROUPS = [1]
+
+
+class bn_groups(object):
+  """with bn_groups(2): net(torch.cat([src, trg]))  ==  net(src), net(trg)."""
+
+  def __init__(self, groups):
+    self.groups = int(groups)
+
+  def __enter__(self):
+    self.saved = _BN_GROUPS[0]
+    _BN_GROUPS[0] = self.groups
+    return self
+
+  def __exit__(self, *exc):
+    _BN_GROUPS[0] = self.saved
+    return False
+
+
+def _per_group(fn, x):
+  """fn on each of the _BN_GROUPS[0] sub-batches of x (views), concatenated."""
+  g = _BN_GROUPS[0]
+  if g <= 1:
+    return fn(x)
+  if x.shape[0] % g:
+    raise ValueError('batch %d does not split into %d batch-norm groups' %
+                     (x.shape[0], g))
+  return torch.cat([fn(c) for c in x.chunk(g, dim=0)], dim=0)
+
+
 def _bn_relu(bn, x):
   """relu(bn(x)): two HIP passes forward, two backward (statistics, normalise +
   ReLU + store in x's dtype) where the layout allows, else torch / MIOpen."""
   if FUSED_BN and bn.is_training and x.is_cuda:
     from lsi.nnutils import _hip_bn  # pylint: disable=g-import-not-at-top
-    if _hip_bn.supported(x):
-      return _hip_bn.batch_norm_relu(x, bn.beta, bn.eps, True)
+    if _hip_bn.supported(x, _BN_GROUPS[0]):
+      return _hip_bn.batch_norm_relu(x, bn.beta, bn.eps, True, _BN_GROUPS[0])
   return F.relu(bn(x))
 
 
@@ -73,6 +109,11 @@ class SlimBatchNorm(nn.Module):
     self.is_training = True
 
   def forward(self, x):
+    if self.is_training and _BN_GROUPS[0] > 1:
+      return _per_group(self._forward, x)
+    return self._forward(x)
+
+  def _forward(self, x):
     # Under bf16 autocast the large maps stay in bf16 (MIOpen computes the
     # statistics in fp32 internally; gamma / beta are fp32): no cast to fp32 and
     # back around every batch norm, which was a tenth of the bf16 step
@@ -173,8 +214,9 @@ class SlimFC(nn.Module):
   def forward(self, x):
     x = self.fc(x)
     if self.is_training:
-      return F.relu(F.batch_norm(x, None, None, self.gamma, self.beta, True, 0.0,
-                                 self.eps))
+      return _per_group(
+          lambda c: F.relu(F.batch_norm(c, None, None, self.gamma, self.beta,
+                                        True, 0.0, self.eps)), x)
     return F.relu(F.batch_norm(x, self.moving_mean, self.moving_variance,
                                self.gamma, self.beta, False, 0.0, self.eps))
 
@@ -304,14 +346,33 @@ class LdiPredictor(nn.Module):
     self.pixelwise_pred = PixelwisePredictor(
         cin, nc=nc, n_layers=n_layers, n_layerwise_steps=n_layerwise_steps,
         skip_channels=skip_channels)
+    # per-channel factors of the RGBD prediction (1, 1, 1, disp_scale); not a
+    # parameter, not in the checkpoint
+    self.register_buffer('_scale4', torch.ones(4), persistent=False)
+    self._scale4_value = 1.0
 
-  def forward(self, feat, skip_feat=None):
+  def forward(self, feat, skip_feat=None, disp_scale=None):
+    """disp_scale (optional): the disparities come back multiplied by it, as
+    float32 (ldi_enc_dec.py:203-205 scales the network's disparities by
+    max_disp).  Without masks the scaling is ONE multiply of the whole
+    L x B x H x W x 4 prediction, so textures and disparities stay views of one
+    buffer of RGBD pixels -- the layout the renderer reads with one 16-byte load
+    per pixel (LSI_PACKED_RGBD)."""
     pred = self.pixelwise_pred(feat, skip_feat)
     if self.pred_masks:
       tex, masks, disps = pred[..., 0:3], pred[..., 3:4], pred[..., 4:5]
       # the reference applies the sigmoid a second time here (nets.py:202)
       masks = nn_helpers.enforce_bg_occupied(torch.sigmoid(masks))
+      if disp_scale is not None:
+        tex, masks, disps = tex.float(), masks.float(), disps.float() * disp_scale
     else:
+      if disp_scale is not None:
+        # (the factors live on the device: no host copy, nothing a captured HIP
+        # graph could not hold)
+        if float(self._scale4_value) != float(disp_scale):
+          self._scale4.copy_(torch.tensor([1.0, 1.0, 1.0, float(disp_scale)]))
+          self._scale4_value = float(disp_scale)
+        pred = pred.float() * self._scale4
       tex, disps = pred[..., 0:3], pred[..., 3:4]
       masks = None   # all ones (nets.py:204); None = ones for the renderer
     return [tex, masks, disps]

@@ -211,3 +211,38 @@ def test_resume_picks_the_newest_checkpoint_and_pretrain_restore(tmp_path):
   restored = train_utils.Trainer.optimistic_restore(b, a.state_dict())
   assert restored == ['0.bias', '0.weight']            # shapes of layer 1 differ
   assert torch.equal(b[0].weight, a[0].weight)
+
+
+def test_batched_pair_pass_equals_two_passes(tmp_path):
+  """LdiNet.forward runs source and target images through the network in ONE
+  pass with per-view batch-norm statistics (nets.bn_groups); the reference makes
+  two passes (ldi_enc_dec.py:175-228).  Same outputs, same gradients."""
+  script, opts = _opts(tmp_path)
+  torch.manual_seed(1)
+  net = script.LdiNet(opts)
+  src = torch.rand(2, 128, 128, 3)
+  trg = torch.rand(2, 128, 128, 3)
+  outs, grads = {}, {}
+  for mode in (True, False):
+    net.batched_pairs = mode
+    net.zero_grad()
+    a, b = net(src, trg)
+    assert a[0].shape == (2, 2, 128, 128, 3) and b[2].shape == (2, 2, 128, 128, 1)
+    outs[mode] = [a[0], a[2], b[0], b[2]]
+    (a[0].sum() + 2 * a[2].sum() + 3 * b[0].sum() + 4 * b[2].sum()).backward()
+    grads[mode] = [p.grad.clone() for p in net.parameters()]
+  for x, y in zip(outs[True], outs[False]):
+    torch.testing.assert_close(x, y, rtol=1e-4, atol=1e-5)
+  for x, y in zip(grads[True], grads[False]):
+    torch.testing.assert_close(x, y, rtol=2e-3, atol=1e-4 * float(y.abs().max()) + 1e-7)
+  # one batch-norm group per view: different statistics than the joint batch
+  with nets_module().bn_groups(1):
+    net.batched_pairs = False
+    joint = net.predict(torch.cat([src, trg], 0))
+  assert float((joint[0][:, :2] - outs[False][0]).abs().max()) > 1e-4
+
+
+def nets_module():
+  sys.path.insert(0, PKG)
+  from lsi.nnutils import nets
+  return nets

@@ -259,7 +259,7 @@ def test_fused_batch_norm_is_what_the_network_runs(tmp_path, built_lib):
     fused, _ = tr.train_step()
   finally:
     _hip_bn.batch_norm_relu = orig
-  assert len(calls) >= 40, len(calls)
+  assert len(calls) >= 30, len(calls)   # every conv layer, once (src and trg in one pass)
   nets.FUSED_BN = False
   try:
     tr2 = _trainer(tmp_path / 'b')
@@ -269,3 +269,33 @@ def test_fused_batch_norm_is_what_the_network_runs(tmp_path, built_lib):
     nets.FUSED_BN = True
   assert abs(float(fused) - float(plain)) <= 2e-3 * abs(float(plain)), (
       float(fused), float(plain))
+
+
+def test_batched_pair_pass_on_the_gpu_and_rgbd_output_layout(tmp_path, built_lib):
+  """One pass over [src; trg] with per-view batch-norm statistics (fused HIP
+  batch norm, groups = 2) equals two passes; and what the network hands to the
+  renderer is one buffer of RGBD pixels (textures and scaled disparities are
+  views of it), which the descriptor recognises (LSI_PACKED_RGBD)."""
+  from lsi import _C
+  from lsi.geometry import ldi
+  tr = _trainer(tmp_path)
+  net, dev = tr.model, tr.device
+  g = torch.Generator().manual_seed(2)
+  src = torch.rand(2, 128, 256, 3, generator=g).to(dev)
+  trg = torch.rand(2, 128, 256, 3, generator=g).to(dev)
+  outs, grads = {}, {}
+  for mode in (True, False):
+    net.batched_pairs = mode
+    net.zero_grad()
+    a, b = net(src, trg)
+    outs[mode] = [a[0], a[2], b[0], b[2]]
+    (a[0].sum() + 2 * a[2].sum() + 3 * b[0].sum() + 4 * b[2].sum()).backward()
+    grads[mode] = [p.grad.clone() for p in net.parameters()]
+    tex, disp = a[0], a[2]
+    d = ldi._desc(tex, None, disp, 64, 128, 0.5, 0.4, 50.0, 0.1, 0, 0)
+    assert d.flags & _C.LSI_PACKED_RGBD, (mode, tex.stride(), disp.stride())
+  for x, y in zip(outs[True], outs[False]):
+    torch.testing.assert_close(x, y, rtol=1e-3, atol=1e-4)
+  num = sum(float(((x - y) ** 2).sum()) for x, y in zip(grads[True], grads[False]))
+  den = sum(float((y ** 2).sum()) for y in grads[False])
+  assert num <= 1e-4 * den, num / den       # (MIOpen picks other kernels at batch 4 / 2)
