@@ -385,19 +385,24 @@ int lsi_compose_depth_fwd(int32_t L, int64_t N, const float* masks,
  * power of two <= 256, C <= 2048 -- else LSI_EINVAL.  Statistics in fp32
  * (shifted sums, fp32 device atomics across workgroups), biased variance
  * (tf.nn.moments).  relu = 0: batch norm only.
- *   workspace: lsi_bn_workspace_floats(npix, C, bf16) floats, ZERO-FILLED ONCE
- *   by the caller and then reusable by any later call on the same stream (the
- *   library leaves its counter and accumulators zero).
- *   mean_rstd: [2][C] out (forward), in (backward).  dbeta: [C] out.
+ *   groups: the npix x C arrays are `groups` such blocks stored one after the
+ *   other (sub-batches along N), each normalised with its own statistics -- the
+ *   reference runs its network once per view, so a batch holding both views
+ *   keeps two sets (one launch per pass for all groups).
+ *   workspace: lsi_bn_workspace_floats(npix, C, bf16, groups) floats,
+ *   ZERO-FILLED ONCE by the caller and then reusable by any later call on the
+ *   same stream (the library leaves its counters and accumulators zero).
+ *   mean_rstd: [groups][2][C] out (forward), in (backward).  dbeta:
+ *   [groups][C] out (the caller adds the groups).
  */
-size_t lsi_bn_workspace_floats(int64_t npix, int32_t C, int32_t bf16);
+size_t lsi_bn_workspace_floats(int64_t npix, int32_t C, int32_t bf16, int32_t groups);
 int lsi_bn_relu_fwd(const void* x, void* y, const float* beta, float* workspace,
                     float* mean_rstd, int64_t npix, int32_t C, int32_t bf16,
-                    int32_t relu, float eps, lsi_stream_t stream);
+                    int32_t relu, float eps, int32_t groups, lsi_stream_t stream);
 int lsi_bn_relu_bwd(const void* x, const void* dy, const float* mean_rstd,
                     const float* beta, void* dx, float* dbeta, float* workspace,
                     int64_t npix, int32_t C, int32_t bf16, int32_t relu,
-                    lsi_stream_t stream);
+                    int32_t groups, lsi_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_bf16.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/lsi_hip.h"
 
@@ -70,10 +71,10 @@ template <> struct Vec<true> {
   }
 };
 
-// workspace layout (floats): [0] arrival counter (int), [16, 16 + 4096) the
-// accumulators -- both zero between launches --, then 2*C constants of the
+// workspace layout per group (floats): [0] arrival counter (int), [16, 16 + 4096)
+// the accumulators -- both zero between launches --, then 2*C constants of the
 // second pass
-constexpr int WS_ACC = 16, WS_CONST = 16 + 4096;
+constexpr int WS_ACC = 16, WS_CONST = 16 + 4096, WS_STRIDE = 16 + 4096 + 4096;
 
 // Sums of the per-thread accumulators over the threads that hold the same
 // channels (tid % lpp), added to the 2*C global accumulators; returns true in
@@ -117,76 +118,29 @@ __device__ bool reduce_all(const float* a0, const float* a1, int lpp, int C,
   return true;
 }
 
-// pass 1 of the forward: sums of (x - k) and (x - k)^2 per channel, k = the
-// channel's value at pixel 0
+// group `blockIdx.y` of a launch: its slice of every per-group array
 template <bool BF16>
-__global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(
-    const void* __restrict__ x, const float* __restrict__ beta,
-    float* __restrict__ ws, float* __restrict__ mean_rstd, long npix, int C,
-    float eps) {
-  constexpr int NV = Vec<BF16>::N;
-  const int lpp = C / NV;                      // lanes per pixel
-  const int rows = BN_THREADS / lpp;           // pixels per workgroup step
-  const int lane = threadIdx.x % lpp, row = threadIdx.x / lpp;
-  float kk[NV], s[NV], q[NV];
-  Vec<BF16>::load(x, lane, kk);
-#pragma unroll
-  for (int k = 0; k < NV; ++k) { s[k] = 0.f; q[k] = 0.f; }
-  const long stride = (long)gridDim.x * rows;
-  long p = (long)blockIdx.x * rows + row;
-  for (; p + 3 * stride < npix; p += 4 * stride) {   // four loads in flight
-    float v[4][NV];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) Vec<BF16>::load(x, (p + u * stride) * lpp + lane, v[u]);
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-      for (int k = 0; k < NV; ++k) {
-        const float d = v[u][k] - kk[k];
-        s[k] += d; q[k] = __fmaf_rn(d, d, q[k]);
-      }
-  }
-  for (; p < npix; p += stride) {
-    float v[NV];
-    Vec<BF16>::load(x, p * lpp + lane, v);
-#pragma unroll
-    for (int k = 0; k < NV; ++k) {
-      const float d = v[k] - kk[k];
-      s[k] += d; q[k] = __fmaf_rn(d, d, q[k]);
-    }
-  }
-  __shared__ float tot[2 * 2048];
-  if (!reduce_all<NV>(s, q, lpp, C, ws, tot)) return;
-  // the last workgroup: mean, rstd, and y = x * a + b
-  float* ab = ws + WS_CONST;
-  for (int c = threadIdx.x; c < C; c += BN_THREADS) {
-    float k0[NV];
-    Vec<BF16>::load(x, c / NV, k0);
-    const double shift = (double)k0[c % NV];
-    const double m1 = (double)tot[c] / (double)npix;
-    double var = (double)tot[C + c] / (double)npix - m1 * m1;   // biased (tf.nn.moments)
-    if (var < 0.0) var = 0.0;
-    const double mean = shift + m1;
-    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-    mean_rstd[c] = (float)mean;
-    mean_rstd[C + c] = rstd;
-    ab[c] = rstd;
-    ab[C + c] = beta[c] - (float)mean * rstd;
-  }
+__device__ __forceinline__ const void* grp_in(const void* p, long npix, int C) {
+  return static_cast<const char*>(p) + (size_t)blockIdx.y * npix * C * (BF16 ? 2 : 4);
+}
+template <bool BF16>
+__device__ __forceinline__ void* grp_out(void* p, long npix, int C) {
+  return static_cast<char*>(p) + (size_t)blockIdx.y * npix * C * (BF16 ? 2 : 4);
 }
 
 // pass 2 of the forward: y = relu(x * a + b), a = rstd, b = beta - mean * rstd
 template <bool BF16>
-__global__ __launch_bounds__(BN_THREADS) void bn_norm_kernel(
-    const void* __restrict__ x, void* __restrict__ y, const float* __restrict__ ws,
-    long npix, int C, int relu) {
+__device__ __forceinline__ void norm_pass(const void* __restrict__ x, void* __restrict__ y,
+                                          const float* ab, long npix, int C, int relu) {
   constexpr int NV = Vec<BF16>::N;
   const int lpp = C / NV, rows = BN_THREADS / lpp;
   const int lane = threadIdx.x % lpp, row = threadIdx.x / lpp;
-  const float* ab = ws + WS_CONST;
   float a[NV], b[NV];
 #pragma unroll
-  for (int k = 0; k < NV; ++k) { a[k] = ab[lane * NV + k]; b[k] = ab[C + lane * NV + k]; }
+  for (int k = 0; k < NV; ++k) {
+    a[k] = ab[lane * NV + k];
+    b[k] = ab[C + lane * NV + k];
+  }
   const long stride = (long)gridDim.x * rows;
   long p = (long)blockIdx.x * rows + row;
   for (; p + 3 * stride < npix; p += 4 * stride) {
@@ -215,71 +169,87 @@ __global__ __launch_bounds__(BN_THREADS) void bn_norm_kernel(
   }
 }
 
-// pass 1 of the backward: sums of dz = dy * [z > 0] and of dz * xhat
+// pass 1 of the forward: sums of (x - k) and (x - k)^2 per channel, k = the
+// channel's value at pixel 0
 template <bool BF16>
-__global__ __launch_bounds__(BN_THREADS) void bn_bwd_stats_kernel(
-    const void* __restrict__ x, const void* __restrict__ dy,
-    const float* __restrict__ mean_rstd, const float* __restrict__ beta,
-    float* __restrict__ ws, float* __restrict__ dbeta, long npix, int C, int relu) {
+__global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(
+    const void* __restrict__ x_, const float* __restrict__ beta,
+    float* __restrict__ ws_, float* __restrict__ mean_rstd_, long npix, int C,
+    float eps) {
   constexpr int NV = Vec<BF16>::N;
-  const int lpp = C / NV, rows = BN_THREADS / lpp;
+  const void* x = grp_in<BF16>(x_, npix, C);
+  float* ws = ws_ + (size_t)blockIdx.y * WS_STRIDE;
+  float* mean_rstd = mean_rstd_ + (size_t)blockIdx.y * 2 * C;
+  const int lpp = C / NV;                      // lanes per pixel
+  const int rows = BN_THREADS / lpp;           // pixels per workgroup step
   const int lane = threadIdx.x % lpp, row = threadIdx.x / lpp;
-  float mu[NV], rs[NV], be[NV], s[NV], q[NV];
+  float kk[NV], s[NV], q[NV];
+  Vec<BF16>::load(x, lane, kk);
 #pragma unroll
-  for (int k = 0; k < NV; ++k) {
-    mu[k] = mean_rstd[lane * NV + k]; rs[k] = mean_rstd[C + lane * NV + k];
-    // (the forward's z = x * rstd + (beta - mean * rstd): the same mask)
-    be[k] = beta[lane * NV + k] - mu[k] * rs[k]; s[k] = 0.f; q[k] = 0.f;
-  }
+  for (int k = 0; k < NV; ++k) { s[k] = 0.f; q[k] = 0.f; }
   const long stride = (long)gridDim.x * rows;
   long p = (long)blockIdx.x * rows + row;
-  auto acc = [&](const float* v, const float* g) {
+  for (; p + 7 * stride < npix; p += 8 * stride) {   // eight loads in flight
+    float v[8][NV];
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
-      const float xh = (v[k] - mu[k]) * rs[k];
-      const float dz = (!relu || __fmaf_rn(v[k], rs[k], be[k]) > 0.0f) ? g[k] : 0.0f;
-      s[k] += dz;
-      q[k] = __fmaf_rn(dz, xh, q[k]);
-    }
-  };
-  for (; p + stride < npix; p += 2 * stride) {   // four loads in flight
-    float v[2][NV], g[2][NV];
+    for (int u = 0; u < 8; ++u) Vec<BF16>::load(x, (p + u * stride) * lpp + lane, v[u]);
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      Vec<BF16>::load(x, (p + u * stride) * lpp + lane, v[u]);
-      Vec<BF16>::load(dy, (p + u * stride) * lpp + lane, g[u]);
-    }
-    acc(v[0], g[0]);
-    acc(v[1], g[1]);
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int k = 0; k < NV; ++k) {
+        const float d = v[u][k] - kk[k];
+        s[k] += d; q[k] = __fmaf_rn(d, d, q[k]);
+      }
   }
   for (; p < npix; p += stride) {
-    float v[NV], g[NV];
+    float v[NV];
     Vec<BF16>::load(x, p * lpp + lane, v);
-    Vec<BF16>::load(dy, p * lpp + lane, g);
-    acc(v, g);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const float d = v[k] - kk[k];
+      s[k] += d; q[k] = __fmaf_rn(d, d, q[k]);
+    }
   }
   __shared__ float tot[2 * 2048];
-  if (!reduce_all<NV>(s, q, lpp, C, ws, tot)) return;
-  float* c12 = ws + WS_CONST;
-  const float inv_m = (float)(1.0 / (double)npix);
-  for (int c = threadIdx.x; c < C; c += BN_THREADS) {
-    dbeta[c] = tot[c];
-    c12[c] = tot[c] * inv_m;
-    c12[C + c] = tot[C + c] * inv_m;
+  if (reduce_all<NV>(s, q, lpp, C, ws, tot)) {
+    // the last workgroup: mean, rstd, and y = x * a + b
+    for (int c = threadIdx.x; c < C; c += BN_THREADS) {
+      float k0[NV];
+      Vec<BF16>::load(x, c / NV, k0);
+      const double shift = (double)k0[c % NV];
+      const double m1 = (double)tot[c] / (double)npix;
+      double var = (double)tot[C + c] / (double)npix - m1 * m1;   // biased (tf.nn.moments)
+      if (var < 0.0) var = 0.0;
+      const double mean = shift + m1;
+      const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+      mean_rstd[c] = (float)mean;
+      mean_rstd[C + c] = rstd;
+      tot[c] = rstd;
+      tot[C + c] = beta[c] - (float)mean * rstd;
+    }
+    __syncthreads();
+    float* ab = ws + WS_CONST;
+    for (int t = threadIdx.x; t < 2 * C; t += BN_THREADS) ab[t] = tot[t];
   }
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(BN_THREADS) void bn_norm_kernel(
+    const void* __restrict__ x, void* __restrict__ y, const float* __restrict__ ws,
+    long npix, int C, int relu) {
+  norm_pass<BF16>(grp_in<BF16>(x, npix, C), grp_out<BF16>(y, npix, C),
+                         ws + (size_t)blockIdx.y * WS_STRIDE + WS_CONST, npix, C, relu);
 }
 
 // pass 2 of the backward: dx = rstd * (dz - mean(dz) - xhat * mean(dz * xhat))
 template <bool BF16>
-__global__ __launch_bounds__(BN_THREADS) void bn_bwd_dx_kernel(
-    const void* __restrict__ x, const void* __restrict__ dy,
-    const float* __restrict__ mean_rstd, const float* __restrict__ beta,
-    const float* __restrict__ ws, void* __restrict__ dx, long npix, int C,
-    int relu) {
+__device__ __forceinline__ void dx_pass(const void* __restrict__ x, const void* __restrict__ dy,
+                                        const float* __restrict__ mean_rstd,
+                                        const float* __restrict__ beta, const float* c12,
+                                        void* __restrict__ dx, long npix, int C, int relu) {
   constexpr int NV = Vec<BF16>::N;
   const int lpp = C / NV, rows = BN_THREADS / lpp;
   const int lane = threadIdx.x % lpp, row = threadIdx.x / lpp;
-  const float* c12 = ws + WS_CONST;
   float mu[NV], rs[NV], be[NV], c1[NV], c2[NV];
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
@@ -321,6 +291,80 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_dx_kernel(
   }
 }
 
+// pass 1 of the backward: sums of dz = dy * [z > 0] and of dz * xhat
+template <bool BF16>
+__global__ __launch_bounds__(BN_THREADS) void bn_bwd_stats_kernel(
+    const void* __restrict__ x_, const void* __restrict__ dy_,
+    const float* __restrict__ mean_rstd_, const float* __restrict__ beta,
+    float* __restrict__ ws_, float* __restrict__ dbeta_, long npix, int C, int relu) {
+  constexpr int NV = Vec<BF16>::N;
+  const void* x = grp_in<BF16>(x_, npix, C);
+  const void* dy = grp_in<BF16>(dy_, npix, C);
+  const float* mean_rstd = mean_rstd_ + (size_t)blockIdx.y * 2 * C;
+  float* ws = ws_ + (size_t)blockIdx.y * WS_STRIDE;
+  float* dbeta = dbeta_ + (size_t)blockIdx.y * C;
+  const int lpp = C / NV, rows = BN_THREADS / lpp;
+  const int lane = threadIdx.x % lpp, row = threadIdx.x / lpp;
+  float mu[NV], rs[NV], be[NV], s[NV], q[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    mu[k] = mean_rstd[lane * NV + k]; rs[k] = mean_rstd[C + lane * NV + k];
+    // (the forward's z = x * rstd + (beta - mean * rstd): the same mask)
+    be[k] = beta[lane * NV + k] - mu[k] * rs[k]; s[k] = 0.f; q[k] = 0.f;
+  }
+  const long stride = (long)gridDim.x * rows;
+  long p = (long)blockIdx.x * rows + row;
+  auto acc = [&](const float* v, const float* g) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const float xh = (v[k] - mu[k]) * rs[k];
+      const float dz = (!relu || __fmaf_rn(v[k], rs[k], be[k]) > 0.0f) ? g[k] : 0.0f;
+      s[k] += dz;
+      q[k] = __fmaf_rn(dz, xh, q[k]);
+    }
+  };
+  for (; p + 3 * stride < npix; p += 4 * stride) {   // eight loads in flight
+    float v[4][NV], g[4][NV];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      Vec<BF16>::load(x, (p + u * stride) * lpp + lane, v[u]);
+      Vec<BF16>::load(dy, (p + u * stride) * lpp + lane, g[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc(v[u], g[u]);
+  }
+  for (; p < npix; p += stride) {
+    float v[NV], g[NV];
+    Vec<BF16>::load(x, p * lpp + lane, v);
+    Vec<BF16>::load(dy, p * lpp + lane, g);
+    acc(v, g);
+  }
+  __shared__ float tot[2 * 2048];
+  if (reduce_all<NV>(s, q, lpp, C, ws, tot)) {
+    const float inv_m = (float)(1.0 / (double)npix);
+    for (int c = threadIdx.x; c < C; c += BN_THREADS) {
+      dbeta[c] = tot[c];
+      tot[c] *= inv_m;
+      tot[C + c] *= inv_m;
+    }
+    __syncthreads();
+    float* c12 = ws + WS_CONST;
+    for (int t = threadIdx.x; t < 2 * C; t += BN_THREADS) c12[t] = tot[t];
+  }
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(BN_THREADS) void bn_bwd_dx_kernel(
+    const void* __restrict__ x, const void* __restrict__ dy,
+    const float* __restrict__ mean_rstd, const float* __restrict__ beta,
+    const float* __restrict__ ws, void* __restrict__ dx, long npix, int C,
+    int relu) {
+  dx_pass<BF16>(grp_in<BF16>(x, npix, C), grp_in<BF16>(dy, npix, C),
+                       mean_rstd + (size_t)blockIdx.y * 2 * C, beta,
+                       ws + (size_t)blockIdx.y * WS_STRIDE + WS_CONST,
+                       grp_out<BF16>(dx, npix, C), npix, C, relu);
+}
+
 bool bn_shape_ok(long npix, int C, int bf16) {
   const int nv = bf16 ? 8 : 4;
   if (npix <= 0 || C <= 0 || C % nv) return false;
@@ -328,6 +372,10 @@ bool bn_shape_ok(long npix, int C, int bf16) {
   return lpp <= BN_THREADS && (lpp & (lpp - 1)) == 0 && C <= 2048;
 }
 
+// Workgroups per group.  (Both passes in ONE launch for small activations --
+// last workgroup publishes the constants, the others wait for a flag -- was
+// built and measured: 16.4 / 21.7 us against 13.8 / 19.5 us for two launches
+// at 1.6 MB, 277-281 against 285 samples/s for the bf16 training step; dropped.)
 int bn_grid(long npix, int C, int bf16) {
   const int rows = BN_THREADS / (C / (bf16 ? 8 : 4));
   long g = (npix + rows * 16 - 1) / (rows * 16);   // >= 16 steps per workgroup
@@ -340,29 +388,32 @@ bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
 
-// workspace: see WS_ACC / WS_CONST above (shape independent)
-extern "C" size_t lsi_bn_workspace_floats(int64_t npix, int32_t C, int32_t bf16) {
-  if (!bn_shape_ok(npix, C, bf16)) return 0;
-  return (size_t)WS_CONST + 2 * (size_t)C;
+// workspace: groups x (counters, accumulators, constants) -- shape independent
+extern "C" size_t lsi_bn_workspace_floats(int64_t npix, int32_t C, int32_t bf16,
+                                          int32_t groups) {
+  if (!bn_shape_ok(npix, C, bf16) || groups < 1) return 0;
+  return (size_t)WS_STRIDE * groups;
 }
 
 extern "C" int lsi_bn_relu_fwd(const void* x, void* y, const float* beta,
                                float* workspace, float* mean_rstd, int64_t npix,
                                int32_t C, int32_t bf16, int32_t relu, float eps,
-                               lsi_stream_t stream_) {
+                               int32_t groups, lsi_stream_t stream_) {
   if (!x || !y || !beta || !workspace || !mean_rstd) return LSI_ENULL;
-  if (!bn_shape_ok(npix, C, bf16) || !al16(x) || !al16(y)) return LSI_EINVAL;
+  if (!bn_shape_ok(npix, C, bf16) || !al16(x) || !al16(y) || groups < 1 ||
+      groups > 65535)
+    return LSI_EINVAL;
   hipStream_t st = (hipStream_t)stream_;
-  const int g = bn_grid(npix, C, bf16);
+  const dim3 grid(bn_grid(npix, C, bf16), groups), blk(BN_THREADS);
   if (bf16) {
-    hipLaunchKernelGGL(bn_stats_kernel<true>, dim3(g), dim3(BN_THREADS), 0, st, x, beta,
-                       workspace, mean_rstd, (long)npix, C, eps);
-    hipLaunchKernelGGL(bn_norm_kernel<true>, dim3(g), dim3(BN_THREADS), 0, st, x, y,
+    hipLaunchKernelGGL(bn_stats_kernel<true>, grid, blk, 0, st, x, beta, workspace,
+                       mean_rstd, (long)npix, C, eps);
+    hipLaunchKernelGGL(bn_norm_kernel<true>, grid, blk, 0, st, x, y,
                        (const float*)workspace, (long)npix, C, relu);
   } else {
-    hipLaunchKernelGGL(bn_stats_kernel<false>, dim3(g), dim3(BN_THREADS), 0, st, x, beta,
-                       workspace, mean_rstd, (long)npix, C, eps);
-    hipLaunchKernelGGL(bn_norm_kernel<false>, dim3(g), dim3(BN_THREADS), 0, st, x, y,
+    hipLaunchKernelGGL(bn_stats_kernel<false>, grid, blk, 0, st, x, beta, workspace,
+                       mean_rstd, (long)npix, C, eps);
+    hipLaunchKernelGGL(bn_norm_kernel<false>, grid, blk, 0, st, x, y,
                        (const float*)workspace, (long)npix, C, relu);
   }
   return hipGetLastError() == hipSuccess ? LSI_OK : LSI_ELAUNCH;
@@ -371,21 +422,24 @@ extern "C" int lsi_bn_relu_fwd(const void* x, void* y, const float* beta,
 extern "C" int lsi_bn_relu_bwd(const void* x, const void* dy, const float* mean_rstd,
                                const float* beta, void* dx, float* dbeta,
                                float* workspace, int64_t npix, int32_t C,
-                               int32_t bf16, int32_t relu, lsi_stream_t stream_) {
+                               int32_t bf16, int32_t relu, int32_t groups,
+                               lsi_stream_t stream_) {
   if (!x || !dy || !mean_rstd || !beta || !dx || !dbeta || !workspace) return LSI_ENULL;
-  if (!bn_shape_ok(npix, C, bf16) || !al16(x) || !al16(dy) || !al16(dx)) return LSI_EINVAL;
+  if (!bn_shape_ok(npix, C, bf16) || !al16(x) || !al16(dy) || !al16(dx) ||
+      groups < 1 || groups > 65535)
+    return LSI_EINVAL;
   hipStream_t st = (hipStream_t)stream_;
-  const int g = bn_grid(npix, C, bf16);
+  const dim3 grid(bn_grid(npix, C, bf16), groups), blk(BN_THREADS);
   if (bf16) {
-    hipLaunchKernelGGL(bn_bwd_stats_kernel<true>, dim3(g), dim3(BN_THREADS), 0, st, x,
-                       dy, mean_rstd, beta, workspace, dbeta, (long)npix, C, relu);
-    hipLaunchKernelGGL(bn_bwd_dx_kernel<true>, dim3(g), dim3(BN_THREADS), 0, st, x, dy,
-                       mean_rstd, beta, (const float*)workspace, dx, (long)npix, C, relu);
+    hipLaunchKernelGGL(bn_bwd_stats_kernel<true>, grid, blk, 0, st, x, dy, mean_rstd,
+                       beta, workspace, dbeta, (long)npix, C, relu);
+    hipLaunchKernelGGL(bn_bwd_dx_kernel<true>, grid, blk, 0, st, x, dy, mean_rstd, beta,
+                       (const float*)workspace, dx, (long)npix, C, relu);
   } else {
-    hipLaunchKernelGGL(bn_bwd_stats_kernel<false>, dim3(g), dim3(BN_THREADS), 0, st, x,
-                       dy, mean_rstd, beta, workspace, dbeta, (long)npix, C, relu);
-    hipLaunchKernelGGL(bn_bwd_dx_kernel<false>, dim3(g), dim3(BN_THREADS), 0, st, x, dy,
-                       mean_rstd, beta, (const float*)workspace, dx, (long)npix, C, relu);
+    hipLaunchKernelGGL(bn_bwd_stats_kernel<false>, grid, blk, 0, st, x, dy, mean_rstd,
+                       beta, workspace, dbeta, (long)npix, C, relu);
+    hipLaunchKernelGGL(bn_bwd_dx_kernel<false>, grid, blk, 0, st, x, dy, mean_rstd, beta,
+                       (const float*)workspace, dx, (long)npix, C, relu);
   }
   return hipGetLastError() == hipSuccess ? LSI_OK : LSI_ELAUNCH;
 }

@@ -91,9 +91,9 @@ SIGNATURES = {
                         [_I32, _F32, _F32, _VP, _VP]),
     'lsi_compose_depth_fwd': (ctypes.c_int, [_I32, _I64] + [_VP] * 2 +
                               [_I32, _F32, _F32, _F32, _VP, _VP]),
-    'lsi_bn_workspace_floats': (_SZ, [_I64, _I32, _I32]),
-    'lsi_bn_relu_fwd': (ctypes.c_int, [_VP] * 5 + [_I64, _I32, _I32, _I32, _F32, _VP]),
-    'lsi_bn_relu_bwd': (ctypes.c_int, [_VP] * 7 + [_I64, _I32, _I32, _I32, _VP]),
+    'lsi_bn_workspace_floats': (_SZ, [_I64, _I32, _I32, _I32]),
+    'lsi_bn_relu_fwd': (ctypes.c_int, [_VP] * 5 + [_I64, _I32, _I32, _I32, _F32, _I32, _VP]),
+    'lsi_bn_relu_bwd': (ctypes.c_int, [_VP] * 7 + [_I64, _I32, _I32, _I32, _I32, _VP]),
 }
 
 _lib = None

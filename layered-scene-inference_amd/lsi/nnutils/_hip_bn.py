@@ -52,17 +52,15 @@ class _BnRelu(torch.autograd.Function):
     npix = (n // groups) * h * w          # per group: its own statistics
     bf16 = int(x.dtype == torch.bfloat16)
     lib = _C.lib()
-    ws = _workspace(dev, int(lib.lsi_bn_workspace_floats(npix, c, bf16)))
+    ws = _workspace(dev, int(lib.lsi_bn_workspace_floats(npix, c, bf16, groups)))
     y = torch.empty_like(x, memory_format=torch.channels_last)
     mean_rstd = torch.empty((groups, 2, c), dtype=torch.float32, device=dev)
     beta_f = beta.detach().float().contiguous()
-    step = npix * c * x.element_size()    # bytes of one group (N-major storage)
-    for g in range(groups):
-      rc = lib.lsi_bn_relu_fwd(x.data_ptr() + g * step, y.data_ptr() + g * step,
-                               _C.ptr(beta_f), _C.ptr(ws), _C.ptr(mean_rstd[g]),
-                               npix, c, bf16, int(relu), float(eps),
-                               _C.stream_ptr(dev))
-      _C.check(rc, 'lsi_bn_relu_fwd')
+    # (N-major storage: the groups are consecutive blocks of npix * C values)
+    rc = lib.lsi_bn_relu_fwd(_C.ptr(x), _C.ptr(y), _C.ptr(beta_f), _C.ptr(ws),
+                             _C.ptr(mean_rstd), npix, c, bf16, int(relu),
+                             float(eps), groups, _C.stream_ptr(dev))
+    _C.check(rc, 'lsi_bn_relu_fwd')
     ctx.save_for_backward(x, beta_f, mean_rstd)
     ctx.relu = int(relu)
     ctx.groups = groups
@@ -78,17 +76,13 @@ class _BnRelu(torch.autograd.Function):
     bf16 = int(x.dtype == torch.bfloat16)
     dy = dy.to(x.dtype).contiguous(memory_format=torch.channels_last)
     lib = _C.lib()
-    ws = _workspace(dev, int(lib.lsi_bn_workspace_floats(npix, c, bf16)))
+    ws = _workspace(dev, int(lib.lsi_bn_workspace_floats(npix, c, bf16, groups)))
     dx = torch.empty_like(x, memory_format=torch.channels_last)
     dbeta = torch.empty((groups, c), dtype=torch.float32, device=dev)
-    step = npix * c * x.element_size()
-    for g in range(groups):
-      rc = lib.lsi_bn_relu_bwd(x.data_ptr() + g * step, dy.data_ptr() + g * step,
-                               _C.ptr(mean_rstd[g]), _C.ptr(beta_f),
-                               dx.data_ptr() + g * step, _C.ptr(dbeta[g]),
-                               _C.ptr(ws), npix, c, bf16, ctx.relu,
-                               _C.stream_ptr(dev))
-      _C.check(rc, 'lsi_bn_relu_bwd')
+    rc = lib.lsi_bn_relu_bwd(_C.ptr(x), _C.ptr(dy), _C.ptr(mean_rstd),
+                             _C.ptr(beta_f), _C.ptr(dx), _C.ptr(dbeta), _C.ptr(ws),
+                             npix, c, bf16, ctx.relu, groups, _C.stream_ptr(dev))
+    _C.check(rc, 'lsi_bn_relu_bwd')
     return dx, (dbeta.sum(0) if groups > 1 else dbeta[0]), None, None, None
 
 
