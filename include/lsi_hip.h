@@ -392,8 +392,8 @@ int lsi_compose_depth_fwd(int32_t L, int64_t N, const float* masks,
  *   workspace: lsi_bn_workspace_floats(npix, C, bf16, groups) floats,
  *   ZERO-FILLED ONCE by the caller and then reusable by any later call on the
  *   same stream (the library leaves its counters and accumulators zero).
- *   mean_rstd: [groups][2][C] out (forward), in (backward).  dbeta:
- *   [groups][C] out (the caller adds the groups).
+ *   mean_rstd: [groups][2][C] out (forward), in (backward).  dbeta: [C] out
+ *   (summed over the groups).
  */
 size_t lsi_bn_workspace_floats(int64_t npix, int32_t C, int32_t bf16, int32_t groups);
 int lsi_bn_relu_fwd(const void* x, void* y, const float* beta, float* workspace,

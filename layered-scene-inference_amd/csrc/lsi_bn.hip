@@ -73,8 +73,8 @@ template <> struct Vec<true> {
 
 // workspace layout per group (floats): [0] arrival counter (int), [16, 16 + 4096)
 // the accumulators -- both zero between launches --, then 2*C constants of the
-// second pass
-constexpr int WS_ACC = 16, WS_CONST = 16 + 4096, WS_STRIDE = 16 + 4096 + 4096;
+// second pass and (backward) the group's C sums of dz
+constexpr int WS_ACC = 16, WS_CONST = 16 + 4096, WS_STRIDE = 16 + 4096 + 3 * 2048;
 
 // Sums of the per-thread accumulators over the threads that hold the same
 // channels (tid % lpp), added to the 2*C global accumulators; returns true in
@@ -296,13 +296,12 @@ template <bool BF16>
 __global__ __launch_bounds__(BN_THREADS) void bn_bwd_stats_kernel(
     const void* __restrict__ x_, const void* __restrict__ dy_,
     const float* __restrict__ mean_rstd_, const float* __restrict__ beta,
-    float* __restrict__ ws_, float* __restrict__ dbeta_, long npix, int C, int relu) {
+    float* __restrict__ ws_, long npix, int C, int relu) {
   constexpr int NV = Vec<BF16>::N;
   const void* x = grp_in<BF16>(x_, npix, C);
   const void* dy = grp_in<BF16>(dy_, npix, C);
   const float* mean_rstd = mean_rstd_ + (size_t)blockIdx.y * 2 * C;
   float* ws = ws_ + (size_t)blockIdx.y * WS_STRIDE;
-  float* dbeta = dbeta_ + (size_t)blockIdx.y * C;
   const int lpp = C / NV, rows = BN_THREADS / lpp;
   const int lane = threadIdx.x % lpp, row = threadIdx.x / lpp;
   float mu[NV], rs[NV], be[NV], s[NV], q[NV];
@@ -342,13 +341,13 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_stats_kernel(
   __shared__ float tot[2 * 2048];
   if (reduce_all<NV>(s, q, lpp, C, ws, tot)) {
     const float inv_m = (float)(1.0 / (double)npix);
+    float* c12 = ws + WS_CONST;
     for (int c = threadIdx.x; c < C; c += BN_THREADS) {
-      dbeta[c] = tot[c];
+      c12[2 * C + c] = tot[c];   // the group's share of dbeta (added up in pass 2)
       tot[c] *= inv_m;
       tot[C + c] *= inv_m;
     }
     __syncthreads();
-    float* c12 = ws + WS_CONST;
     for (int t = threadIdx.x; t < 2 * C; t += BN_THREADS) c12[t] = tot[t];
   }
 }
@@ -357,8 +356,16 @@ template <bool BF16>
 __global__ __launch_bounds__(BN_THREADS) void bn_bwd_dx_kernel(
     const void* __restrict__ x, const void* __restrict__ dy,
     const float* __restrict__ mean_rstd, const float* __restrict__ beta,
-    const float* __restrict__ ws, void* __restrict__ dx, long npix, int C,
-    int relu) {
+    const float* __restrict__ ws, void* __restrict__ dx, float* __restrict__ dbeta,
+    long npix, int C, int relu) {
+  if (blockIdx.x == 0 && blockIdx.y == 0) {  // dbeta = the groups' sums of dz
+    for (int c = threadIdx.x; c < C; c += BN_THREADS) {
+      float t = 0.0f;
+      for (unsigned g = 0; g < gridDim.y; ++g)
+        t += ws[(size_t)g * WS_STRIDE + WS_CONST + 2 * C + c];
+      dbeta[c] = t;
+    }
+  }
   dx_pass<BF16>(grp_in<BF16>(x, npix, C), grp_in<BF16>(dy, npix, C),
                        mean_rstd + (size_t)blockIdx.y * 2 * C, beta,
                        ws + (size_t)blockIdx.y * WS_STRIDE + WS_CONST,
@@ -432,14 +439,14 @@ extern "C" int lsi_bn_relu_bwd(const void* x, const void* dy, const float* mean_
   const dim3 grid(bn_grid(npix, C, bf16), groups), blk(BN_THREADS);
   if (bf16) {
     hipLaunchKernelGGL(bn_bwd_stats_kernel<true>, grid, blk, 0, st, x, dy, mean_rstd,
-                       beta, workspace, dbeta, (long)npix, C, relu);
+                       beta, workspace, (long)npix, C, relu);
     hipLaunchKernelGGL(bn_bwd_dx_kernel<true>, grid, blk, 0, st, x, dy, mean_rstd, beta,
-                       (const float*)workspace, dx, (long)npix, C, relu);
+                       (const float*)workspace, dx, dbeta, (long)npix, C, relu);
   } else {
     hipLaunchKernelGGL(bn_bwd_stats_kernel<false>, grid, blk, 0, st, x, dy, mean_rstd,
-                       beta, workspace, dbeta, (long)npix, C, relu);
+                       beta, workspace, (long)npix, C, relu);
     hipLaunchKernelGGL(bn_bwd_dx_kernel<false>, grid, blk, 0, st, x, dy, mean_rstd, beta,
-                       (const float*)workspace, dx, (long)npix, C, relu);
+                       (const float*)workspace, dx, dbeta, (long)npix, C, relu);
   }
   return hipGetLastError() == hipSuccess ? LSI_OK : LSI_ELAUNCH;
 }

@@ -91,6 +91,8 @@ def build_parser():
   a('--batched_pairs', type=_bool, default=True,
     help='source and target images go through the network in one pass, every '
     'batch norm with separate statistics per view (same arithmetic as two passes)')
+  a('--fused_adam', type=_bool, default=True,
+    help='torch.optim.Adam(fused=True) on the GPU')
   a('--flat_grads', type=_bool, default=False,
     help='data parallel without the DDP wrapper: one flat gradient buffer, one '
     'all-reduce per step (implied by --hip_graph with more than one rank)')

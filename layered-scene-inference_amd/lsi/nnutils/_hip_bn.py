@@ -78,12 +78,12 @@ class _BnRelu(torch.autograd.Function):
     lib = _C.lib()
     ws = _workspace(dev, int(lib.lsi_bn_workspace_floats(npix, c, bf16, groups)))
     dx = torch.empty_like(x, memory_format=torch.channels_last)
-    dbeta = torch.empty((groups, c), dtype=torch.float32, device=dev)
+    dbeta = torch.empty((c,), dtype=torch.float32, device=dev)
     rc = lib.lsi_bn_relu_bwd(_C.ptr(x), _C.ptr(dy), _C.ptr(mean_rstd),
                              _C.ptr(beta_f), _C.ptr(dx), _C.ptr(dbeta), _C.ptr(ws),
                              npix, c, bf16, ctx.relu, groups, _C.stream_ptr(dev))
     _C.check(rc, 'lsi_bn_relu_bwd')
-    return dx, (dbeta.sum(0) if groups > 1 else dbeta[0]), None, None, None
+    return dx, dbeta, None, None, None
 
 
 def batch_norm_relu(x, beta, eps=1e-3, relu=True, groups=1):

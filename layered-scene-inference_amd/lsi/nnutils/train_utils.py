@@ -119,10 +119,14 @@ class Trainer(object):
     self._graph, self._graph_plan, self._static = None, None, None
     self._graph_b = None
     self._graph_warm = 0
+    # (fused: one multi-tensor kernel per step instead of the foreach chain --
+    # 12 launches, 0.5 ms of a 14 ms bf16 step; same update rule,
+    # train_utils.py:109-112)
     self.optim = torch.optim.Adam(self.model.parameters(),
                                   lr=opts.learning_rate,
                                   betas=(opts.beta1, 0.999), eps=1e-8,
-                                  capturable=self.use_graph)
+                                  capturable=self.use_graph,
+                                  fused=bool(use_gpu) and bool(getattr(opts, 'fused_adam', True)))
     if self.use_graph:
       self._stream = torch.cuda.Stream(self.device)
     self.resume()
