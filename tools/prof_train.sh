@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/${1:-train_prof}
 mkdir -p $OUT
 for bf in false true; do
-  python $R/tools/train_bench.py --bf16 $bf --steps 10 > $OUT/train_$bf.json 2> $OUT/train_$bf.err
+  python $R/tools/train_bench.py --bf16 $bf --steps 20 > $OUT/train_$bf.json 2> $OUT/train_$bf.err
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_$bf -o kt -- python $R/tools/train_bench.py --bf16 $bf --steps 5 > /dev/null 2> $OUT/kt_$bf.err
   rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_$bf -o p -- python $R/tools/train_bench.py --bf16 $bf --steps 3 > /dev/null 2> $OUT/pmc_$bf.err
 done
