@@ -714,7 +714,12 @@ size_t lsi_splat_workspace_bytes(const LsiSplatDesc* d) {
                              canvas_channels(d) * sizeof(float);
   // STREAM-path boundary-row exchange area (worst case band height)
   const size_t stream_need = lsi_stream_workspace_bytes(d);
-  return atomic_need > stream_need ? atomic_need : stream_need;
+  // TILE-path disparity ranges (larger than the canvases only for targets of
+  // a few cells)
+  const size_t tile_need = lsi_tile_workspace_bytes(d);
+  size_t need = atomic_need > stream_need ? atomic_need : stream_need;
+  if (tile_need > need) need = tile_need;
+  return need;
 }
 
 int lsi_splat_fwd(const LsiSplatDesc* d, const float* tex, const float* disp,

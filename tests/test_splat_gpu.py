@@ -1320,3 +1320,21 @@ def test_differential_fuzz_of_the_round3_kernels(dev):
                         '60', '1234'], capture_output=True, text=True, timeout=900)
   assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
   assert 'fuzz_compact: 60 cases' in out.stdout
+
+
+def test_workspace_covers_every_path_on_tiny_targets(dev):
+  """lsi_splat_workspace_bytes is enough for whichever path renders: a target
+  of one cell needs more room for the any-pose path's disparity ranges than
+  for canvases (found by tools/fuzz_tile.py)."""
+  from lsi.geometry import ldi
+  rs = np.random.RandomState(5)
+  tex = torch.tensor(rs.rand(3, 2, 4, 4, 3).astype(np.float32), device=dev)
+  disp = torch.tensor((0.1 + 0.5 * rs.rand(3, 2, 4, 4, 1)).astype(np.float32), device=dev)
+  mat = torch.eye(4).expand(2, 4, 4).contiguous()
+  outs = {}
+  for path in ('tile', 'atomic'):
+    outs[path] = ldi.forward_splat_matrix([tex, None, disp], mat, compose_layers=True,
+                                          trg_downsampling=0.25, bg_layer_disp=0.05,
+                                          max_disp=1.0, zbuf_scale=10.0, path=path)
+  torch.testing.assert_close(outs['tile'][0], outs['atomic'][0], rtol=0, atol=IMG_ATOL)
+  torch.testing.assert_close(outs['tile'][1], outs['atomic'][1], rtol=WTS_RTOL, atol=0)
