@@ -156,6 +156,8 @@ __global__ __launch_bounds__(SWEEP_T, LSI_SWEEP_WGS) void splat_sweep_kernel(
   for (int k = 0; k < 16; ++k) m[k] = a.M[16 * b + k];
   const float s = d.trg_downsampling, zscale = d.zbuf_scale;
   const float inv_md = div_rn(1.0f, d.max_disp);
+  // exp((c - 0.5) * scale) = exp2(c * zA + zB)
+  const float zA = zscale * 1.44269504f, zB = -0.5f * zscale * 1.44269504f;
   const float tx0f = (float)tx0;
   const int tw_eff = min(TW, Wt - tx0);
   const float ax_lo = (float)(tx0 - 1), ax_hi = (float)(tx0 + tw_eff - 1);
@@ -518,6 +520,9 @@ __global__ __launch_bounds__(SWEEP_T, LSI_SWEEP_WGS) void splat_sweep_kernel(
       if (d.reserved & 2048) return;  // timing experiment: loads only
 #endif
       const float py = (float)p.y + 0.5f;
+      // (the row's share of q = ((px*m0 + py*m1) + m2) + d*m3 -- the product
+      // py*m1 rounds the same wherever it is formed: once per item)
+      const float pm0 = py * m[1], pm1 = py * m[5], pm2 = py * m[9], pm3 = py * m[13];
       const float dvs[4] = {p.dv.x, p.dv.y, p.dv.z, p.dv.w};
       const float t0s[4] = {p.ta.x, p.ta.w, p.tb.z, p.tc.y};
       const float t1s[4] = {p.ta.y, p.tb.x, p.tb.w, p.tc.z};
@@ -527,11 +532,11 @@ __global__ __launch_bounds__(SWEEP_T, LSI_SWEEP_WGS) void splat_sweep_kernel(
       for (int j = 0; j < 4; ++j) {
         const float px = (float)(p.x + j) + 0.5f;
         const float dv = dvs[j];
-        const float q1 = mrow(m, 1, px, py, dv);
-        const float nden = safe_den(mrow(m, 2, px, py, dv));
+        const float q1 = ((px * m[4] + pm1) + m[6]) + dv * m[7];
+        const float nden = safe_den(((px * m[8] + pm2) + m[10]) + dv * m[11]);
         const float Y = div_rn(q1, nden) * s - 0.5f;
         const float y0 = floorf(Y);
-        const float q0 = mrow(m, 0, px, py, dv);
+        const float q0 = ((px * m[0] + pm0) + m[2]) + dv * m[3];
         const float X = div_rn(q0, nden) * s - 0.5f;
         const float x0 = floorf(X);
         // (non-finite X / Y fail the comparisons: dropped, like every path)
@@ -540,18 +545,33 @@ __global__ __launch_bounds__(SWEEP_T, LSI_SWEEP_WGS) void splat_sweep_kernel(
 #if LSI_STREAM_HOOKS
         if (prof) tacc[5] += 1 + ((long long)__popcll(__ballot(ok)) << 32);  // px-iters, ok lanes
 #endif
-        const float q3 = mrow(m, 3, px, py, dv);
-        const float dd = div_rn(q3, nden);
-        const float pw = (VEC4 && !HAS_MASK)
-                             ? zbuffer_weight(dd * inv_md, zscale)
-                             : zbuffer_weight(dd * inv_md, zscale) * mks[j];
+        const float q3 = ((px * m[12] + pm3) + m[14]) + dv * m[15];
+        // The target disparity feeds the weight and the disparity output
+        // (1e-4 relative), no index or threshold: reciprocal + one Newton step
+        // instead of the IEEE division (the disparity output keeps the exact
+        // quotient)
+        float dd;
+        if (WANT_DISP) {
+          dd = div_rn(q3, nden);
+        } else {
+          float r = __builtin_amdgcn_rcpf(nden);
+          r = __fmaf_rn(__fmaf_rn(-nden, r, 1.0f), r, r);
+          dd = q3 * r;
+        }
+        // exp((clip(D/max,0,1) - 0.5) * scale) [D > 0] as exp2 of one fma
+        const float xn = dd * inv_md;
+        const float ez = __builtin_amdgcn_exp2f(
+            __fmaf_rn(__builtin_amdgcn_fmed3f(xn, 0.0f, 1.0f), zA, zB));
+        const float zw = xn > 0.0f ? ez : 0.0f;
+        const float pw = (VEC4 && !HAS_MASK) ? zw : zw * mks[j];
         ok = ok && pw != 0.0f;  // contributes exactly +0 everywhere
         // Corner weights (sampling.py:193-222).  The border masks are implied:
         // a corner outside the image is outside every tile and never read.
         const float wx0 = (x0 + 1.0f) - X, wx1 = X - x0;
         const float wy0 = (y0 + 1.0f) - Y, wy1 = Y - y0;
-        const float w00 = clamp_small(wx0 * wy0), w01 = clamp_small(wx1 * wy0);
-        const float w10 = clamp_small(wx0 * wy1), w11 = clamp_small(wx1 * wy1);
+        const float p00 = wx0 * wy0, p01 = wx1 * wy0, p10 = wx0 * wy1, p11 = wx1 * wy1;
+        const float w00 = p00 > 1e-3f ? p00 : 0.0f, w01 = p01 > 1e-3f ? p01 : 0.0f;
+        const float w10 = p10 > 1e-3f ? p10 : 0.0f, w11 = p11 > 1e-3f ? p11 : 0.0f;
         const float4 V = make_float4(t0s[j] * pw, t1s[j] * pw, t2s[j] * pw, pw);
         const int iy = ok ? (int)(y0 - ty0f) : 0;  // -1 .. th_eff - 1
         const int ix = ok ? (int)(x0 - tx0f) : 0;  // -1 .. tw_eff - 1
