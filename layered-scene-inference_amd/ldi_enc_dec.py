@@ -93,6 +93,9 @@ def build_parser():
     'batch norm with separate statistics per view (same arithmetic as two passes)')
   a('--fused_adam', type=_bool, default=True,
     help='torch.optim.Adam(fused=True) on the GPU')
+  a('--miopen_tune', type=_bool, default=False,
+    help='let MIOpen tune its convolution solvers for this run (one-time 50-100 s; '
+    'MIOPEN_FIND_ENFORCE=3, cached in ~/.config/miopen)')
   a('--flat_grads', type=_bool, default=False,
     help='data parallel without the DDP wrapper: one flat gradient buffer, one '
     'all-reduce per step (implied by --hip_graph with more than one rank)')

@@ -83,6 +83,14 @@ class Trainer(object):
       # igemm_bwd kernels the search tries was seen to fault (GPU memory access
       # fault inside MIOpen's search, depending on where buffers happen to lie).
       torch.backends.cudnn.benchmark = bool(getattr(opts, 'miopen_search', False))
+      # --miopen_tune: MIOpen tunes its solvers for this run's layer shapes
+      # (MIOPEN_FIND_ENFORCE=3: search, results kept in the user perf-db under
+      # ~/.config/miopen) before the first step: 50-100 s once per machine, then
+      # bf16 297 -> 373 samples/s (391 with --hip_graph), fp32 155 -> 182 at
+      # batch 4, 256 x 768 -- the shipped perf-db has no entries for these
+      # shapes.  Must be in the environment before the first convolution.
+      if getattr(opts, 'miopen_tune', False):
+        os.environ.setdefault('MIOPEN_FIND_ENFORCE', '3')
     # (a one-rank job launched by torch.distributed.run gets its process group
     # too: the collectives of the data-parallel step then run -- over one rank
     # -- which is how the step is exercised on a single-GPU box)
