@@ -8,8 +8,8 @@
 // descriptor the forward was launched with): path STREAM with the SIMPLE bit
 // (every batch element: M rows 2, 3 = (0,0,1,0), (0,0,0,1), M[1][0] = M[1][3]
 // = 0 -- the target row depends on the source row only, normaliser 1, target
-// disparity = source disparity), channels-last contiguous textures, rows of
-// whole 256-pixel segments, no mask.
+// disparity = source disparity), channels-last contiguous textures (or RGBD
+// pixels), W % 4 == 0, no mask.
 //
 // * Workgroup = (band of RS consecutive SOURCE rows, batch element[, layer]).
 //   Every source pixel is written exactly once whatever the map does.  The
@@ -165,8 +165,11 @@ __device__ __forceinline__ void bs_run(const BSArgs& a, const float (&m)[8],
   const float xmax = (float)Wt - 1.0f, ymax = (float)a.Ht - 1.0f;
   const float inv_md = div_rn(1.0f, a.max_disp);
   const float zs_md = a.zscale * inv_md;
-  const float* const g_tex_in = a.tex + (long)b * a.tex_sb + (long)l_lo * a.tex_sl + (PACK ? 16 : 12) * lane;
-  const float* const g_disp_in = a.disp + (long)b * a.disp_sb + (long)l_lo * a.disp_sl + 4 * lane;
+  // (lanes past the end of a row -- its last segment may be partial -- read the
+  // row's last four pixels instead and store nothing)
+  const float* const g_tex_in = a.tex + (long)b * a.tex_sb + (long)l_lo * a.tex_sl;
+  const float* const g_disp_in = a.disp + (long)b * a.disp_sb + (long)l_lo * a.disp_sl;
+  const int px_last = a.W - 4;
   float* const o_tex = a.g_tex + ((size_t)l_lo * a.B + b) * ((size_t)a.H * a.W) * 3 + 12 * lane;
   float* const o_disp = a.g_disp + ((size_t)l_lo * a.B + b) * ((size_t)a.H * a.W) + 4 * lane;
   const size_t lay_px = (size_t)a.B * a.H * a.W;
@@ -182,8 +185,9 @@ __device__ __forceinline__ void bs_run(const BSArgs& a, const float (&m)[8],
   };
   auto load_item = [&](BSIn& o, const Pos& p, bool live) {
     const Pos q = live ? p : Pos{0, 0, 0};  // past the end: a harmless re-read
-    bs_load<PACK>(o, g_disp_in + (long)q.l * a.disp_sl + (long)(ys + q.r) * a.disp_sy + q.sg * BS_SEG,
-                  g_tex_in + (long)q.l * a.tex_sl + (long)(ys + q.r) * a.tex_sy + (PACK ? 4 : 3) * q.sg * BS_SEG);
+    const int px = min(q.sg * BS_SEG + 4 * lane, px_last);
+    bs_load<PACK>(o, g_disp_in + (long)q.l * a.disp_sl + (long)(ys + q.r) * a.disp_sy + px,
+                  g_tex_in + (long)q.l * a.tex_sl + (long)(ys + q.r) * a.tex_sy + (PACK ? 4 : 3) * px);
   };
   auto item = [&](const BSIn& in, const Pos& p) {
     const int y = ys + p.r, sg = p.sg, l = p.l;
@@ -268,11 +272,13 @@ __device__ __forceinline__ void bs_run(const BSArgs& a, const float (&m)[8],
       if (((i + 1) & ((1 << LSI_BS_FENCE) - 1)) == 0 && i < 3) asm volatile("" ::: "memory");
     }
     const size_t po = (size_t)l * lay_px + (size_t)y * a.W + (size_t)sg * BS_SEG;
-    float* pt = o_tex + 3 * po;
-    *reinterpret_cast<float4*>(pt) = make_float4(ot[0], ot[1], ot[2], ot[3]);
-    *reinterpret_cast<float4*>(pt + 4) = make_float4(ot[4], ot[5], ot[6], ot[7]);
-    *reinterpret_cast<float4*>(pt + 8) = make_float4(ot[8], ot[9], ot[10], ot[11]);
-    *reinterpret_cast<float4*>(o_disp + po) = make_float4(od[0], od[1], od[2], od[3]);
+    if (sg * BS_SEG + 4 * lane < a.W) {
+      float* pt = o_tex + 3 * po;
+      *reinterpret_cast<float4*>(pt) = make_float4(ot[0], ot[1], ot[2], ot[3]);
+      *reinterpret_cast<float4*>(pt + 4) = make_float4(ot[4], ot[5], ot[6], ot[7]);
+      *reinterpret_cast<float4*>(pt + 8) = make_float4(ot[8], ot[9], ot[10], ot[11]);
+      *reinterpret_cast<float4*>(o_disp + po) = make_float4(od[0], od[1], od[2], od[3]);
+    }
   };
 
   Pos p0{0, 0, 0}, p1{0, 0, 0};
@@ -305,16 +311,17 @@ __global__ __launch_bounds__(BS_T, LSI_BS_WPE) void splat_bwd_stream_kernel(BSAr
   // ---- loads of the wave's first two items, before anything else -------------
   BSIn set[2];
   {
-    const float* const g_tex_in = a.tex + (long)b * a.tex_sb + (long)l_lo * a.tex_sl + (PACK ? 16 : 12) * lane;
-    const float* const g_disp_in = a.disp + (long)b * a.disp_sb + (long)l_lo * a.disp_sl + 4 * lane;
+    const float* const g_tex_in = a.tex + (long)b * a.tex_sb + (long)l_lo * a.tex_sl;
+    const float* const g_disp_in = a.disp + (long)b * a.disp_sb + (long)l_lo * a.disp_sl;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const int it = wave + k * BS_NW;
       const int itc = it < nitem ? it : 0;
       const int rs = itc / NL, l = itc - rs * NL;
       const int r = rs / nseg, sg = rs - r * nseg;
-      bs_load<PACK>(set[k], g_disp_in + (long)l * a.disp_sl + (long)(ys + r) * a.disp_sy + sg * BS_SEG,
-                    g_tex_in + (long)l * a.tex_sl + (long)(ys + r) * a.tex_sy + (PACK ? 4 : 3) * sg * BS_SEG);
+      const int px = min(sg * BS_SEG + 4 * lane, a.W - 4);
+      bs_load<PACK>(set[k], g_disp_in + (long)l * a.disp_sl + (long)(ys + r) * a.disp_sy + px,
+                    g_tex_in + (long)l * a.tex_sl + (long)(ys + r) * a.tex_sy + (PACK ? 4 : 3) * px);
     }
   }
 
@@ -396,7 +403,7 @@ bool lsi_bwd_stream_applies(const LsiSplatDesc* d, const float* tex,
   if (d->path != LSI_PATH_STREAM || !(d->tune_window & LSI_STREAM_SIMPLE_BIT))
     return false;
   if (d->flags & (LSI_HAS_MASK | LSI_WANT_DISP)) return false;
-  if (d->W % BS_SEG != 0 || d->L < 1) return false;
+  if (d->W % 4 != 0 || d->W < 4 || d->L < 1) return false;
   // (LSI_PACKED_RGBD: the entry points have verified the caller's statement)
   const bool pack = (d->flags & LSI_PACKED_RGBD) != 0;
   if (!pack && (d->tex_sc != 1 || d->tex_sx != 3 || d->disp_sx != 1)) return false;
@@ -427,7 +434,7 @@ int lsi_bwd_stream_launch(const LsiSplatDesc* d, const float* tex,
       a.vec4 = a.vec4 && aligned16b(c->img) && aligned16b(c->wts) &&
                aligned16b(c->g_img) && aligned16b(c->g_wts);
   a.B = d->B; a.H = d->H; a.W = d->W; a.Ht = d->Ht; a.Wt = d->Wt; a.L = d->L;
-  a.nseg = d->W / BS_SEG;
+  a.nseg = (d->W + BS_SEG - 1) / BS_SEG;
   a.tex_sb = (int)d->tex_sb; a.tex_sl = (int)d->tex_sl; a.tex_sy = (int)d->tex_sy;
   a.disp_sb = (int)d->disp_sb; a.disp_sl = (int)d->disp_sl; a.disp_sy = (int)d->disp_sy;
   a.s = d->trg_downsampling; a.max_disp = d->max_disp; a.zscale = d->zbuf_scale;

@@ -33,7 +33,7 @@ constexpr int LSI_STREAM_SIMPLE_BIT = 1 << 20;
 size_t lsi_stream_workspace_bytes(const LsiSplatDesc* d);
 int lsi_stream_launch(const SplatArgs& a, hipStream_t stream);
 // The compact STREAM instance (lsi_splat_stream2.hip): compose mode, no mask,
-// unit normaliser, channels-last textures, rows of whole 256-pixel segments.
+// unit normaliser, channels-last textures or RGBD pixels, W % 4 == 0.
 bool lsi_stream2_applies(const SplatArgs& a, bool simple, int layout);
 // disp_pass: the per-layer-tile instance as the disparity pass (only output:
 // a.out_disp = max over layers of each layer's normalised splatted disparity)

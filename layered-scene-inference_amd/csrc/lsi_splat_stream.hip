@@ -1658,10 +1658,10 @@ extern "C" int lsi_stream_ok(const LsiSplatDesc* d, const float* M) {
   if (layout != 2 &&
       (d->disp_sx != 1 || d->disp_sy % 4 || d->disp_sb % 4 || d->disp_sl % 4))
     return 0;
-  // RGBD pixels: only the compact instance reads them (rows of whole segments,
-  // no mask, unit normaliser: checked below) -- else the any-stride TILE path
+  // RGBD pixels: only the compact instance reads them (no mask, unit
+  // normaliser: checked below) -- else the any-stride TILE path
   if ((layout == 2 || want_disp) &&
-      (layout == 1 || d->W % SEG != 0 || d->L > 15 ||
+      (layout == 1 || d->L > 15 ||
        (d->flags & (LSI_HAS_MASK | LSI_DETERMINISTIC)) ||
        (layout == 0 && (d->tex_sx != 3 || d->tex_sc != 1))))
     return 0;

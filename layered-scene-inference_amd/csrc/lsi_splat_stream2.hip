@@ -1,7 +1,8 @@
 // LSI_PATH_STREAM, compact instance: the configuration every documented
 // command of the reference runs (ldi.py:71-182 with compose_layers=True, no
-// mask input, rectified stereo with unit normaliser, channels-last textures,
-// rows that are whole 256-pixel segments).  Same algorithm and the same exact
+// mask input, rectified stereo with unit normaliser, channels-last textures
+// or RGBD pixels, W % 4 == 0: rows of 256-pixel segments, the last one
+// possibly partial).  Same algorithm and the same exact
 // arithmetic as splat_stream_kernel (lsi_splat_stream.hip, which keeps every
 // other case); what differs is everything around the pixel arithmetic:
 //   * no prologue before the first loads: every wave finds the band's source
@@ -65,6 +66,7 @@ struct S2Args {
   // per-layer tiles sum (d * w, -, -, w); the only output is out_disp
   float* out_disp;
   int B, H, Ht, Wt, L, nseg;
+  int W;  // source width (W % 4 == 0; the last segment of a row may be partial)
   int tex_sl, tex_sb, tex_sy, disp_sl, disp_sb, disp_sy;  // element strides
   float s, max_disp, zA, zB, lbg;  // exp2(fma(clip(d), zA, zB)); L * bg weight
   float bg;                        // bg weight of one layer's canvas
@@ -400,15 +402,23 @@ __global__ __launch_bounds__(MAXT) void splat_stream2_kernel(S2Args a) {
   const float m_lane = a.M[16 * b + (lane & 7)];
   // ---- loader state ---------------------------------------------------------
   // (PACK: RGBD pixels, 16 floats per lane; the disparity pointer is unused)
-  const float* const g_tex = a.tex + (long)b * a.tex_sb + (PACK ? 16 : 12) * lane;
-  const float* const g_disp = a.disp + (long)b * a.disp_sb + 4 * lane;
+  // Lanes past the end of a row (its last segment may be partial: W % 256 != 0)
+  // read the row's last four pixels instead -- always inside the tensor -- and
+  // are switched off where the item is computed.
+  const float* const g_tex0 = a.tex + (long)b * a.tex_sb;
+  const float* const g_disp0 = a.disp + (long)b * a.disp_sb;
+  const int px_last = a.W - 4;
+  const int px_own = min(4 * lane, px_last);
+  const float* const g_tex = g_tex0 + (PACK ? 4 : 3) * px_own;   // (harmless re-reads)
+  const float* const g_disp = g_disp0 + px_own;
   const int tex_sl = a.tex_sl, disp_sl = a.disp_sl;
   const float* p_disp = g_disp;
   const float* p_tex = g_tex;
   int ld_left = 0, ld_done = 0, ld_slot = 0, ld_first = 0;
   auto aim = [&](int y, int sg, int l0) {
-    p_disp = g_disp + (long)l0 * disp_sl + (long)y * a.disp_sy + sg * SEG;
-    p_tex = g_tex + (long)l0 * tex_sl + (long)y * a.tex_sy + (PACK ? 4 : 3) * sg * SEG;
+    const int px = min(sg * SEG + 4 * lane, px_last);
+    p_disp = g_disp0 + (long)l0 * disp_sl + (long)y * a.disp_sy + px;
+    p_tex = g_tex0 + (long)l0 * tex_sl + (long)y * a.tex_sy + (PACK ? 4 : 3) * px;
   };
   auto load_layer = [&](Px& o) {
     if (PACK) {  // d4, t0, t1, t2 = the lane's pixels 0 .. 3 as (r, g, b, d)
@@ -691,6 +701,8 @@ __global__ __launch_bounds__(MAXT) void splat_stream2_kernel(S2Args a) {
   float tmin = 0.f, wy0 = 0.f, wy1 = 0.f, wymin = 0.f, wymax = 0.f, wlo_f = 0.f;
   int use_a = 0, use_b = 0;
   float qb[4] = {0.f, 0.f, 0.f, 0.f};
+  bool lane_dead = false;   // this lane's pixels of the current unit are past the row end
+  const bool ragged = (a.W & (SEG - 1)) != 0;
   int qn = 0;
   // merge: the lane's window slots (cells lane, lane + 64, ...)
   const int mslot = (lane >> 1) + (lane & 1) * WHS;
@@ -754,6 +766,7 @@ __global__ __launch_bounds__(MAXT) void splat_stream2_kernel(S2Args a) {
       t_wlo = (t_win & 0xffff) - 32768; t_wwin = t_win >> 16;
       const int yx = S2_RFL(tx.yx);
       const int y = yx & 0xffff, xs = (yx >> 16) * SEG;
+      lane_dead = xs + 4 * lane >= a.W;
       tmin = tx.tmin;
       const float py = (float)y + 0.5f;
       const float pym01 = py * m[1];
@@ -789,11 +802,19 @@ __global__ __launch_bounds__(MAXT) void splat_stream2_kernel(S2Args a) {
       const float txp[12] = {cur.d4.x, cur.d4.y, cur.d4.z, cur.t0.x,
                              cur.t0.y, cur.t0.z, cur.t1.x, cur.t1.y,
                              cur.t1.z, cur.t2.x, cur.t2.y, cur.t2.z};
-      const float (&dv)[4] = PACK ? dvp : dvn;
+      const float (&dv0)[4] = PACK ? dvp : dvn;
       const float (&tx0_)[12] = PACK ? txp : txn;
-      float tx_[12];
+      float dv[4], tx_[12];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) dv[k] = dv0[k];
 #pragma unroll
       for (int k = 0; k < 12; ++k) tx_[k] = tx0_[k];
+      if (ragged) {  // pixels past the row end: disparity 0 (weight 0), colour 0
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dv[k] = lane_dead ? 0.0f : dv[k];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) tx_[k] = lane_dead ? 0.0f : tx_[k];
+      }
       if (BOTH && a.out_disp) {  // the disparity pass: the "colour" is (d, 0, 0)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -1230,7 +1251,7 @@ struct S2Plan { int R, nw, cell, cap, qcap, ilv, nsplit, lsub; size_t lds; doubl
 // still gives every CU a workgroup.
 int s2_plan(const LsiSplatDesc* d, int wmax, int maxnw, bool both, S2Plan* out) {
   const int nt = both ? d->L : 1;
-  const int nseg = d->W / SEG;
+  const int nseg = (d->W + SEG - 1) / SEG;
   static const char* cap_env = getenv("LSI_STREAM_LDS_CAP");
   const size_t lds_cap = cap_env ? (size_t)atol(cap_env) : 160 * 1024;
   static const char* ns_env = getenv("LSI_S2_NSPLIT");  // experiments
@@ -1332,7 +1353,7 @@ bool lsi_stream2_applies(const SplatArgs& a, bool simple, int layout) {
       (both ? 0u : (unsigned)LSI_COMPOSE))
     return false;
   if (both && (d->L > 15 || !a.out_wts_c)) return false;
-  if (d->W % SEG != 0 || d->H > 65535 || d->W / SEG > 32767) return false;
+  if (d->W % 4 != 0 || d->W < 4 || d->H > 65535 || (d->W + SEG - 1) / SEG > 32767) return false;
   if (layout == 0 && (d->tex_sx != 3 || d->tex_sc != 1 || d->disp_sx != 1)) return false;
   return true;
 }
@@ -1349,7 +1370,8 @@ int lsi_stream2_launch(const SplatArgs& a, int wmax, hipStream_t stream,
   k.out_img_c = a.out_img_c; k.out_wts_c = a.out_wts_c;
   k.out_disp = disp_pass ? a.out_disp : nullptr;
   k.B = d->B; k.H = d->H; k.Ht = d->Ht; k.Wt = d->Wt; k.L = d->L;
-  k.nseg = d->W / SEG;
+  k.nseg = (d->W + SEG - 1) / SEG;
+  k.W = d->W;
   k.tex_sl = (int)d->tex_sl; k.tex_sb = (int)d->tex_sb; k.tex_sy = (int)d->tex_sy;
   k.disp_sl = (int)d->disp_sl; k.disp_sb = (int)d->disp_sb; k.disp_sy = (int)d->disp_sy;
   k.s = d->trg_downsampling; k.max_disp = d->max_disp;

@@ -540,10 +540,12 @@ GENERAL_STREAM = 0x40000000  # LsiSplatDesc.reserved: not the compact instance
                                   'clampy', 'nonfinite', 'zoom_out', 'zoom_in'])
 @pytest.mark.parametrize('shape', [(2, 2, 64, 256), (4, 1, 24, 768),
                                    (1, 3, 10, 512), (3, 1, 130, 256),
-                                   (9, 1, 12, 256)])
+                                   (9, 1, 12, 256), (2, 2, 20, 384),
+                                   (3, 1, 16, 132), (2, 1, 8, 640)])
 def test_stream_compact_instance_routes(kind, shape, dev, ref_cpu):
   """The compact STREAM instance (csrc/lsi_splat_stream2.hip: compose mode, no
-  mask, unit normaliser, rows of whole 256-pixel segments) on every internal
+  mask, unit normaliser; rows of 256-pixel segments, the last one possibly
+  partial: W = 384, 132, 640) on every internal
   route, against the C oracle and against the general stream kernel, for
   several band heights (incl. bands that do not divide the image) and both
   merge exclusions."""
@@ -703,9 +705,10 @@ def test_stream_path_rejects_what_it_cannot_render(dev):
   rs = np.random.RandomState(22)
   tex, disp, mat = _synth(rs, 1, 1, 16, 32)
   ldi_src = [torch.tensor(tex, device=dev), None, torch.tensor(disp, device=dev)]
+  # (the disparity output: with the composed view only)
   with pytest.raises(RuntimeError, match='precondition'):
-    ldi.forward_splat_matrix(ldi_src, torch.tensor(mat), compute_trg_disp=True,
-                             path='stream')
+    ldi.forward_splat_matrix(ldi_src, torch.tensor(mat), compose_layers=False,
+                             compute_trg_disp=True, path='stream')
   tex2, disp2, mat2 = _synth(rs, 1, 1, 16, 30)   # W % 4 != 0
   with pytest.raises(RuntimeError, match='precondition'):
     ldi.forward_splat_matrix(
@@ -1149,14 +1152,13 @@ def test_streamed_backward_matches_autograd_and_the_gather_kernel(kind, both, de
     assert bad.mean() < 0.005, (name, bad.mean(), np.abs(a - want).max() / scale)
 
 
-@pytest.mark.parametrize('w', [256, 512, 384])
+@pytest.mark.parametrize('w', [256, 512, 384, 68])
 def test_packed_rgbd_pixels_render_like_separate_tensors(w, dev):
   """Colour and disparity given as views of ONE [L,B,H,W,4] buffer (what a
   channels-last conv head writes, sliced): the descriptor carries
   LSI_PACKED_RGBD, the compact STREAM instance and the streamed backward read
-  whole RGBD pixels with 16-byte loads (W % 256 == 0; other widths go to the
-  any-stride path) -- outputs and gradients as for separate contiguous
-  tensors."""
+  whole RGBD pixels with 16-byte loads (also rows whose last 256-pixel segment
+  is partial) -- outputs and gradients as for separate contiguous tensors."""
   from lsi import _C
   from lsi.geometry import ldi
   nl, b, h = 3, 2, 24
@@ -1227,7 +1229,7 @@ def test_packed_rgbd_flag_is_verified_by_the_entry_points(dev):
 
 
 @pytest.mark.parametrize('packed', [False, True])
-@pytest.mark.parametrize('w', [256, 512])
+@pytest.mark.parametrize('w', [256, 512, 384, 140])
 def test_stream_renders_the_target_disparity_of_rectified_pairs(w, packed, dev):
   """forward_splat(compose_layers=True, compute_trg_disp=True) -- what the
   evaluation script asks for (ldi_pred_eval.py:340-353) -- on a rectified pair:
@@ -1272,7 +1274,9 @@ def test_stream_renders_the_target_disparity_of_rectified_pairs(w, packed, dev):
 
 
 @pytest.mark.parametrize('shape', [(1, 1, 37, 256, 1.0), (2, 3, 18, 768, 0.5),
-                                   (4, 1, 40, 512, 0.25), (2, 2, 8, 256, 0.5)])
+                                   (4, 1, 40, 512, 0.25), (2, 2, 8, 256, 0.5),
+                                   (2, 2, 12, 384, 0.5), (3, 1, 10, 132, 0.5),
+                                   (2, 1, 6, 640, 1.0)])
 def test_streamed_backward_shapes_and_scales(shape, dev, monkeypatch):
   """The streamed backward against the gather kernel over target scales 1 /
   0.5 / 0.25, one to three row segments, band remainders (H not a multiple of

@@ -23,7 +23,7 @@ for it in range(n):
   inv = int(round(1 / s))
   h = int(rs.choice([4, 12, 36, 64, 100, 256])) // inv * inv
   h = max(h, inv)
-  w = int(rs.choice([256, 256, 512, 768, 1024]))
+  w = int(rs.choice([256, 256, 512, 768, 1024, 384, 640, 132, 260, 1000, 20]))
   dmax = float(rs.choice([0.4, 1.0]))
   pred = rs.rand(nl, b, h, w, 4).astype(np.float32)
   kind = rs.choice(['noise', 'smooth', 'const', 'steep'])
