@@ -107,3 +107,42 @@ def test_kitti_configs_full_batch(workload, batch, dev, ref_cpu):
     _check(out, want, False)
     if workload != 'cfg2':
       break   # per-layer outputs of the large configs: covered by cfg2's shape
+
+
+@pytest.mark.parametrize('workload,batch', [('cfg3', 32), ('cfg2', 4)])
+def test_kitti_configs_disparity_output_and_backward_full_size(workload, batch, dev,
+                                                                ref_cpu, monkeypatch):
+  """The round-3 kernels at BASELINE's sizes: (1) compose + target disparity
+  (the evaluation call: composed view by the compact STREAM instance, disparity
+  by its per-layer-tile pass) against the C oracle; (2) both outputs of a
+  training step from one sweep against the oracle's per-layer and composed
+  views; (3) the streamed backward of both against the one-thread-per-pixel
+  gather kernel, on RGBD-pixel inputs (what the network hands over)."""
+  from lsi.geometry import ldi
+  tex, _, disp, mat, md, bg = _inputs(workload, batch, 70 + batch)
+  want = ref_cpu.forward_splat(tex.numpy(), None, disp.numpy(), mat.numpy(),
+                               0.5, bg, md, ZB, True)
+  out = _render(dev, tex, None, disp, mat, md, bg, 'auto', True)
+  _check(out, want, True)
+  del out
+  kw = dict(trg_downsampling=0.5, bg_layer_disp=bg, max_disp=md, zbuf_scale=ZB)
+  pred = torch.cat([tex, disp], dim=-1)
+  grads = {}
+  for stream in ('1', '0'):
+    monkeypatch.setenv('LSI_BWD_STREAM', stream)
+    p = pred.to(dev).requires_grad_(True)
+    img, wts, img_c, wts_c = ldi.forward_splat_both(
+        [p[..., 0:3], None, p[..., 3:4]], mat, **kw)
+    if stream == '1':
+      per_layer = ref_cpu.forward_splat(tex.numpy(), None, disp.numpy(), mat.numpy(),
+                                        0.5, bg, md, ZB, False, want_disp=False)
+      _check((img.detach(), wts.detach()), per_layer, False)
+      _check((img_c.detach(), wts_c.detach()), want, False)
+    g = torch.Generator().manual_seed(3)
+    ci = torch.rand(img.shape, generator=g).to(dev)
+    cc = torch.rand(img_c.shape, generator=g).to(dev)
+    ((img * ci).sum() + (img_c * cc).sum() + 1e-3 * torch.log(wts_c).sum()).backward()
+    grads[stream] = p.grad.cpu().double().numpy()
+    del p, img, wts, img_c, wts_c
+  scale = np.abs(grads['0']).max() + 1e-30
+  assert np.abs(grads['1'] - grads['0']).max() <= 2e-5 * scale
