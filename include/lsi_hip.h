@@ -133,8 +133,13 @@ int lsi_rowband_ok(const LsiSplatDesc* desc, const float* M_host);
 /*
  * Host-side test for LSI_PATH_STREAM on a HOST copy of the matrices: returns 0
  * when the path does not apply (projection not row-uniform, unsupported
- * strides/alignment, LSI_WANT_DISP), else the number of LDS window cells per
- * wave the call needs (put it in desc->tune_window).
+ * strides/alignment), else the number of LDS window cells per wave the call
+ * needs, plus flag bits (put the value in desc->tune_window unchanged).
+ * LSI_WANT_DISP is rendered for composed output of unit-normaliser pairs
+ * (channels-last or RGBD-pixel textures, no mask, at most 15 layers: the
+ * composed view, then a second launch with one tile per layer for the
+ * disparity, ldi.py:147-180); LSI_PACKED_RGBD inputs under the same
+ * conditions; other requests return 0 (LSI_PATH_TILE renders them).
  */
 int lsi_stream_ok(const LsiSplatDesc* desc, const float* M_host);
 

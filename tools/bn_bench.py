@@ -10,6 +10,8 @@ from lsi.nnutils import _hip_bn
 
 ap = argparse.ArgumentParser()
 ap.add_argument('--bf16', default='true')
+ap.add_argument('--batch', type=int, default=8)
+ap.add_argument('--groups', type=int, default=2)
 args = ap.parse_args()
 dt = torch.bfloat16 if args.bf16 == 'true' else torch.float32
 es = 2 if dt == torch.bfloat16 else 4
@@ -19,13 +21,13 @@ SHAPES = [(32, 256, 768), (32, 128, 384), (64, 128, 384), (64, 64, 192), (128, 6
 rows = []
 for c, h, w in SHAPES:
   # rotate over enough tensors to exceed the Infinity Cache
-  nbuf = max(2, int(600e6 // (4 * c * h * w * es)) + 1)
+  nbuf = max(2, int(600e6 // (args.batch * c * h * w * es)) + 1)
   nbuf = min(nbuf, 64)
-  xs = [torch.randn(4, c, h, w, device=dev, dtype=dt).contiguous(memory_format=torch.channels_last).requires_grad_(True) for _ in range(nbuf)]
+  xs = [torch.randn(args.batch, c, h, w, device=dev, dtype=dt).contiguous(memory_format=torch.channels_last).requires_grad_(True) for _ in range(nbuf)]
   beta = torch.zeros(c, device=dev, requires_grad=True)
-  gy = torch.randn(4, c, h, w, device=dev, dtype=dt).contiguous(memory_format=torch.channels_last)
+  gy = torch.randn(args.batch, c, h, w, device=dev, dtype=dt).contiguous(memory_format=torch.channels_last)
   def fwd(i):
-    return _hip_bn.batch_norm_relu(xs[i % nbuf], beta)
+    return _hip_bn.batch_norm_relu(xs[i % nbuf], beta, 1e-3, True, args.groups)
   iters = 20
   side = torch.cuda.Stream(dev)
   side.wait_stream(torch.cuda.current_stream(dev))
@@ -53,7 +55,7 @@ for c, h, w in SHAPES:
       side.synchronize()
       times.append(e0.elapsed_time(e1) * 1e3 / (5 * iters))
   tf, tb = times[0], times[1] - times[0]
-  nb = 4 * c * h * w * es
+  nb = args.batch * c * h * w * es
   rows.append({'C': c, 'hw': [h, w], 'MB': round(nb / 1e6, 2), 'fwd_us': round(tf, 2), 'bwd_us': round(tb, 2),
                'fwd_GBps': round(3 * nb / tf / 1e3), 'bwd_GBps': round(5 * nb / tb / 1e3)})
   print(json.dumps(rows[-1]))
