@@ -339,7 +339,8 @@ struct Px { float4 d4, t0, t1, t2; };
 // BOTH: lsi_splat_fwd_both -- the per-layer views AND the composed one from one
 // sweep: one tile per layer in LDS, every item (one layer of a unit) merges its
 // window into its layer's tile, the epilogue writes L + 1 views.
-template <int NSETS, bool CELL, int MAXT, bool BOTH = false, bool PACK = false>
+template <int NSETS, bool CELL, int MAXT, bool BOTH = false, bool PACK = false,
+          bool RAGGED = false>
 __global__ __launch_bounds__(MAXT) void splat_stream2_kernel(S2Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -408,7 +409,7 @@ __global__ __launch_bounds__(MAXT) void splat_stream2_kernel(S2Args a) {
   const float* const g_tex0 = a.tex + (long)b * a.tex_sb;
   const float* const g_disp0 = a.disp + (long)b * a.disp_sb;
   const int px_last = a.W - 4;
-  const int px_own = min(4 * lane, px_last);
+  const int px_own = RAGGED ? min(4 * lane, px_last) : 4 * lane;
   const float* const g_tex = g_tex0 + (PACK ? 4 : 3) * px_own;   // (harmless re-reads)
   const float* const g_disp = g_disp0 + px_own;
   const int tex_sl = a.tex_sl, disp_sl = a.disp_sl;
@@ -416,7 +417,7 @@ __global__ __launch_bounds__(MAXT) void splat_stream2_kernel(S2Args a) {
   const float* p_tex = g_tex;
   int ld_left = 0, ld_done = 0, ld_slot = 0, ld_first = 0;
   auto aim = [&](int y, int sg, int l0) {
-    const int px = min(sg * SEG + 4 * lane, px_last);
+    const int px = RAGGED ? min(sg * SEG + 4 * lane, px_last) : sg * SEG + 4 * lane;
     p_disp = g_disp0 + (long)l0 * disp_sl + (long)y * a.disp_sy + px;
     p_tex = g_tex0 + (long)l0 * tex_sl + (long)y * a.tex_sy + (PACK ? 4 : 3) * px;
   };
@@ -702,7 +703,6 @@ __global__ __launch_bounds__(MAXT) void splat_stream2_kernel(S2Args a) {
   int use_a = 0, use_b = 0;
   float qb[4] = {0.f, 0.f, 0.f, 0.f};
   bool lane_dead = false;   // this lane's pixels of the current unit are past the row end
-  const bool ragged = (a.W & (SEG - 1)) != 0;
   int qn = 0;
   // merge: the lane's window slots (cells lane, lane + 64, ...)
   const int mslot = (lane >> 1) + (lane & 1) * WHS;
@@ -766,7 +766,7 @@ __global__ __launch_bounds__(MAXT) void splat_stream2_kernel(S2Args a) {
       t_wlo = (t_win & 0xffff) - 32768; t_wwin = t_win >> 16;
       const int yx = S2_RFL(tx.yx);
       const int y = yx & 0xffff, xs = (yx >> 16) * SEG;
-      lane_dead = xs + 4 * lane >= a.W;
+      if (RAGGED) lane_dead = xs + 4 * lane >= a.W;
       tmin = tx.tmin;
       const float py = (float)y + 0.5f;
       const float pym01 = py * m[1];
@@ -809,7 +809,7 @@ __global__ __launch_bounds__(MAXT) void splat_stream2_kernel(S2Args a) {
       for (int k = 0; k < 4; ++k) dv[k] = dv0[k];
 #pragma unroll
       for (int k = 0; k < 12; ++k) tx_[k] = tx0_[k];
-      if (ragged) {  // pixels past the row end: disparity 0 (weight 0), colour 0
+      if (RAGGED) {  // pixels past the row end: disparity 0 (weight 0), colour 0
 #pragma unroll
         for (int k = 0; k < 4; ++k) dv[k] = lane_dead ? 0.0f : dv[k];
 #pragma unroll
@@ -1395,16 +1395,16 @@ int lsi_stream2_launch(const SplatArgs& a, int wmax, hipStream_t stream,
     k.stamps = reinterpret_cast<long long*>(a.canvas);
 #endif
   const bool pack = (d->flags & LSI_PACKED_RGBD) != 0;  // (verified by the caller)
-  const void* fn;
-  if (both)  // (row locks: s2_plan never picks cell locks with both outputs)
-    fn = pack ? (const void*)splat_stream2_kernel<LSI_S2_NSETS, false, LSI_S2_MAXT, true, true>
-              : (const void*)splat_stream2_kernel<LSI_S2_NSETS, false, LSI_S2_MAXT, true>;
-  else if (plan.cell)
-    fn = pack ? (const void*)splat_stream2_kernel<LSI_S2_NSETS, true, LSI_S2_MAXT, false, true>
-              : (const void*)splat_stream2_kernel<LSI_S2_NSETS, true, LSI_S2_MAXT>;
-  else
-    fn = pack ? (const void*)splat_stream2_kernel<LSI_S2_NSETS, false, LSI_S2_MAXT, false, true>
-              : (const void*)splat_stream2_kernel<LSI_S2_NSETS, false, LSI_S2_MAXT>;
+  const bool ragged = d->W % SEG != 0;  // the last segment of a row is partial
+  // <NSETS, cell locks, MAXT, both outputs, RGBD pixels, partial last segment>
+  // (row locks with both outputs: s2_plan never picks cell locks there)
+#define S2_FN(C, B, P, R) (const void*)splat_stream2_kernel<LSI_S2_NSETS, C, LSI_S2_MAXT, B, P, R>
+#define S2_PICK(C, B) (pack ? (ragged ? S2_FN(C, B, true, true) : S2_FN(C, B, true, false)) \
+                            : (ragged ? S2_FN(C, B, false, true) : S2_FN(C, B, false, false)))
+  const void* fn = both ? S2_PICK(false, true)
+                        : (plan.cell ? S2_PICK(true, false) : S2_PICK(false, false));
+#undef S2_PICK
+#undef S2_FN
   if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)plan.lds) != hipSuccess)
     return LSI_ELAUNCH;
