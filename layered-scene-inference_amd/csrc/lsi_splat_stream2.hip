@@ -357,7 +357,11 @@ __global__ __launch_bounds__(MAXT) void splat_stream2_kernel(S2Args a) {
     const unsigned xcd = lin & 7u, q = nwg >> 3, r8 = nwg & 7u;
     const unsigned base =
         xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q;
+#ifdef S2X_ROUNDROBIN  // experiment: workgroup i keeps id i (XCD i % 8: an image's bands on all XCDs)
+    const unsigned id = lin + 0 * base;
+#else
     const unsigned id = base + (lin >> 3);
+#endif
     b = s2_div_small((int)id, (int)gridDim.x, a.inv_gx);
     band = (int)id - b * (int)gridDim.x;
   }
