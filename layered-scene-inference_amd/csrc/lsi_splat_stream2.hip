@@ -1209,11 +1209,13 @@ __global__ __launch_bounds__(MAXT) void splat_stream2_kernel(S2Args a) {
         a.out_wts[o] = Wsum;
         C.x += A.x + bg; C.y += A.y + bg; C.z += A.z + bg; C.w += Wsum;
       }
-      const float rw = __builtin_amdgcn_rcpf(safe_den(C.w));
-      a.out_img_c[3 * (o0 + i) + 0] = C.x * rw;
-      a.out_img_c[3 * (o0 + i) + 1] = C.y * rw;
-      a.out_img_c[3 * (o0 + i) + 2] = C.z * rw;
-      a.out_wts_c[o0 + i] = C.w;
+      if (a.out_img_c) {
+        const float rw = __builtin_amdgcn_rcpf(safe_den(C.w));
+        a.out_img_c[3 * (o0 + i) + 0] = C.x * rw;
+        a.out_img_c[3 * (o0 + i) + 1] = C.y * rw;
+        a.out_img_c[3 * (o0 + i) + 2] = C.z * rw;
+        a.out_wts_c[o0 + i] = C.w;
+      }
     }
   } else {
     const float lbg = a.lbg;
@@ -1353,10 +1355,14 @@ bool lsi_stream2_applies(const SplatArgs& a, bool simple, int layout) {
   if (((d->reserved >> 16) & 3) == 2) return false;  // exchange bands asked for
   if (!simple || (layout != 0 && layout != 2)) return false;
   const bool both = a.out_img_c != nullptr;  // lsi_splat_fwd_both: per-layer + composed
-  if ((d->flags & (LSI_COMPOSE | LSI_HAS_MASK | LSI_WANT_DISP | LSI_DETERMINISTIC)) !=
-      (both ? 0u : (unsigned)LSI_COMPOSE))
-    return false;
-  if (both && (d->L > 15 || !a.out_wts_c)) return false;
+  const unsigned mode = d->flags & (LSI_COMPOSE | LSI_HAS_MASK | LSI_WANT_DISP | LSI_DETERMINISTIC);
+  // per-layer outputs alone (compose_layers=False): the tile-per-layer instance
+  // without its composed view, for small launches (a training-size LDI: 31 us
+  // against the general kernel's 62; at config 3 the general kernel is ahead)
+  const bool layers_only = !both && mode == 0u && (long)d->B * d->L <= 16;
+  if (!layers_only && mode != (both ? 0u : (unsigned)LSI_COMPOSE)) return false;
+  if ((both || layers_only) && d->L > 15) return false;
+  if (both && !a.out_wts_c) return false;
   if (d->W % 4 != 0 || d->W < 4 || d->H > 65535 || (d->W + SEG - 1) / SEG > 32767) return false;
   if (layout == 0 && (d->tex_sx != 3 || d->tex_sc != 1 || d->disp_sx != 1)) return false;
   return true;
@@ -1366,7 +1372,8 @@ int lsi_stream2_launch(const SplatArgs& a, int wmax, hipStream_t stream,
                        bool disp_pass) {
   const LsiSplatDesc* d = &a.d;
   S2Plan plan;
-  const bool both = disp_pass || a.out_img_c != nullptr;
+  // (one tile per layer: both outputs, the disparity pass, per-layer outputs alone)
+  const bool both = disp_pass || a.out_img_c != nullptr || !(d->flags & LSI_COMPOSE);
   if (s2_plan(d, wmax, LSI_S2_MAXT / 64, both, &plan) != LSI_OK) return LSI_EINVAL;
   S2Args k;
   k.tex = a.tex; k.disp = a.disp; k.M = a.M;

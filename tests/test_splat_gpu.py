@@ -1342,3 +1342,28 @@ def test_workspace_covers_every_path_on_tiny_targets(dev):
                                           max_disp=1.0, zbuf_scale=10.0, path=path)
   torch.testing.assert_close(outs['tile'][0], outs['atomic'][0], rtol=0, atol=IMG_ATOL)
   torch.testing.assert_close(outs['tile'][1], outs['atomic'][1], rtol=WTS_RTOL, atol=0)
+
+
+@pytest.mark.parametrize('shape', [(2, 4, 24, 256), (3, 2, 10, 384), (1, 1, 6, 132),
+                                   (15, 1, 8, 256)])
+def test_per_layer_outputs_alone_on_the_compact_instance(shape, dev):
+  """forward_splat(compose_layers=False) of a small rectified LDI (B * L <= 16)
+  runs the tile-per-layer instance of the compact STREAM kernel without its
+  composed view: against the NumPy oracle and the general stream kernel."""
+  from lsi.geometry import ldi
+  nl, b, h, w = shape
+  tex, disp, _, mat = _rectified_case(300 + w + nl, nl, b, h, w)
+  s, bg, md, zb = 0.5, 1e-3, 0.4, 50.0
+  kw = dict(compose_layers=False, trg_downsampling=s, bg_layer_disp=bg, max_disp=md,
+            zbuf_scale=zb)
+  src = [torch.tensor(tex, device=dev), None, torch.tensor(disp, device=dev)]
+  got = [t.cpu().numpy() for t in ldi.forward_splat_matrix(src, torch.tensor(mat), **kw)]
+  gen = [t.cpu().numpy() for t in ldi.forward_splat_matrix(
+      src, torch.tensor(mat), experiment=GENERAL_STREAM, **kw)]
+  want = O.forward_splat(tex, np.ones_like(disp), disp, mat, trg_downsampling=s,
+                         bg_layer_disp=bg, max_disp=md, zbuf_scale=zb,
+                         compose_layers=False)
+  assert got[0].shape == (nl, b, h // 2, w // 2, 3)
+  for other in (gen, (want['img'], want['wts'])):
+    np.testing.assert_allclose(got[0], other[0], rtol=0, atol=IMG_ATOL)
+    np.testing.assert_allclose(got[1], other[1], rtol=WTS_RTOL, atol=0)
