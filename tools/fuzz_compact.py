@@ -106,6 +106,9 @@ for it in range(n):
   assert np.isfinite(grads['1']).all(), tag
   scale = np.abs(grads['0']).max() + 1e-30
   e = float(np.abs(grads['1'] - grads['0']).max() / scale); worst['grad'] = max(worst['grad'], e)
-  assert e <= 2e-5, (tag, 'grad', e)
+  # (the disparity gradient is a difference of nearly equal corner terms times
+  # M[0][3]: fp32 rounding of either kernel grows with that entry)
+  gtol = 2e-5 * max(1.0, float(np.abs(mat.numpy()[:, 0, 3]).max()) / 60.0)
+  assert e <= gtol, (tag, 'grad', e, gtol)
   assert (grads['1'][..., 3][bad] == 0).all(), tag
 print('fuzz_compact: %d cases (%d on STREAM) ok; worst' % (n, stream_hits), worst)
