@@ -191,7 +191,8 @@ int lsi_splat_fwd(const LsiSplatDesc* desc, const float* tex, const float* disp,
  * float4 per output pixel: the gradient w.r.t. the un-normalised canvases).
  * When desc carries the forward's STREAM verdict for rectified pairs (path
  * LSI_PATH_STREAM + tune_window as lsi_stream_ok returned it), channels-last
- * textures (or RGBD pixels) with W % 4 == 0 and no mask, the streamed kernel
+ * textures (or RGBD pixels) with W % 4 == 0 (a mask, if any, with unit pixel
+ * stride), the streamed kernel
  * (csrc/lsi_splat_bwd_stream.hip) derives that canvas in LDS and leaves the
  * workspace untouched; other descriptors take a pre-pass + one thread per
  * source pixel.

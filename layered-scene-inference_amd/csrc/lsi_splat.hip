@@ -836,10 +836,10 @@ int lsi_splat_bwd(const LsiSplatDesc* d, const float* tex, const float* disp,
   hipStream_t stream = (hipStream_t)stream_;
   // rectified pairs rendered by STREAM: the streamed gather (16-byte loads and
   // stores, the band's gradient-canvas rows built in LDS; no pre-pass)
-  if (lsi_bwd_stream_applies(d, tex, disp, g_tex, g_disp_in)) {
+  if (lsi_bwd_stream_applies(d, tex, disp, mask, g_tex, g_disp_in, g_mask)) {
     const LsiBwdCanvas ci = {out_img, out_wts, g_img, g_wts};
-    return lsi_bwd_stream_launch(d, tex, disp, M, &ci, nullptr, g_tex,
-                                 g_disp_in, stream);
+    return lsi_bwd_stream_launch(d, tex, disp, mask, M, &ci, nullptr, g_tex,
+                                 g_disp_in, g_mask, stream);
   }
   const int nl = (d->flags & LSI_COMPOSE) ? 1 : d->L;
   const size_t n = (size_t)nl * d->B * d->Ht * d->Wt;
@@ -912,11 +912,11 @@ int lsi_splat_bwd_both(const LsiSplatDesc* d, const float* tex,
   if ((d->flags & LSI_HAS_MASK) && !mask) return LSI_ENULL;
   if (workspace_bytes < lsi_splat_bwd_workspace_bytes(d)) return LSI_EWORKSPACE;
   hipStream_t stream = (hipStream_t)stream_;
-  if (lsi_bwd_stream_applies(d, tex, disp, g_tex, g_disp_in)) {
+  if (lsi_bwd_stream_applies(d, tex, disp, mask, g_tex, g_disp_in, g_mask)) {
     const LsiBwdCanvas ci = {out_img, out_wts, g_img, g_wts};
     const LsiBwdCanvas cc = {out_img_c, out_wts_c, g_img_c, g_wts_c};
-    return lsi_bwd_stream_launch(d, tex, disp, M, &ci, &cc, g_tex, g_disp_in,
-                                 stream);
+    return lsi_bwd_stream_launch(d, tex, disp, mask, M, &ci, &cc, g_tex, g_disp_in,
+                                 g_mask, stream);
   }
   const size_t n1 = (size_t)d->B * d->Ht * d->Wt;
   hipLaunchKernelGGL(splat_bwd_pre_both_kernel,

@@ -9,7 +9,7 @@
 // (every batch element: M rows 2, 3 = (0,0,1,0), (0,0,0,1), M[1][0] = M[1][3]
 // = 0 -- the target row depends on the source row only, normaliser 1, target
 // disparity = source disparity), channels-last contiguous textures (or RGBD
-// pixels), W % 4 == 0, no mask.
+// pixels), W % 4 == 0; an optional mask with unit pixel stride.
 //
 // * Workgroup = (band of RS consecutive SOURCE rows, batch element[, layer]).
 //   Every source pixel is written exactly once whatever the map does.  The
@@ -66,6 +66,9 @@ struct BSArgs {
   const float* tex;
   const float* disp;
   const float* M;
+  const float* mask;  // L x B x H x W (unit pixel stride) or NULL
+  float* g_mask;      // contiguous L x B x H x W, with mask
+  int mask_sb, mask_sl, mask_sy;
   BSCanvas ci, cc;
   int vec4;  // canvas rows can be read 4 cells at a time (16-byte loads)
   float* g_tex;
@@ -78,7 +81,7 @@ struct BSArgs {
   int GR;       // canvas rows the LDS tile holds (0: always gather from global)
 };
 
-struct BSIn { float4 d4, t0, t1, t2; };
+struct BSIn { float4 d4, t0, t1, t2, mk; };
 
 // Gradient w.r.t. the un-normalised canvases A (3 ch) and W of one cell:
 //   img = A / W',  wts = W,  W' = W + 1e-8 [W == 0]
@@ -153,7 +156,7 @@ typedef const __attribute__((address_space(3))) bs_f4v bs_lds_f4;
 
 // The wave's items, two register sets of loads in flight.  IN_LDS: the band's
 // canvas rows glo .. are in the LDS tile `gt`; else gathered from Gb.
-template <bool IN_LDS, bool PACK>
+template <bool IN_LDS, bool PACK, bool MASK>
 __device__ __forceinline__ void bs_run(const BSArgs& a, const float (&m)[8],
                                        BSIn (&set)[2], const float4* gt,
                                        size_t obi, size_t obc, int b,
@@ -170,6 +173,10 @@ __device__ __forceinline__ void bs_run(const BSArgs& a, const float (&m)[8],
   const float* const g_tex_in = a.tex + (long)b * a.tex_sb + (long)l_lo * a.tex_sl;
   const float* const g_disp_in = a.disp + (long)b * a.disp_sb + (long)l_lo * a.disp_sl;
   const int px_last = a.W - 4;
+  const float* const g_mask_in =
+      MASK ? a.mask + (long)b * a.mask_sb + (long)l_lo * a.mask_sl : nullptr;
+  float* const o_mask =
+      MASK ? a.g_mask + ((size_t)l_lo * a.B + b) * ((size_t)a.H * a.W) + 4 * lane : nullptr;
   float* const o_tex = a.g_tex + ((size_t)l_lo * a.B + b) * ((size_t)a.H * a.W) * 3 + 12 * lane;
   float* const o_disp = a.g_disp + ((size_t)l_lo * a.B + b) * ((size_t)a.H * a.W) + 4 * lane;
   const size_t lay_px = (size_t)a.B * a.H * a.W;
@@ -188,6 +195,9 @@ __device__ __forceinline__ void bs_run(const BSArgs& a, const float (&m)[8],
     const int px = min(q.sg * BS_SEG + 4 * lane, px_last);
     bs_load<PACK>(o, g_disp_in + (long)q.l * a.disp_sl + (long)(ys + q.r) * a.disp_sy + px,
                   g_tex_in + (long)q.l * a.tex_sl + (long)(ys + q.r) * a.tex_sy + (PACK ? 4 : 3) * px);
+    if (MASK)
+      o.mk = *reinterpret_cast<const float4*>(
+          g_mask_in + (long)q.l * a.mask_sl + (long)(ys + q.r) * a.mask_sy + px);
   };
   auto item = [&](const BSIn& in, const Pos& p) {
     const int y = ys + p.r, sg = p.sg, l = p.l;
@@ -206,7 +216,8 @@ __device__ __forceinline__ void bs_run(const BSArgs& a, const float (&m)[8],
                            in.t1.x, in.t1.y, in.t1.z, in.t2.x, in.t2.y, in.t2.z};
     const float (&dv)[4] = PACK ? dvp : dvn;
     const float (&tx)[12] = PACK ? txp : txn;
-    float ot[12], od[4];
+    const float mkv[4] = {in.mk.x, in.mk.y, in.mk.z, in.mk.w};
+    float ot[12], od[4], om[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const float d = dv[i];
@@ -257,13 +268,16 @@ __device__ __forceinline__ void bs_run(const BSArgs& a, const float (&m)[8],
       const float a1 = __fmaf_rn(w3, g3.y, __fmaf_rn(w2, g2.y, __fmaf_rn(w1, g1.y, w0 * g0.y)));
       const float a2 = __fmaf_rn(w3, g3.z, __fmaf_rn(w2, g2.z, __fmaf_rn(w1, g1.z, w0 * g0.z)));
       const float gpw = __fmaf_rn(w3, S3, __fmaf_rn(w2, S2, __fmaf_rn(w1, S1, w0 * S0)));
-      ot[3 * i] = a0 * zw; ot[3 * i + 1] = a1 * zw; ot[3 * i + 2] = a2 * zw;
-      const float k0 = w0 != 0.0f ? zw * S0 : 0.0f, k1 = w1 != 0.0f ? zw * S1 : 0.0f;
-      const float k2 = w2 != 0.0f ? zw * S2 : 0.0f, k3 = w3 != 0.0f ? zw * S3 : 0.0f;
+      // pixel weight = soft z-buffer weight * mask (ldi.py:145-146)
+      const float pw = MASK ? zw * mkv[i] : zw;
+      ot[3 * i] = a0 * pw; ot[3 * i + 1] = a1 * pw; ot[3 * i + 2] = a2 * pw;
+      if (MASK) om[i] = gpw * zw;
+      const float k0 = w0 != 0.0f ? pw * S0 : 0.0f, k1 = w1 != 0.0f ? pw * S1 : 0.0f;
+      const float k2 = w2 != 0.0f ? pw * S2 : 0.0f, k3 = w3 != 0.0f ? pw * S3 : 0.0f;
       // corner weights -> X: d wx0/dX = -v0, d wx1/dX = +v1
       const float gX = -ax.v0 * (k0 * ay.w0 + k2 * ay.w1) + ax.v1 * (k1 * ay.w0 + k3 * ay.w1);
       const float inr = (xn >= 0.0f && xn <= 1.0f) ? 1.0f : 0.0f;
-      const float gD = gpw * zw * zs_md * inr;
+      const float gD = gpw * pw * zs_md * inr;
       // (M[1][3] == 0: the row coordinate does not move with the disparity)
       const float gd = (gX * s) * m[3] + gD;
       od[i] = ok ? gd : 0.0f;
@@ -278,6 +292,8 @@ __device__ __forceinline__ void bs_run(const BSArgs& a, const float (&m)[8],
       *reinterpret_cast<float4*>(pt + 4) = make_float4(ot[4], ot[5], ot[6], ot[7]);
       *reinterpret_cast<float4*>(pt + 8) = make_float4(ot[8], ot[9], ot[10], ot[11]);
       *reinterpret_cast<float4*>(o_disp + po) = make_float4(od[0], od[1], od[2], od[3]);
+      if (MASK)
+        *reinterpret_cast<float4*>(o_mask + po) = make_float4(om[0], om[1], om[2], om[3]);
     }
   };
 
@@ -294,7 +310,7 @@ __device__ __forceinline__ void bs_run(const BSArgs& a, const float (&m)[8],
   }
 }
 
-template <bool PACK>
+template <bool PACK, bool MASK>
 __global__ __launch_bounds__(BS_T, LSI_BS_WPE) void splat_bwd_stream_kernel(BSArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float4* const gt = reinterpret_cast<float4*>(smem);  // [GR][Wt]
@@ -322,6 +338,10 @@ __global__ __launch_bounds__(BS_T, LSI_BS_WPE) void splat_bwd_stream_kernel(BSAr
       const int px = min(sg * BS_SEG + 4 * lane, a.W - 4);
       bs_load<PACK>(set[k], g_disp_in + (long)l * a.disp_sl + (long)(ys + r) * a.disp_sy + px,
                     g_tex_in + (long)l * a.tex_sl + (long)(ys + r) * a.tex_sy + (PACK ? 4 : 3) * px);
+      if (MASK)
+        set[k].mk = *reinterpret_cast<const float4*>(
+            a.mask + (long)b * a.mask_sb + (long)(l_lo + l) * a.mask_sl +
+            (long)(ys + r) * a.mask_sy + px);
     }
   }
 
@@ -383,9 +403,9 @@ __global__ __launch_bounds__(BS_T, LSI_BS_WPE) void splat_bwd_stream_kernel(BSAr
   __syncthreads();
   if (nitem <= 0) return;
   if (in_lds)
-    bs_run<true, PACK>(a, m, set, gt, obi, obc, b, l_lo, NL, ys, nitem, glo, wave, lane);
+    bs_run<true, PACK, MASK>(a, m, set, gt, obi, obc, b, l_lo, NL, ys, nitem, glo, wave, lane);
   else
-    bs_run<false, PACK>(a, m, set, gt, obi, obc, b, l_lo, NL, ys, nitem, glo, wave, lane);
+    bs_run<false, PACK, MASK>(a, m, set, gt, obi, obc, b, l_lo, NL, ys, nitem, glo, wave, lane);
 }
 
 bool aligned16b(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -396,13 +416,21 @@ bool aligned16b(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) ==
 // they take this path (the forward's lsi_stream_ok looked at M on the host and
 // left its verdict in the descriptor).
 bool lsi_bwd_stream_applies(const LsiSplatDesc* d, const float* tex,
-                            const float* disp, const float* g_tex,
-                            const float* g_disp) {
+                            const float* disp, const float* mask,
+                            const float* g_tex, const float* g_disp,
+                            const float* g_mask) {
   if (const char* e = getenv("LSI_BWD_STREAM"))
     if (e[0] == '0') return false;
   if (d->path != LSI_PATH_STREAM || !(d->tune_window & LSI_STREAM_SIMPLE_BIT))
     return false;
-  if (d->flags & (LSI_HAS_MASK | LSI_WANT_DISP)) return false;
+  if (d->flags & LSI_WANT_DISP) return false;
+  if (d->flags & LSI_HAS_MASK) {
+    if (!mask || !g_mask || (d->flags & LSI_PACKED_RGBD) || d->mask_sx != 1) return false;
+    const int64_t ms[] = {d->mask_sl, d->mask_sb, d->mask_sy};
+    for (int64_t v : ms)
+      if (v < 0 || v > 0x7fffffffLL || v % 4) return false;
+    if (!aligned16b(mask) || !aligned16b(g_mask)) return false;
+  }
   if (d->W % 4 != 0 || d->W < 4 || d->L < 1) return false;
   // (LSI_PACKED_RGBD: the entry points have verified the caller's statement)
   const bool pack = (d->flags & LSI_PACKED_RGBD) != 0;
@@ -418,11 +446,15 @@ bool lsi_bwd_stream_applies(const LsiSplatDesc* d, const float* tex,
 }
 
 int lsi_bwd_stream_launch(const LsiSplatDesc* d, const float* tex,
-                          const float* disp, const float* M,
+                          const float* disp, const float* mask, const float* M,
                           const LsiBwdCanvas* ci, const LsiBwdCanvas* cc,
-                          float* g_tex, float* g_disp, hipStream_t stream) {
+                          float* g_tex, float* g_disp, float* g_mask,
+                          hipStream_t stream) {
   BSArgs a;
   a.tex = tex; a.disp = disp; a.M = M; a.g_tex = g_tex; a.g_disp = g_disp;
+  const bool has_mask = (d->flags & LSI_HAS_MASK) != 0;
+  a.mask = has_mask ? mask : nullptr; a.g_mask = has_mask ? g_mask : nullptr;
+  a.mask_sb = (int)d->mask_sb; a.mask_sl = (int)d->mask_sl; a.mask_sy = (int)d->mask_sy;
   const LsiBwdCanvas none = {nullptr, nullptr, nullptr, nullptr};
   const LsiBwdCanvas& i_ = ci ? *ci : none;
   const LsiBwdCanvas& c_ = cc ? *cc : none;
@@ -462,8 +494,9 @@ int lsi_bwd_stream_launch(const LsiSplatDesc* d, const float* tex,
   size_t lds = bytes_for(rs);
   if (lds > cap) { a.GR = 0; lds = 0; }
   const void* fn = (d->flags & LSI_PACKED_RGBD)
-                       ? (const void*)splat_bwd_stream_kernel<true>
-                       : (const void*)splat_bwd_stream_kernel<false>;
+                       ? (const void*)splat_bwd_stream_kernel<true, false>
+                       : (has_mask ? (const void*)splat_bwd_stream_kernel<false, true>
+                                   : (const void*)splat_bwd_stream_kernel<false, false>);
   if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)(lds > 0 ? lds : 16)) != hipSuccess)
     return LSI_ELAUNCH;

@@ -51,12 +51,14 @@ struct LsiBwdCanvas {
   const float* g_wts;  // may be NULL
 };
 bool lsi_bwd_stream_applies(const LsiSplatDesc* d, const float* tex,
-                            const float* disp, const float* g_tex,
-                            const float* g_disp);
+                            const float* disp, const float* mask,
+                            const float* g_tex, const float* g_disp,
+                            const float* g_mask);
 int lsi_bwd_stream_launch(const LsiSplatDesc* d, const float* tex,
-                          const float* disp, const float* M,
+                          const float* disp, const float* mask, const float* M,
                           const LsiBwdCanvas* ci, const LsiBwdCanvas* cc,
-                          float* g_tex, float* g_disp, hipStream_t stream);
+                          float* g_tex, float* g_disp, float* g_mask,
+                          hipStream_t stream);
 
 // LSI_PATH_TILE launcher and workspace need (lsi_splat_tile.hip).
 size_t lsi_tile_workspace_bytes(const LsiSplatDesc* d);

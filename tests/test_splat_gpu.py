@@ -1367,3 +1367,55 @@ def test_per_layer_outputs_alone_on_the_compact_instance(shape, dev):
   for other in (gen, (want['img'], want['wts'])):
     np.testing.assert_allclose(got[0], other[0], rtol=0, atol=IMG_ATOL)
     np.testing.assert_allclose(got[1], other[1], rtol=WTS_RTOL, atol=0)
+
+
+@pytest.mark.parametrize('both', [False, True])
+@pytest.mark.parametrize('w', [256, 384])
+def test_streamed_backward_with_a_mask(w, both, dev, monkeypatch):
+  """A caller that passes the reference's mask tensor (ldi.py:145-146: pixel
+  weight = soft z-buffer weight * mask) keeps the streamed backward: gradients
+  w.r.t. textures, masks and disparities against fp64 autograd of the op graph
+  and against the gather kernel."""
+  import lsi_torch_ref as TR
+  from lsi.geometry import ldi
+  nl, b, h = 3, 2, 20
+  tex, disp, _, mat = _rectified_case(77 + w, nl, b, h, w)
+  rs = np.random.RandomState(w)
+  mask = rs.uniform(0.2, 1.0, (nl, b, h, w, 1)).astype(np.float32)
+  s, bg, md, zb = 0.5, 1e-3, 0.4, 50.0
+  kw = dict(trg_downsampling=s, bg_layer_disp=bg, max_disp=md, zbuf_scale=zb)
+
+  def run(stream):
+    monkeypatch.setenv('LSI_BWD_STREAM', '1' if stream else '0')
+    t32 = [torch.tensor(x, device=dev, requires_grad=True) for x in (tex, mask, disp)]
+    g = torch.Generator().manual_seed(5)
+    if both:
+      outs = list(ldi.forward_splat_both(t32, torch.tensor(mat), **kw))
+    else:
+      outs = list(ldi.forward_splat_matrix(t32, torch.tensor(mat), compose_layers=True, **kw))
+    loss, coefs = 0, []
+    for o in outs:
+      c = torch.rand(o.shape, generator=g, dtype=torch.float64)
+      coefs.append(c)
+      loss = loss + ((o if o.shape[-1] == 3 else torch.log(o) * 1e-3) * c.float().to(dev)).sum()
+    loss.backward()
+    return [t.grad.cpu().double().numpy() for t in t32], coefs
+
+  got, coefs = run(True)
+  old, _ = run(False)
+  for a, o, name in zip(got, old, ('tex', 'mask', 'disp')):
+    scale = np.abs(o).max() + 1e-30
+    assert np.abs(a - o).max() <= 2e-5 * scale, (name, np.abs(a - o).max() / scale)
+  t64 = [torch.tensor(x, dtype=torch.float64, requires_grad=True) for x in (tex, mask, disp)]
+  m64 = torch.tensor(mat, dtype=torch.float64)
+  loss, k = 0, 0
+  for compose in ([False, True] if both else [True]):
+    img, wts, _ = TR.forward_splat(t64[0], t64[1], t64[2], m64, s, bg, md, zb, compose)
+    loss = loss + (img * coefs[k]).sum() + (torch.log(wts) * 1e-3 * coefs[k + 1]).sum()
+    k += 2
+  loss.backward()
+  for a, b_, name in zip(got, t64, ('tex', 'mask', 'disp')):
+    want = b_.grad.numpy()
+    scale = np.abs(want).max() + 1e-30
+    bad = np.abs(a - want) > 2e-4 * scale + 1e-3 * np.abs(want)
+    assert bad.mean() < 0.005, (name, bad.mean(), np.abs(a - want).max() / scale)
