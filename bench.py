@@ -15,11 +15,14 @@ Workloads (BASELINE.json `configs`):
   cfg5  KITTI 4-layer 512x1536, batch 8
 Multi-GPU: independent LDIs, NO data-path collective (replicas of an
 embarrassingly parallel renderer); RCCL is used only for the barrier and the
-max-over-ranks of the elapsed time.  Default `--scaling weak`: every rank
-renders the workload's whole batch -- the per-GPU minibatch of a data-parallel
-training run, per-GPU work fixed as N grows.  `--scaling strong` splits the
-batch B/N over the ranks instead (cfg2 is per GPU either way); `--shard-of N`
-times one such shard on a single GPU.  `python bench.py --gpus N` from a bare
+max-over-ranks of the elapsed time.  Default `--scaling strong`: the workload's
+batch is split B/N over the ranks (SURVEY.md 8e / BASELINE config 3: 32 views
+-> 4 per GPU at N = 8; cfg2 is per GPU either way) -- `value` is the rate of
+that split, the one north_star's ">= 6x from 1 to 8 GPUs" is about.  The same
+run then also times the weak-scaling case (every rank renders the whole batch:
+the per-GPU minibatch of a data-parallel training run) and reports it under
+`extra.weak`; `--scaling weak` makes that the headline instead.  `--shard-of N`
+times one rank's shard of an N-rank split on a single GPU.  `python bench.py --gpus N` from a bare
 shell re-launches itself under torch.distributed.run (one rank per GPU).
 
 Inputs smaller than the 256 MiB Infinity Cache would be served from it when one
@@ -174,12 +177,13 @@ class Renderer(object):
       _C.check(rc, 'lsi_splat_fwd')
 
 
-def shard_batch(workload, world, scaling='weak'):
+def shard_batch(workload, world, scaling='strong'):
   """Per-rank batch and scaling mode: independent LDIs shard along B with no
-  data-path collective.  'weak' (default): every rank renders
-  the workload's whole batch (data-parallel replicas, what a DDP training run
-  does with its per-GPU minibatch); 'strong': the workload's batch is split
-  B/N over the ranks."""
+  data-path collective.  'strong' (default): the workload's
+  batch is split B/N over the ranks (config 3: 32 -> 4 per GPU at N = 8);
+  'weak': every rank renders the workload's whole batch (data-parallel
+  replicas, what a DDP training run does with its per-GPU minibatch).  A
+  workload whose batch is per GPU (cfg2) is 'weak' either way."""
   nl, h, w, batch, per_gpu, cams, max_disp, bg = WORKLOADS[workload]
   if per_gpu or scaling == 'weak':
     return batch, 'weak'
@@ -543,10 +547,10 @@ def main():
                   help='LsiSplatDesc.reserved: planner experiments (bits 12+) work '
                   'with any build; the kernel timing hooks (bits 0-9) need '
                   'LSI_HIP_LIB=hooks (build.py --hooks)')
-  ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
-                  help='N > 1: weak = every rank renders the whole batch of the '
-                  'workload (per-GPU work fixed; default), strong = the batch is '
-                  'split B/N over the ranks')
+  ap.add_argument('--scaling', default='strong', choices=['weak', 'strong'],
+                  help='N > 1: strong = the workload\'s batch is split B/N over '
+                  'the ranks (default; the weak figure is added under extra.weak), '
+                  'weak = every rank renders the whole batch (per-GPU work fixed)')
   ap.add_argument('--shard-of', type=int, default=1,
                   help='N=1 only: time the per-rank shard of an N-rank run (what '
                   'one GPU of --gpus N renders); the JSON line is then about that '
@@ -622,6 +626,24 @@ def main():
   # per-rank average launch time: slowest and fastest rank (N > 1: which GPU
   # holds the job back)
   ev_min = -reduce_max([-ev_ms_rank], dist, dev)[0]
+  # N > 1, batch split over the ranks: the weak-scaling figure of the same run
+  # (every rank renders the workload's whole batch) goes under extra.weak
+  weak = None
+  if world > 1 and scaling == 'strong' and args.shard_of == 1:
+    del r
+    torch.cuda.empty_cache()
+    rw = build_renderer(args.workload, batch, 1000 + rank, dev, args)
+    rw.desc.reserved = args.debug_flags
+    w_elapsed, w_ev, _ = timed_region(rw, args.steps, args.warmup, args.launch,
+                                      dist, dev)
+    w_elapsed, w_ev = reduce_max([w_elapsed, w_ev], dist, dev)
+    weak = {'value': batch * world * args.steps / w_elapsed, 'unit': 'views/s',
+            'scaling': 'weak', 'views_per_gpu': batch,
+            'ms_per_step': w_elapsed * 1e3 / args.steps,
+            'avg_launch_us': w_ev * 1e3 / args.steps,
+            'note': 'every rank renders the workload\'s whole batch (per-GPU '
+                    'work fixed); `value` above is the B/N split'}
+    r = rw
 
   if rank == 0:
     views = b_local * world * args.steps
@@ -656,8 +678,9 @@ def main():
                        if r.path_name == 'tile' else
                        # compose mode, no mask, unit normaliser, channels-last,
                        # rows of whole 256-pixel segments: the compact instance
+                       # of any width that is a multiple of 4 pixels
                        'splat_stream2_kernel' if (r.path_name == 'stream' and
-                                                  w % 256 == 0 and
+                                                  w % 4 == 0 and
                                                   args.tex_layout == 'nhwc')
                        else 'splat_%s_kernel' % r.path_name),
             'algorithmic_bytes_per_launch': alg,
@@ -666,6 +689,8 @@ def main():
                 'max': ev_ms * 1e3 / args.steps, 'min': ev_min * 1e3 / args.steps},
         },
     }
+    if weak is not None:
+      out['extra'] = {'weak': weak}
     if world == 1 and not args.no_extra:
       extra = {}
       bwd_us = time_backward(r)

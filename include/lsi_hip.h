@@ -155,7 +155,9 @@ int lsi_stream_ok(const LsiSplatDesc* desc, const float* M_host);
  * stream-ordered STREAM-path lsi_splat_fwd calls WITH THE SAME L, B, Ht, Wt AND
  * flags since (the place of the counters depends on those; the other paths
  * write over them).  One workspace must not be used by
- * two calls that can run concurrently.
+ * two calls that can run concurrently.  desc->path AUTO or ATOMIC: the size
+ * that serves any path (the ATOMIC canvases dominate); STREAM or TILE: what
+ * that path needs (counters, boundary rows, disparity ranges: kilobytes).
  */
 size_t lsi_splat_workspace_bytes(const LsiSplatDesc* desc);
 
@@ -279,6 +281,17 @@ int lsi_scatter_add(int32_t B, int64_t P, int64_t N, const int32_t* idx,
 int lsi_bilinear_fwd(int32_t B, int32_t Hs, int32_t Ws, int32_t C, int32_t Ht,
                      int32_t Wt, const float* imgs, const float* coords,
                      float* out, lsi_stream_t stream);
+
+/*
+ * sampling.bilinear (compose=False), sampling.py:124-130: the four taps, each
+ * multiplied by its border-validity mask, and the four un-masked bilinear
+ * weights, in the reference's order (x0,y0), (x0,y1), (x1,y0), (x1,y1).
+ *   taps [4,B,Ht,Wt,C], wts [4,B,Ht,Wt,1].  Forward only (no caller of the
+ * reference differentiates this form).
+ */
+int lsi_bilinear_taps(int32_t B, int32_t Hs, int32_t Ws, int32_t C, int32_t Ht,
+                      int32_t Wt, const float* imgs, const float* coords,
+                      float* taps, float* wts, lsi_stream_t stream);
 
 /*
  * Gradients of lsi_bilinear_fwd.  g_imgs [B,Hs,Ws,C] must be zero on entry

@@ -139,6 +139,21 @@ __device__ __forceinline__ void project_px(const float* __restrict__ m,
   }
 }
 
+// Streaming stores for outputs that are written once and not read again by the
+// launch (rendered views, gradients): the non-temporal policy keeps them from
+// lingering dirty in the XCD's L2 -- measured on MI355X: the composed view of
+// config 3 (25 MB) written with plain stores costs the launch 4.8 us more
+// (86.7 vs 81.9 us; write-through `sc1` stores are slower than either).
+typedef float lsi_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_stream_f4(float* p, float x, float y, float z,
+                                                float w) {
+  const lsi_v4f v = {x, y, z, w};
+  __builtin_nontemporal_store(v, reinterpret_cast<lsi_v4f*>(p));
+}
+__device__ __forceinline__ void store_stream_f1(float* p, float x) {
+  __builtin_nontemporal_store(x, p);
+}
+
 // fp32 atomic add that lowers to global_atomic_add_f32 / ds_add_f32 (no CAS
 // loop); the translation unit is built with -munsafe-fp-atomics.
 __device__ __forceinline__ void atomic_add_f32(float* p, float v) {

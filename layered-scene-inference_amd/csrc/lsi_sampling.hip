@@ -168,6 +168,32 @@ __global__ __launch_bounds__(256) void bilinear_fwd_kernel(
   }
 }
 
+// sampling.py:124-130 (compose=False): the four border-masked taps and the four
+// un-masked weights, tap order (x0,y0), (x0,y1), (x1,y0), (x1,y1).
+__global__ __launch_bounds__(256) void bilinear_taps_kernel(
+    int Hs, int Ws, int C, int Nt, int B, const float* __restrict__ imgs,
+    const float* __restrict__ coords, float* __restrict__ taps,
+    float* __restrict__ wts) {
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= Nt) return;
+  const size_t ti = (size_t)b * Nt + i;
+  const size_t N = (size_t)B * Nt;  // elements of one tap / weight plane
+  Taps t;
+  taps_of(coords[2 * ti], coords[2 * ti + 1], Hs, Ws, t);
+  const float* ib = imgs + (size_t)b * Hs * Ws * C;
+  const float m[4] = {t.vx0 * t.vy0, t.vx0 * t.vy1, t.vx1 * t.vy0, t.vx1 * t.vy1};
+  const int idx[4] = {t.i00, t.i01, t.i10, t.i11};
+  wts[0 * N + ti] = t.wx0 * t.wy0;
+  wts[1 * N + ti] = t.wx0 * t.wy1;
+  wts[2 * N + ti] = t.wx1 * t.wy0;
+  wts[3 * N + ti] = t.wx1 * t.wy1;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    for (int ch = 0; ch < C; ++ch)
+      taps[(k * N + ti) * C + ch] = t.ok ? m[k] * ib[(size_t)idx[k] * C + ch] : 0.0f;
+}
+
 __global__ __launch_bounds__(256) void bilinear_bwd_kernel(
     int Hs, int Ws, int C, int Nt, const float* __restrict__ imgs,
     const float* __restrict__ coords, const float* __restrict__ g_out,
@@ -287,6 +313,20 @@ int lsi_bilinear_fwd(int32_t B, int32_t Hs, int32_t Ws, int32_t C, int32_t Ht,
   const int Nt = Ht * Wt;
   hipLaunchKernelGGL(bilinear_fwd_kernel, dim3((Nt + 255) / 256, B), dim3(256),
                      0, (hipStream_t)stream, Hs, Ws, C, Nt, imgs, coords, out);
+  return launch_rc();
+}
+
+int lsi_bilinear_taps(int32_t B, int32_t Hs, int32_t Ws, int32_t C, int32_t Ht,
+                      int32_t Wt, const float* imgs, const float* coords,
+                      float* taps, float* wts, lsi_stream_t stream) {
+  if (B <= 0 || Hs <= 0 || Ws <= 0 || C <= 0 || Ht <= 0 || Wt <= 0 ||
+      B > 65535 || (int64_t)Hs * Ws >= (1 << 24))
+    return LSI_EINVAL;
+  if (!imgs || !coords || !taps || !wts) return LSI_ENULL;
+  const int Nt = Ht * Wt;
+  hipLaunchKernelGGL(bilinear_taps_kernel, dim3((Nt + 255) / 256, B), dim3(256),
+                     0, (hipStream_t)stream, Hs, Ws, C, Nt, B, imgs, coords, taps,
+                     wts);
   return launch_rc();
 }
 

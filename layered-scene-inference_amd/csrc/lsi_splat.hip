@@ -717,6 +717,11 @@ size_t lsi_splat_workspace_bytes(const LsiSplatDesc* d) {
   // TILE-path disparity ranges (larger than the canvases only for targets of
   // a few cells)
   const size_t tile_need = lsi_tile_workspace_bytes(d);
+  // A descriptor that names its path asks for that path's need only (STREAM may
+  // hand a request over to TILE); AUTO / ATOMIC: one allocation serves any path.
+  if (d->path == LSI_PATH_STREAM)
+    return stream_need > tile_need ? stream_need : tile_need;
+  if (d->path == LSI_PATH_TILE) return tile_need;
   size_t need = atomic_need > stream_need ? atomic_need : stream_need;
   if (tile_need > need) need = tile_need;
   return need;

@@ -26,6 +26,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <type_traits>
 
@@ -73,6 +74,7 @@ struct BSArgs {
   int vec4;  // canvas rows can be read 4 cells at a time (16-byte loads)
   float* g_tex;
   float* g_disp;
+  int nt;             // streaming (non-temporal) stores of the gradients
   int B, H, W, Ht, Wt, L, nseg;
   int tex_sb, tex_sl, tex_sy, disp_sb, disp_sl, disp_sy;
   float s, max_disp, zscale, zA, zB;
@@ -288,12 +290,20 @@ __device__ __forceinline__ void bs_run(const BSArgs& a, const float (&m)[8],
     const size_t po = (size_t)l * lay_px + (size_t)y * a.W + (size_t)sg * BS_SEG;
     if (sg * BS_SEG + 4 * lane < a.W) {
       float* pt = o_tex + 3 * po;
-      *reinterpret_cast<float4*>(pt) = make_float4(ot[0], ot[1], ot[2], ot[3]);
-      *reinterpret_cast<float4*>(pt + 4) = make_float4(ot[4], ot[5], ot[6], ot[7]);
-      *reinterpret_cast<float4*>(pt + 8) = make_float4(ot[8], ot[9], ot[10], ot[11]);
-      *reinterpret_cast<float4*>(o_disp + po) = make_float4(od[0], od[1], od[2], od[3]);
-      if (MASK)
-        *reinterpret_cast<float4*>(o_mask + po) = make_float4(om[0], om[1], om[2], om[3]);
+      if (a.nt) {  // gradients are written once: streaming stores
+        store_stream_f4(pt, ot[0], ot[1], ot[2], ot[3]);
+        store_stream_f4(pt + 4, ot[4], ot[5], ot[6], ot[7]);
+        store_stream_f4(pt + 8, ot[8], ot[9], ot[10], ot[11]);
+        store_stream_f4(o_disp + po, od[0], od[1], od[2], od[3]);
+        if (MASK) store_stream_f4(o_mask + po, om[0], om[1], om[2], om[3]);
+      } else {
+        *reinterpret_cast<float4*>(pt) = make_float4(ot[0], ot[1], ot[2], ot[3]);
+        *reinterpret_cast<float4*>(pt + 4) = make_float4(ot[4], ot[5], ot[6], ot[7]);
+        *reinterpret_cast<float4*>(pt + 8) = make_float4(ot[8], ot[9], ot[10], ot[11]);
+        *reinterpret_cast<float4*>(o_disp + po) = make_float4(od[0], od[1], od[2], od[3]);
+        if (MASK)
+          *reinterpret_cast<float4*>(o_mask + po) = make_float4(om[0], om[1], om[2], om[3]);
+      }
     }
   };
 
@@ -452,6 +462,10 @@ int lsi_bwd_stream_launch(const LsiSplatDesc* d, const float* tex,
                           hipStream_t stream) {
   BSArgs a;
   a.tex = tex; a.disp = disp; a.M = M; a.g_tex = g_tex; a.g_disp = g_disp;
+  {
+    static const char* nt_env = getenv("LSI_BWD_NT");  // experiments: 0 = plain stores
+    a.nt = nt_env ? atoi(nt_env) : 1;
+  }
   const bool has_mask = (d->flags & LSI_HAS_MASK) != 0;
   a.mask = has_mask ? mask : nullptr; a.g_mask = has_mask ? g_mask : nullptr;
   a.mask_sb = (int)d->mask_sb; a.mask_sl = (int)d->mask_sl; a.mask_sy = (int)d->mask_sy;
@@ -498,8 +512,14 @@ int lsi_bwd_stream_launch(const LsiSplatDesc* d, const float* tex,
                        : (has_mask ? (const void*)splat_bwd_stream_kernel<false, true>
                                    : (const void*)splat_bwd_stream_kernel<false, false>);
   if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
-                          (int)(lds > 0 ? lds : 16)) != hipSuccess)
-    return LSI_ELAUNCH;
+                          (int)(lds > 0 ? lds : 16)) != hipSuccess) {
+    // a device that does not grant the LDS asked for: corners from the arrays
+    (void)hipGetLastError();
+    a.GR = 0; lds = 0;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 16) !=
+        hipSuccess)
+      return LSI_ELAUNCH;
+  }
   const dim3 grid((d->H + rs - 1) / rs, d->B, a.compose ? 1 : d->L);
   void* kargs[1] = {&a};
   if (hipLaunchKernel(fn, grid, dim3(BS_T), kargs, lds, stream) != hipSuccess)

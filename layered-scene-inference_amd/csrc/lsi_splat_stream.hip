@@ -1848,8 +1848,11 @@ int lsi_stream_launch(const SplatArgs& a, hipStream_t stream) {
     SplatArgs a1 = a;
     a1.d.flags &= ~LSI_WANT_DISP;
     a1.out_disp = nullptr;
+    // (lsi_stream_ok admits only what the compact instance takes; with the
+    // instance switched off -- LSI_STREAM2=0, test bits -- the any-pose path
+    // renders the request)
     if (!lsi_stream2_applies(a1, (d->tune_window & LSI_STREAM_SIMPLE_BIT) != 0, layout))
-      return LSI_EINVAL;  // (lsi_stream_ok admits nothing else)
+      return lsi_tile_launch(a, stream);
     const int wmax = d->tune_window & ~LSI_STREAM_SIMPLE_BIT;
     const int rc = lsi_stream2_launch(a1, wmax, stream);
     if (rc != LSI_OK) return rc;

@@ -71,6 +71,8 @@ struct S2Args {
   float s, max_disp, zA, zB, lbg;  // exp2(fma(clip(d), zA, zB)); L * bg weight
   float bg;                        // bg weight of one layer's canvas
   int R, wmax, qcap, cap, ilv;     // band rows, window cells, queue, table, row interleave
+  int hf;                          // halo rows first (see BandOrder)
+  int ep;                          // epilogue stores: 0 scalar, 1 16-byte, 2 16-byte write-through, 3 16-byte nt
   int nsplit, lsub;                // units handed out lsub layers per ticket
   float inv_gx, inv_nseg;
   long long* stamps;  // S2X_STAMPS build: [workgroup][wave][8] wall-clock ticks
@@ -91,17 +93,30 @@ __device__ __forceinline__ int s2_div_small(int n, int d, float rcp) {
 // interleave: consecutive tickets go to source rows a fifth of the band apart,
 // so that the units in flight merge into different tile rows; short bands keep
 // the natural order).
+// Halo rows first (hf): the band's first two and last two source rows are the
+// ones its neighbours read as well (a band of R target rows reads 2R + 2 source
+// rows at s = 0.5).  They are the first units of every band -- taken by wave
+// index at launch, the one moment all workgroups are in step -- so that the two
+// bands that share a row ask the XCD's L2 for it within the same microsecond
+// and one of them is served from the other's fill instead of from HBM.
 struct BandOrder {
-  int nsrc, nrow_pad, q5, nunit, nsplit, nfull, lsub, ntask, rot;
+  int nsrc, nrow_pad, q5, nunit, nsplit, nfull, lsub, ntask, rot, hf, nin;
   float inv_nsplit;
 };
+__host__ __device__ __forceinline__ int s2_rows_padded(int nsrc, int ilv, int hf) {
+  const int edge = (hf && nsrc >= 6) ? 4 : 0;
+  const int nin = nsrc - edge;
+  return edge + (ilv ? (nin + 4) / 5 * 5 : nin);
+}
 // `wg`: a number that differs between workgroups (S2X_STAGGER builds: every
 // workgroup walks its units from another starting point)
 __device__ __forceinline__ BandOrder s2_band_order(const S2Args& a, int nsrc, int wg = 0) {
   BandOrder o;
   o.nsrc = nsrc;
-  o.nrow_pad = a.ilv ? (nsrc + 4) / 5 * 5 : nsrc;
-  o.q5 = o.nrow_pad / 5;
+  o.hf = (a.hf && nsrc >= 6) ? 1 : 0;
+  o.nin = nsrc - 4 * o.hf;
+  o.nrow_pad = s2_rows_padded(nsrc, a.ilv, a.hf);
+  o.q5 = (o.nrow_pad - 4 * o.hf) / 5;
   o.nunit = o.nrow_pad * a.nseg;
   o.nsplit = min(a.nsplit, o.nunit);
   o.nfull = o.nunit - o.nsplit;
@@ -133,11 +148,26 @@ __device__ __forceinline__ Unit s2_unit_of(const S2Args& a, const BandOrder& o, 
 // unit -> row of the band (may be a padding row >= nsrc) and segment
 __device__ __forceinline__ int s2_unit_row(const S2Args& a, const BandOrder& o, int u,
                                            int& sg) {
-  const int yi = (int)(((float)u + 0.5f) * a.inv_nseg);
+  int yi = (int)(((float)u + 0.5f) * a.inv_nseg);
   sg = u - yi * a.nseg;
-  if (!a.ilv) return yi;
-  const int y5 = (int)(((float)yi + 0.5f) * 0.2f);
-  return (yi - 5 * y5) * o.q5 + y5;
+  int base = 0;
+  if (o.hf) {
+    // the first 4 * nseg units: rows 0, nsrc - 1, 1, nsrc - 2 of segment 0, then
+    // of segment 1, ... (consecutive tickets merge into alternating tile rows)
+    if (yi < 4) {
+      if (a.hf == 2) return yi < 2 ? yi : o.nsrc - 4 + yi;  // (experiment: row-major)
+      sg = u >> 2;
+      const int hr = u & 3;
+      return (hr & 1) ? o.nsrc - 1 - (hr >> 1) : (hr >> 1);
+    }
+    yi -= 4; base = 2;
+  }
+  int r = yi;
+  if (a.ilv) {
+    const int y5 = (int)(((float)yi + 0.5f) * 0.2f);
+    r = (yi - 5 * y5) * o.q5 + y5;
+  }
+  return r < o.nin ? base + r : o.nsrc;  // (>= nsrc: a padding row)
 }
 // The unit a wave takes without a ticket (ticket == its wave index), as
 // (row of the band, segment, first layer, layers); nl == 0: none.
@@ -334,7 +364,26 @@ __device__ __noinline__ void s2_flush_queue(unsigned tile_off, unsigned locks_of
   if (rowA >= 0) unlock(rowA);
 }
 
+// 16-byte output store by epilogue mode (S2Args.ep): 1 plain, 2 write-through
+// (sc1), 3 non-temporal (what the launcher picks: see lsi_common.h)
+__device__ __forceinline__ void s2_store4(float* p, float x, float y, float z, float w,
+                                          int ep) {
+  typedef float v4 __attribute__((ext_vector_type(4)));
+  const v4 v = {x, y, z, w};
+  if (ep == 3) {
+    __builtin_nontemporal_store(v, reinterpret_cast<v4*>(p));
+  } else if (ep == 2) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+  } else {
+    *reinterpret_cast<v4*>(p) = v;
+  }
+}
 struct Px { float4 d4, t0, t1, t2; };
+typedef float s2_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 s2_ld_nt(const float* p) {
+  const s2_f4 v = __builtin_nontemporal_load(reinterpret_cast<const s2_f4*>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
 
 // BOTH: lsi_splat_fwd_both -- the per-layer views AND the composed one from one
 // sweep: one tile per layer in LDS, every item (one layer of a unit) merges its
@@ -425,17 +474,22 @@ __global__ __launch_bounds__(MAXT) void splat_stream2_kernel(S2Args a) {
     p_disp = g_disp0 + (long)l0 * disp_sl + (long)y * a.disp_sy + px;
     p_tex = g_tex0 + (long)l0 * tex_sl + (long)y * a.tex_sy + (PACK ? 4 : 3) * px;
   };
+#ifdef S2X_NT  // experiment: streamed inputs loaded with the non-temporal policy
+#define S2_LD(p) s2_ld_nt(p)
+#else
+#define S2_LD(p) (*reinterpret_cast<const float4*>(p))
+#endif
   auto load_layer = [&](Px& o) {
     if (PACK) {  // d4, t0, t1, t2 = the lane's pixels 0 .. 3 as (r, g, b, d)
-      o.d4 = *reinterpret_cast<const float4*>(p_tex);
-      o.t0 = *reinterpret_cast<const float4*>(p_tex + 4);
-      o.t1 = *reinterpret_cast<const float4*>(p_tex + 8);
-      o.t2 = *reinterpret_cast<const float4*>(p_tex + 12);
+      o.d4 = S2_LD(p_tex);
+      o.t0 = S2_LD(p_tex + 4);
+      o.t1 = S2_LD(p_tex + 8);
+      o.t2 = S2_LD(p_tex + 12);
     } else {
-      o.d4 = *reinterpret_cast<const float4*>(p_disp);
-      o.t0 = *reinterpret_cast<const float4*>(p_tex);
-      o.t1 = *reinterpret_cast<const float4*>(p_tex + 4);
-      o.t2 = *reinterpret_cast<const float4*>(p_tex + 8);
+      o.d4 = S2_LD(p_disp);
+      o.t0 = S2_LD(p_tex);
+      o.t1 = S2_LD(p_tex + 4);
+      o.t2 = S2_LD(p_tex + 8);
       p_disp += disp_sl;
     }
     p_tex += tex_sl;
@@ -1173,6 +1227,9 @@ __global__ __launch_bounds__(MAXT) void splat_stream2_kernel(S2Args a) {
   S2_STAMP(5);
 
   // ---- epilogue: (tile + background) normalised, each output written once --
+  // (a.ep: 0 scalar stores; 1 / 2 / 3 four cells per lane, plain / write-through
+  // / non-temporal; 4 / 5 whole lines per store instruction, plain / non-temporal)
+  const int ep_st = (a.ep == 3 || a.ep == 5) ? 3 : (a.ep == 2 ? 2 : 1);
   if (BOTH && a.out_disp) {
     // the disparity pass: every layer's splatted disparity normalised by its own
     // canvas weight, then the maximum over the layers (ldi.py:157-158, 170)
@@ -1180,14 +1237,74 @@ __global__ __launch_bounds__(MAXT) void splat_stream2_kernel(S2Args a) {
     const size_t P = (size_t)Ht * Wt;
     const size_t o0 = (size_t)b * P + (size_t)row0 * Wt;
     const int ncell = rows * Wt;
-    for (int i = tid; i < ncell; i += T) {
+    auto dmax_of = [&](int i) {
       float dmax = 0.0f;
       for (int l = 0; l < a.L; ++l) {
         const float4 A = tile4[(size_t)l * R * Wt + i];
         const float dl = div_rn(A.x, safe_den(A.w + bg));
         dmax = l == 0 ? dl : fmaxf(dmax, dl);
       }
-      a.out_disp[o0 + i] = dmax;
+      return dmax;
+    };
+    if (a.ep) {
+      for (int i = tid; i < (ncell >> 2); i += T)
+        s2_store4(a.out_disp + o0 + 4 * (size_t)i, dmax_of(4 * i), dmax_of(4 * i + 1),
+                  dmax_of(4 * i + 2), dmax_of(4 * i + 3), ep_st);
+    } else {
+      for (int i = tid; i < ncell; i += T) a.out_disp[o0 + i] = dmax_of(i);
+    }
+  } else if (BOTH && a.ep) {
+    // per layer (ldi.py:157-163, 176-177) and composed (:167-174), four cells
+    // per thread: 16-byte streaming stores
+    const float bg = a.bg;
+    const size_t P = (size_t)Ht * Wt;
+    const size_t o0 = (size_t)b * P + (size_t)row0 * Wt;
+    const int nquad = (rows * Wt) >> 2;
+    // (plain stores: a lane's 16 bytes are a third of the 48 it owns -- partial
+    // lines per store instruction, which non-temporal stores do not merge:
+    // measured 215 vs 174 us at config 3)
+    const int ep = a.ep == 2 ? 2 : 1;
+    for (int i = tid; i < nquad; i += T) {
+      float C[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) C[k] = 0.0f;
+      for (int l = 0; l < a.L; ++l) {
+        float c[12], w[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float4 A = tile4[(size_t)l * R * Wt + 4 * i + k];
+          const float Wsum = A.w + bg;
+          const float rw = __builtin_amdgcn_rcpf(safe_den(Wsum));
+          c[3 * k + 0] = (A.x + bg) * rw;
+          c[3 * k + 1] = (A.y + bg) * rw;
+          c[3 * k + 2] = (A.z + bg) * rw;
+          w[k] = Wsum;
+          C[4 * k + 0] += A.x + bg; C[4 * k + 1] += A.y + bg;
+          C[4 * k + 2] += A.z + bg; C[4 * k + 3] += Wsum;
+        }
+        const size_t o = (size_t)l * a.B * P + o0 + 4 * (size_t)i;
+        float* const pi = a.out_img + 3 * o;
+        s2_store4(pi, c[0], c[1], c[2], c[3], ep);
+        s2_store4(pi + 4, c[4], c[5], c[6], c[7], ep);
+        s2_store4(pi + 8, c[8], c[9], c[10], c[11], ep);
+        s2_store4(a.out_wts + o, w[0], w[1], w[2], w[3], ep);
+      }
+      if (a.out_img_c) {
+        float c[12], w[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float rw = __builtin_amdgcn_rcpf(safe_den(C[4 * k + 3]));
+          c[3 * k + 0] = C[4 * k + 0] * rw;
+          c[3 * k + 1] = C[4 * k + 1] * rw;
+          c[3 * k + 2] = C[4 * k + 2] * rw;
+          w[k] = C[4 * k + 3];
+        }
+        float* const pi = a.out_img_c + 3 * (o0 + 4 * (size_t)i);
+        s2_store4(pi, c[0], c[1], c[2], c[3], ep);
+        s2_store4(pi + 4, c[4], c[5], c[6], c[7], ep);
+        s2_store4(pi + 8, c[8], c[9], c[10], c[11], ep);
+        s2_store4(a.out_wts_c + o0 + 4 * (size_t)i, w[0], w[1], w[2], w[3], ep);
+      }
     }
   } else if (BOTH) {
     // per layer (ldi.py:157-163, 176-177) and composed (:167-174): the sum of
@@ -1217,6 +1334,68 @@ __global__ __launch_bounds__(MAXT) void splat_stream2_kernel(S2Args a) {
         a.out_wts_c[o0 + i] = C.w;
       }
     }
+  } else if (a.ep >= 4) {
+    // Fully coalesced 16-byte stores: store instruction n of a wave writes ONE
+    // contiguous kilobyte (whole 128-byte lines), lane l the floats 4 (64 n + l)
+    // ... + 3 of the band's colour plane -- they belong to the cells f / 3 and
+    // f / 3 + 1, read straight from the tile.  (With four cells per lane -- the
+    // branch below -- a store instruction writes 16 bytes every 48: partial
+    // lines, which non-temporal stores do not merge.)
+    const float lbg = a.lbg;
+    const size_t P = (size_t)Ht * Wt;
+    float* const oi = a.out_img + ((size_t)b * P + (size_t)row0 * Wt) * 3;
+    float* const ow = a.out_wts + (size_t)b * P + (size_t)row0 * Wt;
+    const int ncell = rows * Wt;
+    const int nq = (3 * ncell) >> 2;
+    for (int q = tid; q < nq; q += T) {
+      const unsigned f = 4u * (unsigned)q;
+      const unsigned c0 = __umulhi(f, 0xAAAAAAABu) >> 1;  // f / 3
+      const unsigned o = f - 3u * c0;
+      const float4 A = tile4[c0];
+      const float4 Bc = tile4[min((int)c0 + 1, ncell - 1)];
+      const float ra = __builtin_amdgcn_rcpf(safe_den(A.w + lbg));
+      const float rb_ = __builtin_amdgcn_rcpf(safe_den(Bc.w + lbg));
+      const float ax = (A.x + lbg) * ra, ay = (A.y + lbg) * ra, az = (A.z + lbg) * ra;
+      const float bx = (Bc.x + lbg) * rb_, by = (Bc.y + lbg) * rb_, bz = (Bc.z + lbg) * rb_;
+      // o = 0: a.xyz b.x | o = 1: a.yz b.xy | o = 2: a.z b.xyz
+      const float v0 = o == 0 ? ax : (o == 1 ? ay : az);
+      const float v1 = o == 0 ? ay : (o == 1 ? az : bx);
+      const float v2 = o == 0 ? az : (o == 1 ? bx : by);
+      const float v3 = o == 0 ? bx : (o == 1 ? by : bz);
+      s2_store4(oi + f, v0, v1, v2, v3, ep_st);
+    }
+    const float* const tw = reinterpret_cast<const float*>(tile4) + 3;
+    for (int q = tid; q < (ncell >> 2); q += T) {
+      const float* t = tw + 16 * q;
+      s2_store4(ow + 4 * q, t[0] + lbg, t[4] + lbg, t[8] + lbg, t[12] + lbg, ep_st);
+    }
+  } else if (a.ep) {
+    // four cells per thread: three 16-byte stores of colours and one of weights
+    // (Wt % 4 == 0 and 16-byte aligned outputs: checked by the launcher)
+    const float lbg = a.lbg;
+    const size_t P = (size_t)Ht * Wt;
+    float* const oi = a.out_img + ((size_t)b * P + (size_t)row0 * Wt) * 3;
+    float* const ow = a.out_wts + (size_t)b * P + (size_t)row0 * Wt;
+    const int nquad = (rows * Wt) >> 2;
+    const int ep = a.ep;
+    for (int i = tid; i < nquad; i += T) {
+      float c[12], w[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float4 A = tile4[4 * i + k];
+        const float Wsum = A.w + lbg;
+        const float rw = __builtin_amdgcn_rcpf(safe_den(Wsum));
+        c[3 * k + 0] = (A.x + lbg) * rw;
+        c[3 * k + 1] = (A.y + lbg) * rw;
+        c[3 * k + 2] = (A.z + lbg) * rw;
+        w[k] = Wsum;
+      }
+      float* const pi = oi + 12 * (size_t)i;
+      s2_store4(pi, c[0], c[1], c[2], c[3], ep);
+      s2_store4(pi + 4, c[4], c[5], c[6], c[7], ep);
+      s2_store4(pi + 8, c[8], c[9], c[10], c[11], ep);
+      s2_store4(ow + 4 * (size_t)i, w[0], w[1], w[2], w[3], ep);
+    }
   } else {
     const float lbg = a.lbg;
     const size_t P = (size_t)Ht * Wt;
@@ -1245,7 +1424,7 @@ size_t s2_lds_bytes(int R, int Wt, int nw, int wmax, int cap, int qcap, int cell
          (size_t)((nw * wmax + 15) & ~15) + (cell ? (size_t)nt * R * Wt * 4 : 0) + 16;
 }
 
-struct S2Plan { int R, nw, cell, cap, qcap, ilv, nsplit, lsub; size_t lds; double est; };
+struct S2Plan { int R, nw, cell, cap, qcap, ilv, hf, nsplit, lsub; size_t lds; double est; };
 
 // Band height, waves per workgroup, how many row-segment units are handed out
 // layer by layer.  Grounded in measurements (profiles/r03/): a launch streams
@@ -1263,6 +1442,8 @@ int s2_plan(const LsiSplatDesc* d, int wmax, int maxnw, bool both, S2Plan* out) 
   static const char* ns_env = getenv("LSI_S2_NSPLIT");  // experiments
   static const char* ls_env = getenv("LSI_S2_LSUB");
   const int force_cell = (d->reserved >> 18) & 3;
+  static const char* hf_env = getenv("LSI_S2_HALOFIRST");
+  const int hf = hf_env ? atoi(hf_env) : 1;
   const double NCU = 256.0, CHIP_GBPS = 5700.0, CU_GBPS = 32.0;
   S2Plan best; best.est = -1.0; best.nw = 0;
   for (int R = 1; R <= 64; R *= 2) {
@@ -1271,7 +1452,7 @@ int s2_plan(const LsiSplatDesc* d, int wmax, int maxnw, bool both, S2Plan* out) 
     const long nwg = (long)((d->Ht + R - 1) / R) * d->B;
     const int srows = (int)ceilf((float)(R + 1) / d->trg_downsampling);
     const int ilv = srows >= 15 ? 1 : 0;
-    const int nrow = ilv ? (srows + 4) / 5 * 5 : srows;
+    const int nrow = s2_rows_padded(srows, ilv, hf);
     const int nunit = nrow * nseg;
     // (both outputs: every item merges, and a merge under cell locks costs more
     // LDS operations than one under two row locks: 204 vs 184 us at config 3)
@@ -1321,7 +1502,7 @@ int s2_plan(const LsiSplatDesc* d, int wmax, int maxnw, bool both, S2Plan* out) 
       if (best.nw == 0 || est < best.est - 1e-9 ||
           (est <= best.est * 1.0001 && R > best.R)) {
         best.est = est; best.R = R; best.nw = c; best.cell = cell;
-        best.cap = cap; best.qcap = q; best.lds = lds; best.ilv = ilv;
+        best.cap = cap; best.qcap = q; best.lds = lds; best.ilv = ilv; best.hf = hf;
         best.nsplit = nsplit; best.lsub = lsub;
       }
     }
@@ -1394,6 +1575,16 @@ int lsi_stream2_launch(const SplatArgs& a, int wmax, hipStream_t stream,
   k.bg = d->bg_wt;
   k.R = plan.R; k.wmax = wmax; k.qcap = plan.qcap; k.cap = plan.cap;
   k.ilv = plan.ilv;
+  k.hf = plan.hf;
+  {
+    static const char* ep_env = getenv("LSI_S2_EPILOGUE");
+    const int ep = ep_env ? atoi(ep_env) : 3;
+    // (four cells per thread, 16-byte stores: rows of whole quads, aligned outputs)
+    bool al = d->Wt % 4 == 0;
+    for (const float* p : {k.out_img, k.out_wts, k.out_img_c, k.out_wts_c, k.out_disp})
+      al = al && ((uintptr_t)p & 15) == 0;
+    k.ep = al ? ep : 0;
+  }
   k.nsplit = plan.nsplit;
   k.lsub = plan.lsub;
   const int nbands = (d->Ht + plan.R - 1) / plan.R;

@@ -27,7 +27,7 @@ if _HERE not in sys.path:
 
 import ldi_enc_dec as train_script  # noqa: E402
 from lsi.geometry import projection  # noqa: E402
-from lsi.nnutils import eval_metrics, helpers as nn_helpers, nets  # noqa: E402
+from lsi.nnutils import eval_metrics, helpers as nn_helpers, nets, train_utils  # noqa: E402
 
 
 def build_parser():
@@ -77,8 +77,8 @@ class Tester(object):
       self.restored = None
     else:
       state = torch.load(path, map_location=self.device)
-      tr.model.load_state_dict(state['model'] if 'model' in state else state,
-                               strict=True)
+      train_utils.Trainer.strict_restore(
+          tr.model, state['model'] if 'model' in state else state)
       self.restored = path
     nets.set_is_training(tr.model, bool(self.opts.batch_norm_training))
 

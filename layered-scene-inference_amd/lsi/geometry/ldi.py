@@ -107,17 +107,22 @@ _WS_LOCK = threading.Lock()
 def _stream_workspace(desc, dev):
   """Zero-filled once, then kept by the library (lsi_hip.h, LSI_WS_KEEP): one
   buffer per (device, stream, call geometry); calls on a stream are ordered.
-  Entries are never evicted: a captured HIP graph has the buffer's address
-  baked in and relies on the counters the library left zero (a process sees a
-  handful of geometries; the buffers hold a few counters and boundary rows)."""
+  Sized for the path the call takes (STREAM: counters, boundary rows and the
+  disparity pass; the any-pose paths: their canvases / ranges).  A buffer that
+  has been handed out is never freed or replaced: a captured HIP graph has its
+  address baked in and relies on the counters the library left zero -- a call
+  of the same geometry that needs more gets its own, larger buffer."""
   need = int(_C.lib().lsi_splat_workspace_bytes(ctypes.byref(desc)))
-  key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, desc.L, desc.B,
-         desc.Ht, desc.Wt, desc.flags & ~_C.LSI_WS_KEEP)
+  key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, desc.path,
+         desc.L, desc.B, desc.H, desc.W, desc.Ht, desc.Wt, desc.tune_rows,
+         desc.flags & ~_C.LSI_WS_KEEP)
   with _WS_LOCK:
-    ws = _WS_CACHE.get(key)
-    if ws is None:
-      ws = torch.zeros((need,), dtype=torch.uint8, device=dev)
-      _WS_CACHE[key] = ws
+    kept = _WS_CACHE.setdefault(key, [])
+    for ws in kept:
+      if ws.numel() >= need:
+        return ws, ws.numel()
+    ws = torch.zeros((need,), dtype=torch.uint8, device=dev)
+    kept.append(ws)
   return ws, ws.numel()
 
 

@@ -64,28 +64,24 @@ def bilinear(imgs, coords, compose=True):
 
 def _bilinear_taps(imgs, coords):
   """compose=False (reference sampling.py:124-130): the four border-masked taps
-  and the four un-masked weights, tap order (x0,y0), (x0,y1), (x1,y0), (x1,y1).
-  No caller in the reference uses this form; it is a plain torch gather."""
+  and the four un-masked weights, tap order (x0,y0), (x0,y1), (x1,y0), (x1,y1)
+  -- lsi_bilinear_taps.  Forward only: no caller of the reference uses this
+  form, let alone differentiates it; inputs that require a gradient are an
+  error rather than a silently cut graph."""
+  if torch.is_grad_enabled() and (imgs.requires_grad or coords.requires_grad):
+    raise RuntimeError('bilinear(compose=False) is not differentiable here '
+                       '(lsi_bilinear_taps has no backward); detach the inputs')
+  dev = _C.require_device(imgs, coords)
+  imgs, coords = imgs.contiguous(), coords.contiguous()
   b, hs, ws, c = imgs.shape
-  x = coords[..., 0:1] - 0.5
-  y = coords[..., 1:2] - 0.5
-  x0 = torch.floor(x); x1 = x0 + 1; y0 = torch.floor(y); y1 = y0 + 1
-  x0s, x1s = x0.clamp(0, ws - 1), x1.clamp(0, ws - 1)
-  y0s, y1s = y0.clamp(0, hs - 1), y1.clamp(0, hs - 1)
-  dt = imgs.dtype
-  vx0, vx1 = (x0 == x0s).to(dt), (x1 == x1s).to(dt)
-  vy0, vy1 = (y0 == y0s).to(dt), (y1 == y1s).to(dt)
-  flat = imgs.reshape(b, hs * ws, c)
-
-  def tap(xs_, ys_):
-    idx = (xs_ + ys_ * ws).long().reshape(b, -1, 1).expand(-1, -1, c)
-    return torch.gather(flat, 1, idx).reshape(coords.shape[:-1] + (c,))
-
-  ims = [vx0 * vy0 * tap(x0s, y0s), vx0 * vy1 * tap(x0s, y1s),
-         vx1 * vy0 * tap(x1s, y0s), vx1 * vy1 * tap(x1s, y1s)]
-  wts = [(x1 - x) * (y1 - y), (x1 - x) * (y - y0), (x - x0) * (y1 - y),
-         (x - x0) * (y - y0)]
-  return ims, wts
+  _, ht, wt, _ = coords.shape
+  taps = torch.empty((4, b, ht, wt, c), dtype=torch.float32, device=dev)
+  wts = torch.empty((4, b, ht, wt, 1), dtype=torch.float32, device=dev)
+  rc = _C.lib().lsi_bilinear_taps(*_dims(b, hs, ws, c, ht, wt), _C.ptr(imgs),
+                                  _C.ptr(coords), _C.ptr(taps), _C.ptr(wts),
+                                  _C.stream_ptr(dev))
+  _C.check(rc, 'lsi_bilinear_taps')
+  return list(taps.unbind(0)), list(wts.unbind(0))
 
 
 def bilinear_wrapper(imgs, coords, compose=True):

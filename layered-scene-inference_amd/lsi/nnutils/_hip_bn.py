@@ -14,13 +14,17 @@ _WS_FLOATS = 1 << 20      # 4 MiB: covers every layer of the 256 x 768 networks
 
 def _workspace(dev, need):
   """Zero-filled once per (device, stream), then kept: the kernels leave their
-  arrival counter zero, and calls on one stream are ordered."""
+  arrival counter zero, and calls on one stream are ordered.  A buffer that has
+  been handed out is never freed (a captured HIP graph has its address baked
+  in): a larger need gets a further buffer, the old one stays alive."""
   key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
   with _WS_LOCK:
-    ws = _WS.get(key)
-    if ws is None or ws.numel() < need:
-      ws = torch.zeros((max(need, _WS_FLOATS),), dtype=torch.float32, device=dev)
-      _WS[key] = ws
+    kept = _WS.setdefault(key, [])
+    for ws in kept:
+      if ws.numel() >= need:
+        return ws
+    ws = torch.zeros((max(need, _WS_FLOATS),), dtype=torch.float32, device=dev)
+    kept.append(ws)
   return ws
 
 
@@ -38,7 +42,8 @@ def supported(x, groups=1):
   lpp = c // nv
   if lpp > 256 or lpp & (lpp - 1):
     return False
-  return x.is_contiguous(memory_format=torch.channels_last)
+  return (x.is_contiguous(memory_format=torch.channels_last) and
+          x.data_ptr() % 16 == 0)
 
 
 class _BnRelu(torch.autograd.Function):

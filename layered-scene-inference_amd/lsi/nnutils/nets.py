@@ -424,14 +424,22 @@ class EncoderDecoderUnet(nn.Module):
       flat = 512 * (in_hw[0] // 128) * (in_hw[1] // 128)
       self.fc = nn.Sequential(SlimFC(flat, 2 * nz), SlimFC(2 * nz, nz),
                               SlimFC(nz, nz))
+      # The U-Net's callers never use `feat` (ldi_enc_dec.py:196-205 takes
+      # feat_dec and skip_feat): in the reference's graph the stack is created
+      # and checkpointed but no gradient reaches it.  Frozen here -- out of the
+      # optimiser and of DDP's reducer -- and executed (without autograd) only
+      # when a caller asks for it with `want_feat`.
+      self.fc.requires_grad_(False)
+    self.want_feat = False
 
   def forward(self, inp_img):
     if inp_img.shape[1] % 128 or inp_img.shape[2] % 128:
       raise ValueError('encoder_decoder_unet needs H and W divisible by 128')
     feats = self.encoder(_nhwc_to_nchw(inp_img))
     feat = None
-    if self.fc is not None:
-      feat = self.fc(_nchw_to_nhwc(feats['cnv7b']).reshape(inp_img.shape[0], -1))
+    if self.fc is not None and self.want_feat:
+      with torch.no_grad():
+        feat = self.fc(_nchw_to_nhwc(feats['cnv7b']).reshape(inp_img.shape[0], -1))
     x = feats['cnv7b']
     for tag, _, skip in self._DEC[:self.n_dec]:
       x = getattr(self, 'upcnv' + tag)(x)

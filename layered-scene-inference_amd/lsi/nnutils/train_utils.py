@@ -187,6 +187,23 @@ class Trainer(object):
     model.load_state_dict(picked, strict=False)
     return sorted(picked)
 
+  @staticmethod
+  def strict_restore(model, state_dict):
+    """load_state_dict(strict=True), except that the constant moving statistics
+    of the fully-connected stacks (SlimFC.moving_mean / moving_variance: buffers
+    added to mirror the reference's variable list, always 0 / 1, never updated)
+    may be missing from checkpoints written before they existed."""
+    from lsi.nnutils import nets
+    const = set()
+    for name, mod in model.named_modules():
+      if isinstance(mod, nets.SlimFC):
+        const.update((name + '.moving_mean', name + '.moving_variance'))
+    res = model.load_state_dict(state_dict, strict=False)
+    missing = [k for k in res.missing_keys if k not in const]
+    if missing or res.unexpected_keys:
+      raise RuntimeError('checkpoint does not match the model: missing %s, '
+                         'unexpected %s' % (missing, list(res.unexpected_keys)))
+
   def resume(self):
     """Latest checkpoint in checkpoint_dir if any; else, when --pretrain_name
     is given, a shape-tolerant warm start from
@@ -197,7 +214,7 @@ class Trainer(object):
     path = self.latest_checkpoint(opts.checkpoint_dir)
     if path is not None:
       state = torch.load(path, map_location=self.device)
-      self.model.load_state_dict(state['model'])
+      self.strict_restore(self.model, state['model'])
       self.global_step = int(state['global_step'])
       return
     if getattr(opts, 'pretrain_name', ''):

@@ -32,7 +32,7 @@ def _worker(rank, world, port, out):
   res = {}
   for wl in ('cfg2', 'cfg3', 'cfg5'):
     res[wl] = bench.shard_batch(wl, world)
-    res[wl + '_strong'] = bench.shard_batch(wl, world, 'strong')
+    res[wl + '_weak'] = bench.shard_batch(wl, world, 'weak')
   # per-rank synthetic shard: same shapes, different content (seed 1000 + rank)
   nl, h, w = 2, 16, 32
   tex, disp, mat = bench.make_inputs(nl, 2, h, w, 'kitti', 0.4, 1000 + rank,
@@ -57,11 +57,11 @@ def test_two_rank_gloo_sharding_and_timing_reduction():
   mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
   r0, r1 = out[0], out[1]
   assert r0['cfg2'] == (4, 'weak') and r1['cfg2'] == (4, 'weak')
-  # default: per-GPU work fixed (every rank renders the whole batch) ...
-  assert r0['cfg3'] == (32, 'weak') and r0['cfg5'] == (8, 'weak')
-  # ... --scaling strong: the batch split over the ranks
-  assert r0['cfg3_strong'] == (16, 'strong') and r0['cfg5_strong'] == (4, 'strong')
-  assert r0['cfg2_strong'] == (4, 'weak')
+  # default: the workload's batch split over the ranks (32 -> B/N) ...
+  assert r0['cfg3'] == (16, 'strong') and r0['cfg5'] == (4, 'strong')
+  # ... --scaling weak: per-GPU work fixed (every rank renders the whole batch)
+  assert r0['cfg3_weak'] == (32, 'weak') and r0['cfg5_weak'] == (8, 'weak')
+  assert r0['cfg2_weak'] == (4, 'weak')
   assert r0['views_total'] == 8.0           # 4 views per rank, weak scaling
   assert r0['tmax'] == [2.0, 10.0] == r1['tmax']   # max over ranks
   assert r0['tex_sum'] != r1['tex_sum']      # different data shards
@@ -87,8 +87,8 @@ def test_bare_shell_multi_gpu_launch_selftest():
   lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
   assert len(lines) == 1, out.stdout
   rec = json.loads(lines[0])
-  assert rec['n_gpus'] == 2 and rec['scaling'] == 'weak'
-  assert rec['views_per_step'] == 64          # cfg3: 32 views per rank
+  assert rec['n_gpus'] == 2 and rec['scaling'] == 'strong'
+  assert rec['views_per_step'] == 32          # cfg3: 32 views split 16 + 16
   assert abs(rec['elapsed_max'] - 2.0e-3) < 1e-9   # max over ranks
 
 
@@ -112,7 +112,8 @@ def test_shard_rejects_uneven_split():
   sys.path.insert(0, ROOT)
   import bench
   with pytest.raises(SystemExit):
-    bench.shard_batch('cfg5', 3, 'strong')
-  assert bench.shard_batch('cfg3', 8, 'strong') == (4, 'strong')
-  assert bench.shard_batch('cfg3', 8) == (32, 'weak')
+    bench.shard_batch('cfg5', 3)
+  assert bench.shard_batch('cfg3', 8) == (4, 'strong')
+  assert bench.shard_batch('cfg5', 8) == (1, 'strong')
+  assert bench.shard_batch('cfg3', 8, 'weak') == (32, 'weak')
   assert bench.algorithmic_bytes(2, 4, 256, 768) == 28311808

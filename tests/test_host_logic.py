@@ -121,15 +121,13 @@ def test_torch_oracle_view_synthesis_loss():
   assert float(d.grad[0].abs().sum()) == 0
 
 
-def test_bilinear_taps_variant_on_cpu():
-  # compose=False is a plain torch gather (no HIP kernel): runs anywhere
+def test_bilinear_taps_variant_has_no_cpu_path():
+  # compose=False is a HIP kernel too (lsi_bilinear_taps; pinned on the GPU by
+  # tests/test_sampling_gpu.py::test_bilinear_goldens): CPU tensors are an error
   from lsi.geometry import sampling
   g = golden('bilinear.npz')
-  ims, wts = sampling.bilinear(T(g['imgs']), T(g['coords']), compose=False)
-  np.testing.assert_allclose(torch.stack(ims).numpy(), g['taps_ims'], rtol=0,
-                             atol=0)
-  np.testing.assert_allclose(torch.stack(wts).numpy(), g['taps_wts'], rtol=1e-6,
-                             atol=1e-7)
+  with pytest.raises(RuntimeError):
+    sampling.bilinear(T(g['imgs']), T(g['coords']), compose=False)
 
 
 @pytest.mark.parametrize('tag', ['compose', 'indep', 'full'])

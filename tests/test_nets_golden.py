@@ -37,7 +37,11 @@ def _model(tag):
   opts = script.apply_dataset_overrides(script.build_parser().parse_args(argv))
   opts.max_disp = 1.0     # the goldens hold the heads' raw sigmoid outputs
   torch.manual_seed(0)
-  return script.LdiNet(opts)
+  net = script.LdiNet(opts)
+  for m in net.modules():  # the U-Net's (frozen, normally skipped) fc stack is pinned too
+    if hasattr(m, 'want_feat'):
+      m.want_feat = True
+  return net
 
 
 def _images(g, tag):

@@ -86,6 +86,17 @@ def test_bilinear_goldens(dev):
   ims, wts = sampling.bilinear(T(g['imgs'], dev), T(g['coords'], dev),
                                compose=False)
   np.testing.assert_array_equal(torch.stack(ims).cpu().numpy(), g['taps_ims'])
+  np.testing.assert_allclose(torch.stack(wts).cpu().numpy(), g['taps_wts'],
+                             rtol=1e-6, atol=1e-7)
+  # arbitrary leading dims through the wrapper (sampling.py:135-168)
+  i5, c5 = T(g['imgs5'], dev), T(g['coords5'], dev)
+  ims5, wts5 = sampling.bilinear_wrapper(i5, c5, compose=False)
+  assert ims5[0].shape == tuple(g['out5'].shape) and wts5[0].shape[-1] == 1
+  comp = sum(w * t for w, t in zip(wts5, ims5))   # taps are border-masked already
+  np.testing.assert_allclose(comp.cpu().numpy(), g['out5'], rtol=1e-5, atol=1e-6)
+  with pytest.raises(RuntimeError, match='not differentiable'):
+    sampling.bilinear(T(g['imgs'], dev).requires_grad_(True), T(g['coords'], dev),
+                      compose=False)
 
 
 def test_bilinear_and_splat_gradients(dev):

@@ -154,11 +154,12 @@ def _free_port():
   return port
 
 
-def _ddp_worker(rank, world, port, tmpdir, out, flat='false'):
+def _ddp_worker(rank, world, port, tmpdir, out, flat='false', complete='false'):
   os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
                     RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
   torch.set_num_threads(2)
-  script, opts = _opts(tmpdir, num_iter=1, flat_grads=flat)
+  script, opts = _opts(tmpdir, num_iter=1, flat_grads=flat,
+                       tf_checkpoint_complete=complete)
   tr = _plumbing_trainer(script, opts)
   tr.setup(backend='gloo')
   from torch.nn.parallel import DistributedDataParallel as DDP
@@ -188,6 +189,26 @@ def test_ddp_gradient_allreduce_two_gloo_ranks(tmp_path):
   assert out2[0][0] == out2[1][0] and out2[0][1] == out2[1][1]
   assert abs(out2[0][0] - out[0][0]) <= 1e-6 * abs(out[0][1])
   assert abs(out2[0][1] - out[0][1]) <= 1e-6 * abs(out[0][1])
+
+
+def test_ddp_with_the_complete_tf_variable_list_two_gloo_ranks(tmp_path):
+  """--tf_checkpoint_complete holds the variables the reference creates but
+  never trains (the fc stack on the U-Net bottleneck, upcnv3 .. icnv1): all of
+  them frozen, so DDP's reducer does not wait for them on the second step, and
+  the trained parameters end where they end without the extra variables."""
+  world = 2
+  mgr = mp.Manager()
+  out = mgr.dict()
+  mp.spawn(_ddp_worker, args=(world, _free_port(), str(tmp_path), out, 'false',
+                              'true'), nprocs=world, join=True)
+  assert out[0][0] == out[1][0] and out[0][1] == out[1][1]
+  script, opts = _opts(tmp_path / 'x', tf_checkpoint_complete='true')
+  net = script.LdiNet(opts)
+  frozen = [n for n, p in net.named_parameters() if not p.requires_grad]
+  assert any('.fc.' in n for n in frozen) and any('upcnv1' in n for n in frozen)
+  trainable = sum(p.numel() for p in net.parameters() if p.requires_grad)
+  _, opts0 = _opts(tmp_path / 'y')
+  assert trainable == sum(p.numel() for p in script.LdiNet(opts0).parameters())
 
 
 def test_resume_picks_the_newest_checkpoint_and_pretrain_restore(tmp_path):
