@@ -334,6 +334,66 @@ def time_both(r, iters=20):
   return out
 
 
+def time_python_surface(r, workload, iters=300):
+  """The Python call surface, eager (no graph): microseconds per
+  `ldi.forward_splat(ldi_src, None, k_s, k_t, rot, t, ...)` -- the reference's
+  signature, ldi.py:71-83 -- on the renderer's resident inputs.  Per call the
+  host computes the projection matrices, picks the kernel, allocates the
+  outputs and enqueues one launch; `wall_us` is what an un-graphed caller sees
+  (max of host and GPU time per call), `host_us` the time the calls take to
+  enqueue.  Cameras on the CPU (the loaders' tensors) and on the GPU (one
+  device-to-host copy per call: the kernel choice needs the matrices)."""
+  nl, h, w, batch, per_gpu, cams, max_disp, bg = WORKLOADS[workload]
+  if cams != 'kitti':
+    return None
+  b = r.tex.shape[1]
+  k = torch.tensor([[0.58 * w, 0, w / 2.0], [0, 0.58 * w, h / 2.0],
+                    [0, 0, 1.0]]).expand(b, 3, 3).contiguous()
+  rot = torch.eye(3).expand(b, 3, 3).contiguous()
+  t = torch.tensor([[-0.532], [0.0], [0.0]]).expand(b, 3, 1).contiguous()
+  out = {}
+  for where in ('cpu', 'gpu'):
+    cam = [x.to(r.dev) if where == 'gpu' else x for x in (k, k, rot, t)]
+    turn = [0]
+
+    def call():
+      tex, disp = r.sets[turn[0]]
+      turn[0] = (turn[0] + 1) % len(r.sets)
+      return ldi.forward_splat([tex, None, disp], None, cam[0], cam[1], cam[2],
+                               cam[3], compose_layers=True,
+                               trg_downsampling=S, bg_layer_disp=bg,
+                               max_disp=max_disp, zbuf_scale=ZBUF_SCALE)
+    with torch.no_grad():
+      for _ in range(10):
+        call()
+      torch.cuda.synchronize()
+      t0 = time.perf_counter()
+      for _ in range(iters):
+        call()
+      t1 = time.perf_counter()
+      torch.cuda.synchronize()
+      t2 = time.perf_counter()
+    out['cameras_on_' + where] = {'wall_us': (t2 - t0) * 1e6 / iters,
+                                  'host_us': (t1 - t0) * 1e6 / iters}
+  with torch.no_grad():
+    tex, disp = r.sets[0]
+    for _ in range(5):
+      ldi.forward_splat_both([tex, None, disp], r.mat.cpu(), S, bg, max_disp, ZBUF_SCALE)
+    torch.cuda.synchronize()
+    mat_host = r.mat.cpu()
+    t0 = time.perf_counter()
+    for i in range(iters // 3):
+      tex, disp = r.sets[i % len(r.sets)]
+      ldi.forward_splat_both([tex, None, disp], mat_host, S, bg, max_disp,
+                             ZBUF_SCALE, mat_host=mat_host)
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+  out['forward_splat_both'] = {'wall_us': (t2 - t0) * 1e6 / (iters // 3),
+                               'host_us': (t1 - t0) * 1e6 / (iters // 3)}
+  return out
+
+
 def backward_bytes(nl, b, h, w):
   """the backward re-reads the inputs (16 B / source px), reads
   g_img (12 B) and the saved img/wts (16 B) per target px and writes g_tex and
@@ -721,6 +781,13 @@ def main():
         }
       except Exception as e:  # pylint: disable=broad-except
         extra['both_outputs'] = {'error': str(e)}
+      try:
+        ps = time_python_surface(r, args.workload)
+        if ps is not None:
+          ps['graph_launch_us'] = kern_s * 1e6
+          extra['python_surface'] = ps
+      except Exception as e:  # pylint: disable=broad-except
+        extra['python_surface'] = {'error': str(e)}
       del r
       torch.cuda.empty_cache()
       other = {}

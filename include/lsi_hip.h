@@ -266,6 +266,20 @@ int lsi_splat_generic_bwd(int32_t B, int32_t Hs, int32_t Ws, int32_t C,
                           float* g_coords, lsi_stream_t stream);
 
 /*
+ * projection.forward_projection_matrix (inverse = 0; projection.py:71-86:
+ * pad(K_t) [R t; 0 1] pad(K_s^-1)) or inverse_projection_matrix (inverse = 1;
+ * :89-106) for B cameras, on the HOST (no device work): k_s, k_t, rot [B,3,3],
+ * t [B,3,1], M [B,4,4], all host fp32.  The 3x3 inverse is evaluated in fp64
+ * and rounded once; the 4x4 products accumulate sequentially over k with every
+ * multiply and add rounded on its own -- the matrices lsi_splat_fwd's
+ * bit-exactness contract is stated on (the Python mirror computes the same
+ * values with torch ops).
+ */
+int lsi_projection_matrices(int32_t B, const float* k_s, const float* k_t,
+                            const float* rot, const float* t, int32_t inverse,
+                            float* M);
+
+/*
  * sampling.batch_scatter_add_tensor, sampling.py:287-313 (and scatter_add_tensor
  * :257-284 with B = 1): out[b, idx[b,i]] += upd[b,i]; duplicates add.
  *   out [B,P] (holds init on entry), idx [B,N] int32 in [0,P), upd [B,N].

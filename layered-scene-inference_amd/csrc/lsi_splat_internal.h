@@ -28,6 +28,11 @@ struct SplatArgs {
 // lsi_stream_ok's return value (kept in LsiSplatDesc.tune_window): window cells,
 // plus this bit when every batch element has M rows 2, 3 = (0,0,1,0), (0,0,0,1).
 constexpr int LSI_STREAM_SIMPLE_BIT = 1 << 20;
+// (also set by lsi_stream_ok) every batch element's vertical magnification
+// M[1][1] is >= 1: a band of R target rows reads at most ceil((R + 1) / s)
+// source rows, what the launchers plan their tables for
+constexpr int LSI_STREAM_ROWS_BIT = 1 << 21;
+constexpr int LSI_STREAM_FLAG_BITS = LSI_STREAM_SIMPLE_BIT | LSI_STREAM_ROWS_BIT;
 
 // LSI_PATH_STREAM launcher and workspace need (lsi_splat_stream.hip).
 size_t lsi_stream_workspace_bytes(const LsiSplatDesc* d);
@@ -70,3 +75,8 @@ int lsi_tile_launch(const SplatArgs& a, hipStream_t stream);
 #define LSI_RANGE_SLICES 8
 #define LSI_SWEEP_MAXL 16
 int lsi_sweep_launch(const SplatArgs& a, const float2* range, hipStream_t stream);
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) only when this (device,
+// kernel) has not been granted `bytes` yet: an eager caller launches the same
+// kernel with the same plan thousands of times (lsi_splat.hip).
+int lsi_ensure_dynamic_lds(const void* fn, size_t bytes);

@@ -1670,10 +1670,11 @@ extern "C" int lsi_stream_ok(const LsiSplatDesc* d, const float* M) {
     return 0;
   const float s = d->trg_downsampling;
   float need = 0.0f;
-  bool simple = true;
+  bool simple = true, rows_ok = true;
   for (int b = 0; b < d->B; ++b) {
     const float* m = M + 16 * b;
     if (m[4] != 0.0f || m[8] != 0.0f) return 0;  // M[1][0], M[2][0]
+    if (!(m[5] >= 1.0f)) rows_ok = false;
     if (!(m[9] == 0.0f && m[10] == 1.0f && m[12] == 0.0f && m[13] == 0.0f &&
           m[14] == 0.0f && m[15] == 1.0f))
       simple = false;
@@ -1691,7 +1692,8 @@ extern "C" int lsi_stream_ok(const LsiSplatDesc* d, const float* M) {
   win = (win + 15) / 16 * 16;
   if (win < 64) win = 64;
   if (win > 512) win = 512;  // beyond this the excess takes the exact slow path
-  return win | (simple ? LSI_STREAM_SIMPLE_BIT : 0);
+  return win | (simple ? LSI_STREAM_SIMPLE_BIT : 0) |
+         ((simple && rows_ok) ? LSI_STREAM_ROWS_BIT : 0);
 }
 
 // Workspace layout of the boundary-row exchange for bands of R rows: arrival
@@ -1838,7 +1840,7 @@ int lsi_stream_launch(const SplatArgs& a, hipStream_t stream) {
   if (!aligned16(a.tex) || (layout != 2 && !aligned16(a.disp)) ||
       ((d->flags & LSI_HAS_MASK) && !aligned16(a.mask)))
     return LSI_EINVAL;
-  if ((d->tune_window & ~LSI_STREAM_SIMPLE_BIT) <= 0)
+  if ((d->tune_window & ~LSI_STREAM_FLAG_BITS) <= 0)
     return LSI_EINVAL;  // from lsi_stream_ok
   if (d->flags & LSI_WANT_DISP) {
     // composed view by the compact instance, then its per-layer-tile variant as
@@ -1853,19 +1855,19 @@ int lsi_stream_launch(const SplatArgs& a, hipStream_t stream) {
     // renders the request)
     if (!lsi_stream2_applies(a1, (d->tune_window & LSI_STREAM_SIMPLE_BIT) != 0, layout))
       return lsi_tile_launch(a, stream);
-    const int wmax = d->tune_window & ~LSI_STREAM_SIMPLE_BIT;
+    const int wmax = d->tune_window & ~LSI_STREAM_FLAG_BITS;
     const int rc = lsi_stream2_launch(a1, wmax, stream);
     if (rc != LSI_OK) return rc;
     return lsi_stream2_launch(a, wmax, stream, true);
   }
   if (lsi_stream2_applies(a, (d->tune_window & LSI_STREAM_SIMPLE_BIT) != 0, layout))
-    return lsi_stream2_launch(a, d->tune_window & ~LSI_STREAM_SIMPLE_BIT, stream);
+    return lsi_stream2_launch(a, d->tune_window & ~LSI_STREAM_FLAG_BITS, stream);
   // (RGBD pixels outside the compact instance's cases, e.g. per-layer outputs
   // alone: the any-stride path)
   if (layout == 2) return lsi_tile_launch(a, stream);
   const int NB = (d->Wt + 63) / 64;
   StreamCfg cfg;
-  cfg.wmax = d->tune_window & ~LSI_STREAM_SIMPLE_BIT;
+  cfg.wmax = d->tune_window & ~LSI_STREAM_FLAG_BITS;
   StreamPlan plan;
   const bool both = a.out_img_c != nullptr;
   if (both && (d->flags & LSI_COMPOSE)) return LSI_EINVAL;

@@ -24,6 +24,10 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
+
+#include <mutex>
+#include <vector>
 
 #include "../../include/lsi_hip.h"
 #include "lsi_common.h"
@@ -388,6 +392,11 @@ __device__ __forceinline__ float4 s2_ld_nt(const float* p) {
 // BOTH: lsi_splat_fwd_both -- the per-layer views AND the composed one from one
 // sweep: one tile per layer in LDS, every item (one layer of a unit) merges its
 // window into its layer's tile, the epilogue writes L + 1 views.
+// (Tried in round 4 and dropped: layers outermost with two tiles -- the current
+// layer's and the sum of the finished ones -- and a workgroup rendezvous between
+// layers, which allows bands of 8 rows instead of 4: 257 us against 195 at
+// config 3.  The rendezvous stops every wave's loads four times per band, and
+// one-layer tickets cost more than their share: profiles/r04/both_layer_outer.txt.)
 template <int NSETS, bool CELL, int MAXT, bool BOTH = false, bool PACK = false,
           bool RAGGED = false>
 __global__ __launch_bounds__(MAXT) void splat_stream2_kernel(S2Args a) {
@@ -1253,9 +1262,64 @@ __global__ __launch_bounds__(MAXT) void splat_stream2_kernel(S2Args a) {
     } else {
       for (int i = tid; i < ncell; i += T) a.out_disp[o0 + i] = dmax_of(i);
     }
+  } else if (BOTH && a.ep >= 4) {
+    // per layer (ldi.py:157-163, 176-177) and composed (:167-174), whole lines
+    // per store instruction as in the composed-only epilogue below: lane q of a
+    // wave writes floats 4q .. 4q + 3 of every view's colour plane; they belong
+    // to cells f / 3 and f / 3 + 1 of each layer's tile
+    const float bg = a.bg;
+    const size_t P = (size_t)Ht * Wt;
+    const size_t o0 = (size_t)b * P + (size_t)row0 * Wt;
+    const int ncell = rows * Wt;
+    const int nq = (3 * ncell) >> 2;
+    const size_t lstride = (size_t)R * Wt;
+    for (int q = tid; q < nq; q += T) {
+      const unsigned f = 4u * (unsigned)q;
+      const unsigned c0 = __umulhi(f, 0xAAAAAAABu) >> 1;  // f / 3
+      const unsigned o3 = f - 3u * c0;
+      const int c1 = min((int)c0 + 1, ncell - 1);
+      float4 CA = make_float4(0.f, 0.f, 0.f, 0.f), CB = CA;
+      for (int l = 0; l < a.L; ++l) {
+        const float4 A = tile4[l * lstride + c0];
+        const float4 Bc = tile4[l * lstride + c1];
+        const float wa = A.w + bg, wb = Bc.w + bg;
+        const float ra = __builtin_amdgcn_rcpf(safe_den(wa));
+        const float rb_ = __builtin_amdgcn_rcpf(safe_den(wb));
+        const float ax = (A.x + bg) * ra, ay = (A.y + bg) * ra, az = (A.z + bg) * ra;
+        const float bx = (Bc.x + bg) * rb_, by = (Bc.y + bg) * rb_, bz = (Bc.z + bg) * rb_;
+        CA.x += A.x + bg; CA.y += A.y + bg; CA.z += A.z + bg; CA.w += wa;
+        CB.x += Bc.x + bg; CB.y += Bc.y + bg; CB.z += Bc.z + bg; CB.w += wb;
+        s2_store4(a.out_img + 3 * ((size_t)l * a.B * P + o0) + f,
+                  o3 == 0 ? ax : (o3 == 1 ? ay : az), o3 == 0 ? ay : (o3 == 1 ? az : bx),
+                  o3 == 0 ? az : (o3 == 1 ? bx : by), o3 == 0 ? bx : (o3 == 1 ? by : bz),
+                  ep_st);
+      }
+      if (a.out_img_c) {
+        const float ra = __builtin_amdgcn_rcpf(safe_den(CA.w));
+        const float rb_ = __builtin_amdgcn_rcpf(safe_den(CB.w));
+        const float ax = CA.x * ra, ay = CA.y * ra, az = CA.z * ra;
+        const float bx = CB.x * rb_, by = CB.y * rb_, bz = CB.z * rb_;
+        s2_store4(a.out_img_c + 3 * o0 + f,
+                  o3 == 0 ? ax : (o3 == 1 ? ay : az), o3 == 0 ? ay : (o3 == 1 ? az : bx),
+                  o3 == 0 ? az : (o3 == 1 ? bx : by), o3 == 0 ? bx : (o3 == 1 ? by : bz),
+                  ep_st);
+      }
+    }
+    const float* const tw = reinterpret_cast<const float*>(tile4) + 3;
+    for (int q = tid; q < (ncell >> 2); q += T) {
+      float cw[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int l = 0; l < a.L; ++l) {
+        const float* t = tw + 4 * (l * lstride + 4 * q);
+        const float w0 = t[0] + bg, w1 = t[4] + bg, w2 = t[8] + bg, w3 = t[12] + bg;
+        cw[0] += w0; cw[1] += w1; cw[2] += w2; cw[3] += w3;
+        s2_store4(a.out_wts + (size_t)l * a.B * P + o0 + 4 * q, w0, w1, w2, w3, ep_st);
+      }
+      if (a.out_img_c)
+        s2_store4(a.out_wts_c + o0 + 4 * q, cw[0], cw[1], cw[2], cw[3], ep_st);
+    }
   } else if (BOTH && a.ep) {
     // per layer (ldi.py:157-163, 176-177) and composed (:167-174), four cells
-    // per thread: 16-byte streaming stores
+    // per thread: 16-byte stores
     const float bg = a.bg;
     const size_t P = (size_t)Ht * Wt;
     const size_t o0 = (size_t)b * P + (size_t)row0 * Wt;
@@ -1434,7 +1498,37 @@ struct S2Plan { int R, nw, cell, cap, qcap, ilv, hf, nsplit, lsub; size_t lds; d
 // apart) and whole rounds of workgroups: so one workgroup per CU (the LDS tile
 // allows only one) in ONE round, as many waves as fit, the tallest band that
 // still gives every CU a workgroup.
+int s2_plan_search(const LsiSplatDesc* d, int wmax, int maxnw, bool both, S2Plan* out);
+
+// The plan depends on the call's geometry only: remembered per geometry, so
+// that an eager caller (one launch per Python call) does not pay the search
+// again (~80 candidate plans) on every launch.
 int s2_plan(const LsiSplatDesc* d, int wmax, int maxnw, bool both, S2Plan* out) {
+  struct Key { int v[14]; };
+  struct Entry { Key k; S2Plan p; };
+  static std::mutex mu;
+  static std::vector<Entry> memo;
+  Key k;
+  const int kv[14] = {d->L, d->B, d->H, d->W, d->Ht, d->Wt, wmax, maxnw, both ? 1 : 0,
+                      d->tune_rows, d->tune_threads, d->reserved, 0,
+                      d->tune_window & LSI_STREAM_FLAG_BITS};
+  memcpy(k.v, kv, sizeof(kv));
+  memcpy(&k.v[12], &d->trg_downsampling, sizeof(float));
+  {
+    std::lock_guard<std::mutex> g(mu);
+    for (const Entry& e : memo)
+      if (memcmp(e.k.v, k.v, sizeof(k.v)) == 0) { *out = e.p; return LSI_OK; }
+  }
+  const int rc = s2_plan_search(d, wmax, maxnw, both, out);
+  if (rc == LSI_OK) {
+    std::lock_guard<std::mutex> g(mu);
+    if (memo.size() >= 64) memo.erase(memo.begin());
+    memo.push_back(Entry{k, *out});
+  }
+  return rc;
+}
+
+int s2_plan_search(const LsiSplatDesc* d, int wmax, int maxnw, bool both, S2Plan* out) {
   const int nt = both ? d->L : 1;
   const int nseg = (d->W + SEG - 1) / SEG;
   static const char* cap_env = getenv("LSI_STREAM_LDS_CAP");
@@ -1578,7 +1672,12 @@ int lsi_stream2_launch(const SplatArgs& a, int wmax, hipStream_t stream,
   k.hf = plan.hf;
   {
     static const char* ep_env = getenv("LSI_S2_EPILOGUE");
-    const int ep = ep_env ? atoi(ep_env) : 3;
+    // 5: whole 128-byte lines per store instruction, non-temporal.  Measured at
+    // config 3 on one box (profiles/r04/ab_epilogue.txt): scalar stores 89.6 us,
+    // 16-byte plain 90.5, 16-byte non-temporal (16 of every 48 bytes per
+    // instruction) 90.4, whole lines plain 90.7, whole lines non-temporal 82.0:
+    // the rendered views no longer linger dirty in the L2s until the launch ends.
+    const int ep = ep_env ? atoi(ep_env) : 5;
     // (four cells per thread, 16-byte stores: rows of whole quads, aligned outputs)
     bool al = d->Wt % 4 == 0;
     for (const float* p : {k.out_img, k.out_wts, k.out_img_c, k.out_wts_c, k.out_disp})
@@ -1607,9 +1706,7 @@ int lsi_stream2_launch(const SplatArgs& a, int wmax, hipStream_t stream,
                         : (plan.cell ? S2_PICK(true, false) : S2_PICK(false, false));
 #undef S2_PICK
 #undef S2_FN
-  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
-                          (int)plan.lds) != hipSuccess)
-    return LSI_ELAUNCH;
+  if (lsi_ensure_dynamic_lds(fn, plan.lds) != LSI_OK) return LSI_ELAUNCH;
   void* kargs[1] = {&k};
   if (hipLaunchKernel(fn, dim3(nbands, d->B), dim3(plan.nw * 64), kargs, plan.lds,
                       stream) != hipSuccess)

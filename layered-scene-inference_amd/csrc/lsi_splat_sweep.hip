@@ -41,6 +41,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/lsi_hip.h"
 #include "lsi_common.h"
@@ -76,6 +77,7 @@ struct SweepCfg {
   int tiles_x;
   int nq4;         // groups of four 64-pixel segments per source row
   int all_layers;  // 1: compose, every layer sums into the tile; 0: grid.z = layer
+  int stream_out;  // 1: 16-byte aligned outputs, Wt % 4 == 0: whole-line streaming stores
   float inv_nq4, inv_nlw;
 };
 
@@ -682,6 +684,42 @@ __global__ __launch_bounds__(SWEEP_T, LSI_SWEEP_WGS) void splat_sweep_kernel(
     return;
   }
   const float bgs = (float)NLW * d.bg_wt;
+  if (!WANT_DISP && c.stream_out && tw_eff == TW) {
+    // Whole 128-byte lines per store instruction, non-temporal (the rendered
+    // view is written once; see store_stream_f4 in lsi_common.h and the compact
+    // stream kernel's epilogue): lane q of a tile row writes floats 4q .. 4q+3
+    // of the row's 3 * TW colour floats -- they belong to cells 4q/3 and 4q/3+1.
+    constexpr int QR = 3 * TW / 4;  // 16-byte stores per tile row (colours)
+    auto cell_at = [&](int cy, int cx) {
+      return tile[((cy + 1) << TWL) + (cx >> 1) + ((cx & 1) << (TWL - 1))];
+    };
+    for (int q = tid; q < th_eff * QR; q += SWEEP_T) {
+      const int cy = q / QR, j = q - cy * QR;
+      const unsigned f = 4u * (unsigned)j;
+      const unsigned c0 = __umulhi(f, 0xAAAAAAABu) >> 1;  // f / 3
+      const unsigned o3 = f - 3u * c0;
+      const float4 A = cell_at(cy, (int)c0);
+      const float4 Bc = cell_at(cy, min((int)c0 + 1, TW - 1));
+      const float wa = safe_den(A.w + bgs), wb = safe_den(Bc.w + bgs);
+      const float ax = div_rn(A.x + bgs, wa), ay = div_rn(A.y + bgs, wa),
+                  az = div_rn(A.z + bgs, wa);
+      const float bx = div_rn(Bc.x + bgs, wb), by = div_rn(Bc.y + bgs, wb),
+                  bz = div_rn(Bc.z + bgs, wb);
+      const float v0 = o3 == 0 ? ax : (o3 == 1 ? ay : az);
+      const float v1 = o3 == 0 ? ay : (o3 == 1 ? az : bx);
+      const float v2 = o3 == 0 ? az : (o3 == 1 ? bx : by);
+      const float v3 = o3 == 0 ? bx : (o3 == 1 ? by : bz);
+      const size_t o = obase + (size_t)(ty0 + cy) * Wt + tx0;
+      store_stream_f4(a.out_img + 3 * o + f, v0, v1, v2, v3);
+    }
+    for (int q = tid; q < th_eff * (TW / 4); q += SWEEP_T) {
+      const int cy = q / (TW / 4), cx = 4 * (q - cy * (TW / 4));
+      const size_t o = obase + (size_t)(ty0 + cy) * Wt + tx0 + cx;
+      store_stream_f4(a.out_wts + o, cell_at(cy, cx).w + bgs, cell_at(cy, cx + 1).w + bgs,
+                      cell_at(cy, cx + 2).w + bgs, cell_at(cy, cx + 3).w + bgs);
+    }
+    return;
+  }
   for (int cell = tid; cell < (th_eff << TWL); cell += SWEEP_T) {
     const int cy = cell >> TWL, cx = cell & (TW - 1);
     const int gy = ty0 + cy, gx = tx0 + cx;
@@ -754,6 +792,11 @@ int lsi_sweep_launch(const SplatArgs& a, const float2* range, hipStream_t stream
   c.tiles_x = (d->Wt + TW - 1) / TW;
   c.nq4 = (d->W + 4 * SEGW - 1) / (4 * SEGW);
   c.all_layers = compose ? 1 : 0;
+  {
+    static const char* so_env = getenv("LSI_SWEEP_STREAM_OUT");  // experiments: 0 = scalar stores
+    c.stream_out = ((so_env ? atoi(so_env) : 1) && d->Wt % 4 == 0 &&
+                    aligned16(a.out_img) && aligned16(a.out_wts)) ? 1 : 0;
+  }
   c.inv_nq4 = 1.0f / (float)c.nq4;
   c.inv_nlw = 1.0f / (float)(compose ? d->L : 1);
   const int tiles_y = (d->Ht + c.th - 1) / c.th;

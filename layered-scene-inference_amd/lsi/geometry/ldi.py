@@ -8,6 +8,7 @@ An LDI is {textures, masks, disps}:
 (reference ldi.py:18-21).  Any strides are accepted (e.g. a permuted NCHW conv
 output) -- the kernels take element strides, nothing is copied.
 """
+import collections
 import ctypes
 import threading
 
@@ -102,6 +103,35 @@ def plan_key(shape, trg_downsampling, max_disp, mat_host):
 
 _WS_CACHE = {}
 _WS_LOCK = threading.Lock()
+_MAT_CACHE = collections.OrderedDict()   # (device, matrix bytes) -> device tensor
+_MAT_CACHE_SIZE = 64
+
+
+def _device_matrices(src2trg_mat, mat_host, dev):
+  """The B x 4 x 4 matrices on the renderer's device.  A host tensor is
+  uploaded once per distinct content (a few kilobytes: keyed by its bytes) and
+  kept -- an eager caller that renders with the same cameras again (the two
+  directions of a stereo pair, an evaluation loop) then issues no copy at all;
+  a pageable host-to-device copy would wait for the kernels queued before it
+  and serialise the host with the GPU.  New content goes through pinned memory,
+  asynchronously."""
+  if src2trg_mat.is_cuda or dev.type != 'cuda':
+    # (a CPU `dev`: the call is about to fail in require_device -- no CPU path)
+    return src2trg_mat.detach().to(dev, torch.float32)
+  host = (mat_host if mat_host is not None else
+          src2trg_mat.detach().to('cpu', torch.float32)).contiguous()
+  key = (dev.index, host.numpy().tobytes())
+  with _WS_LOCK:
+    hit = _MAT_CACHE.get(key)
+    if hit is not None:
+      _MAT_CACHE.move_to_end(key)
+      return hit
+  mat = host.pin_memory().to(dev, non_blocking=True)
+  with _WS_LOCK:
+    _MAT_CACHE[key] = mat
+    while len(_MAT_CACHE) > _MAT_CACHE_SIZE:
+      _MAT_CACHE.popitem(last=False)
+  return mat
 
 
 def _stream_workspace(desc, dev):
@@ -308,7 +338,7 @@ def forward_splat_both(ldi_src, src2trg_mat, trg_downsampling=1,
   tex, mask, disp = ldi_src
   if mat_host is None and path not in ('atomic', 'tile'):
     mat_host = src2trg_mat.detach().to('cpu', torch.float32)
-  mat = src2trg_mat.detach().to(tex.device, torch.float32)
+  mat = _device_matrices(src2trg_mat, mat_host, tex.device)
   cfg = dict(trg_downsampling=trg_downsampling, bg_layer_disp=bg_layer_disp,
              max_disp=max_disp, zbuf_scale=zbuf_scale, path=path,
              deterministic=bool(deterministic), band_rows=band_rows,
@@ -333,7 +363,7 @@ def forward_splat_matrix(ldi_src, src2trg_mat, compose_layers=True,
   tex, mask, disp = ldi_src
   if mat_host is None and path not in ('atomic', 'tile'):
     mat_host = src2trg_mat.detach().to('cpu', torch.float32)
-  mat = src2trg_mat.detach().to(tex.device, torch.float32)
+  mat = _device_matrices(src2trg_mat, mat_host, tex.device)
   cfg = dict(compose_layers=bool(compose_layers),
              compute_trg_disp=bool(compute_trg_disp),
              trg_downsampling=trg_downsampling, bg_layer_disp=bg_layer_disp,

@@ -151,3 +151,32 @@ def test_view_synthesis_loss_matches_the_reference_script_lines(tag):
   assert g[tag + '_pwise'].shape[1:] == (
       recons.shape[2] - 2 * loss._py2_round(recons.shape[2] * bdry),
       recons.shape[3] - 2 * loss._py2_round(recons.shape[3] * bdry))
+
+
+def test_host_projection_matrices_equal_the_torch_ops_bit_for_bit(built_lib):
+  """lsi_projection_matrices (csrc/lsi_host.hip; what forward_splat calls for
+  host cameras) against the torch restatement of projection.py:71-106 (fp64
+  adjugate inverse rounded once, sequential-k products): identical bits, both
+  directions, intrinsics-like and general matrices."""
+  from lsi.geometry import projection
+  gen = torch.Generator().manual_seed(5)
+  for trial in range(120):
+    b = 1 + trial % 5
+    f = torch.rand(b, generator=gen) * 900 + 100
+    k = torch.zeros(b, 3, 3)
+    k[:, 0, 0] = f
+    k[:, 1, 1] = f * (0.9 + 0.2 * torch.rand(b, generator=gen))
+    k[:, 0, 2] = torch.rand(b, generator=gen) * 800
+    k[:, 1, 2] = torch.rand(b, generator=gen) * 300
+    k[:, 2, 2] = 1
+    if trial % 3 == 0:
+      k = k + 0.1 * torch.randn(b, 3, 3, generator=gen)
+    k2 = k * (0.8 + 0.4 * float(torch.rand(1, generator=gen)))
+    rot = torch.linalg.qr(torch.randn(b, 3, 3, generator=gen))[0].contiguous()
+    t = torch.randn(b, 3, 1, generator=gen)
+    for fn in (projection.forward_projection_matrix,
+               projection.inverse_projection_matrix):
+      fast = fn(k, k2, rot, t)                       # B x 3 x 3 on the host: C
+      slow = fn(k[None], k2[None], rot[None], t[None])[0]   # other ranks: torch
+      assert fast.shape == (b, 4, 4) and torch.equal(fast, slow)
+  assert projection._host_matrices(k.double(), k2, rot, t, False) is None
