@@ -173,6 +173,50 @@ def project(mat, disp, trg_downsampling=1.0):
   return u.astype(np.float32), v.astype(np.float32), dd
 
 
+def decisions_are_robust(mat, disp, trg_downsampling, h_trg, w_trg, max_disp):
+  """For comparisons of fp32 results with an fp64 evaluation of the same op
+  graph (gradient checks): True where a source pixel's discrete decisions --
+  floor of the target coordinate and the border masks (sampling.py:189-211),
+  the 1e-3 clamp of its four corner weights (:218-222), the z-buffer weight's
+  `x > 0` and clip (helpers.py:187-191) -- come out the same when the graph is
+  evaluated in fp32 (the reference's arithmetic) and in fp64 (the gradient
+  oracle's).  Where they differ the two legitimately disagree by a whole
+  corner's contribution.
+
+  mat B x 4 x 4, disp B x H x W; returns bool B x H x W."""
+
+  def decide(dt):
+    m = np.asarray(mat, dt)[:, :, :, None, None]
+    d = np.asarray(disp, np.float32).astype(dt)
+    b, h, w = d.shape
+    xs = (np.arange(w, dtype=dt) + dt(0.5))[None, None, :]
+    ys = (np.arange(h, dtype=dt) + dt(0.5))[None, :, None]
+    with np.errstate(all='ignore'):
+      q = [((xs * m[:, j, 0] + ys * m[:, j, 1]) + m[:, j, 2]) + d * m[:, j, 3]
+           for j in range(4)]
+      n = q[2] + dt(1e-8) * (q[2] == 0)
+      s = dt(trg_downsampling)
+      x, y = q[0] / n * s - dt(0.5), q[1] / n * s - dt(0.5)
+      z = q[3] / n / dt(max_disp)
+      x0, y0 = np.floor(x), np.floor(y)
+      bits = [x0, y0, (z > 0), (z >= 0) & (z <= 1)]
+      wx = [(x0 + 1 - x) * ((x0 >= 0) & (x0 <= w_trg - 1)),
+            (x - x0) * ((x0 + 1 >= 0) & (x0 + 1 <= w_trg - 1))]
+      wy = [(y0 + 1 - y) * ((y0 >= 0) & (y0 <= h_trg - 1)),
+            (y - y0) * ((y0 + 1 >= 0) & (y0 + 1 <= h_trg - 1))]
+      for a in wx:
+        for c in wy:
+          bits.append(a * c > dt(1e-3))
+    return bits
+
+  lo, hi = decide(np.float32), decide(np.float64)
+  ok = np.ones(np.asarray(disp).shape, bool)
+  for a, c in zip(lo, hi):
+    with np.errstate(all='ignore'):
+      ok &= (np.asarray(a, np.float64) == np.asarray(c, np.float64))
+  return ok
+
+
 # ---------------------------------------------------------------------------
 # lsi/geometry/sampling.py
 # ---------------------------------------------------------------------------

@@ -146,3 +146,38 @@ def test_kitti_configs_disparity_output_and_backward_full_size(workload, batch, 
     del p, img, wts, img_c, wts_c
   scale = np.abs(grads['0']).max() + 1e-30
   assert np.abs(grads['1'] - grads['0']).max() <= 2e-5 * scale
+  # (4) both kernels against fp64 autograd of the reference's op graph
+  # (oracle/lsi_torch_ref.py) on whole batch elements -- the first, one in the
+  # middle and the last: 3 x L x 196 608 source pixels (2.4 M at config 3);
+  # batch elements are independent, so the oracle needs only their data.  The
+  # bar is stated on each kernel's own distance from fp64, not on their
+  # distance from each other.
+  import lsi_torch_ref as TR
+  sel = sorted({0, batch // 2, batch - 1})
+  t64 = tex[:, sel].double().requires_grad_(True)
+  d64 = disp[:, sel].double().requires_grad_(True)
+  ones = torch.ones_like(d64)
+  m64 = mat[sel].double()
+  img_l, wts_l, _ = TR.forward_splat(t64, ones, d64, m64, 0.5, bg, md, ZB, False)
+  img_k, wts_k, _ = TR.forward_splat(t64, ones, d64, m64, 0.5, bg, md, ZB, True)
+  g = torch.Generator().manual_seed(3)
+  ci = torch.rand(tuple(img_l.shape[:1]) + (batch,) + tuple(img_l.shape[2:]), generator=g)
+  cc = torch.rand((1, batch) + tuple(img_k.shape[2:]), generator=g)
+  ((img_l * ci[:, sel].double()).sum() + (img_k * cc[:, sel].double()).sum() +
+   1e-3 * torch.log(wts_k).sum()).backward()
+  ref = torch.cat([t64.grad, d64.grad], dim=-1).numpy()
+  scale64 = np.abs(ref).max() + 1e-30
+  # (compared where a pixel's floor / clamp / clip decisions are the same in
+  # fp32 and fp64: lsi_oracle.decisions_are_robust)
+  import lsi_oracle as O
+  h, w = tex.shape[2:4]
+  firm = np.stack([O.decisions_are_robust(mat[sel].numpy(), disp[l, sel, :, :, 0].numpy(),
+                                          0.5, h // 2, w // 2, md)
+                   for l in range(tex.shape[0])])[..., None]
+  assert firm.mean() > 0.95
+  err = {k: float((np.abs(v[:, sel] - ref) * firm).max() / scale64)
+         for k, v in grads.items()}
+  print('backward vs fp64 autograd, %s, %d source pixels: streamed %.2e, gather %.2e '
+        '(of the largest gradient entry)' % (workload, ref[..., 0].size, err['1'],
+                                             err['0']))
+  assert err['1'] <= 2e-5 and err['0'] <= 2e-5, err

@@ -44,9 +44,9 @@ def main():
   calls = []
 
   def hook(mod, inp, out):
-    calls.append((mod, tuple(inp[0].shape), tuple(out.shape)))
+    calls.append((mod, tuple(inp[0].shape)))
   hs = [m.register_forward_hook(hook) for m in net.modules()
-        if isinstance(m, (torch.nn.Conv2d, torch.nn.ConvTranspose2d))]
+        if isinstance(m, (nets.SlimConv2d, nets.SlimConvTranspose2d))]
   names = {m: n for n, m in net.named_modules()}
   b = opts.batch_size * 2                       # source and target images
   imgs = torch.rand(b, opts.img_height, opts.img_width, 3, device=dev)
@@ -68,20 +68,30 @@ def main():
     return e0.elapsed_time(e1) * 1e-3 / iters
 
   rows, tot_f, tot_b, t_f, t_b = [], 0.0, 0.0, 0.0, 0.0
-  for idx, (mod, ishape, oshape) in enumerate(calls):
+  for idx, (mod, ishape) in enumerate(calls):
     n, cin, hi, wi = ishape
-    _, cout, ho, wo = oshape
-    transposed = isinstance(mod, torch.nn.ConvTranspose2d)
-    k = mod.kernel_size[0]
-    flops = (2.0 * n * hi * wi * cin * cout * k * k if transposed else
-             2.0 * n * ho * wo * cout * cin * k * k)
+    transposed = isinstance(mod, nets.SlimConvTranspose2d)
+    conv = mod.conv
+    k = conv.kernel_size[0]
     x = torch.randn(ishape, device=dev, dtype=dt).contiguous(
         memory_format=torch.channels_last).requires_grad_(idx > 0)
-    w = mod.weight.detach().to(dt).requires_grad_(True)
+    w = conv.weight.detach().to(dt).requires_grad_(True)
     if transposed:
-      fwd = lambda: F.conv_transpose2d(x, w, None, mod.stride, mod.padding)
+      fwd = lambda: F.conv_transpose2d(x, w, None, conv.stride, conv.padding)
     else:
-      fwd = lambda: F.conv2d(x, w, None, mod.stride, mod.padding)
+      # slim's SAME padding (nets.SlimConv2d.forward): symmetric for stride 1,
+      # one more pixel after for stride 2
+      ph = nets._same_pad(hi, k, mod.stride)
+      pw = nets._same_pad(wi, k, mod.stride)
+      if ph[0] == ph[1] and pw[0] == pw[1]:
+        fwd = lambda: F.conv2d(x, w, None, mod.stride, (ph[0], pw[0]))
+      else:
+        fwd = lambda: F.conv2d(F.pad(x, (pw[0], pw[1], ph[0], ph[1])), w, None, mod.stride)
+    with torch.no_grad():
+      oshape = tuple(fwd().shape)
+    _, cout, ho, wo = oshape
+    flops = (2.0 * n * hi * wi * cin * cout * k * k if transposed else
+             2.0 * n * ho * wo * cout * cin * k * k)
     y = fwd()
     g = torch.randn_like(y)
     tf = bench(lambda: fwd())

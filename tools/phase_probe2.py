@@ -26,17 +26,21 @@ for i in range(3):
   sets.append((tex, disp))
 r = bench.Renderer(sets[0][0], sets[0][1], mat, max_disp, bg, 'stream', rows, threads, sets[1:])
 r.desc.reserved = 4
-nwg = 8192
-r.ws = torch.zeros((nwg * 16 * 8 * 8,), dtype=torch.uint8, device=dev)
+# stamps: the kernel writes one KiB per workgroup into the LAST nbands * B KiB
+# of the workspace it is handed (its start keeps the renderer's own use: the
+# exchange bands' flags and rows); the buffer here has room for 8192 workgroups
+nwg_max = 8192
+base = (r.ws_bytes + 1023) // 1024 * 1024
+r.ws = torch.zeros((base + nwg_max * 1024,), dtype=torch.uint8, device=dev)
 r.ws_bytes = r.ws.numel()
 for _ in range(6):
   r.launch()
 torch.cuda.synchronize()
-r.ws.zero_()
+r.ws[base:].zero_()
 torch.cuda.synchronize()
 r.launch()
 torch.cuda.synchronize()
-t = r.ws.view(torch.int64).view(-1, 16, 8).cpu().numpy().astype(np.float64)
+t = r.ws[base:].view(torch.int64).view(-1, 16, 8).cpu().numpy().astype(np.float64)
 wg_used = t[:, 0, 0] != 0
 t = t[wg_used]
 act = t[:, :, 0] != 0                      # waves that exist
