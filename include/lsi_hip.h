@@ -437,6 +437,25 @@ int lsi_bn_relu_bwd(const void* x, const void* dy, const float* mean_rstd,
                     int64_t npix, int32_t C, int32_t bf16, int32_t relu,
                     int32_t groups, lsi_stream_t stream);
 
+/*
+ * 3x3 stride-1 SAME convolution over 32 input channels on the matrix cores
+ * (v_mfma_f32_16x16x32_bf16, fp32 accumulation): the full-resolution layers of
+ * the LDI heads.
+ *   mode 0  `upcnv1b` (nets.py:104-111): cout = 16 or 32, output bf16
+ *           N x H x W x cout (before batch norm);
+ *   mode 1  `pred_l` (nets.py:150-158): cout <= 4, bias, sigmoid, channel 3
+ *           times scale3, output fp32 N x H x W x 4 -- RGBD pixels;
+ *   mode 2  the data gradient of mode 0 with cout = 32: the same convolution
+ *           with the kernel transposed and flipped (x = the incoming gradient).
+ *   x: bf16 N x H x W x 32, channels innermost (torch channels_last), 16-byte
+ *   aligned; W % 16 == 0.  weight: the layer's fp32 parameter cout x 32 x 3 x 3
+ *   (rounded to bf16 in the kernel, as torch.autocast does).  bias: [cout]
+ *   fp32 or NULL (mode 1).
+ */
+int lsi_conv3x3_c32_fwd(int32_t N, int32_t H, int32_t W, int32_t cout, int32_t mode,
+                        const void* x, const float* weight, const float* bias,
+                        float scale3, void* out, lsi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

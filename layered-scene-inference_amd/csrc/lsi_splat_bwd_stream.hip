@@ -463,8 +463,12 @@ int lsi_bwd_stream_launch(const LsiSplatDesc* d, const float* tex,
   BSArgs a;
   a.tex = tex; a.disp = disp; a.M = M; a.g_tex = g_tex; a.g_disp = g_disp;
   {
-    static const char* nt_env = getenv("LSI_BWD_NT");  // experiments: 0 = plain stores
-    a.nt = nt_env ? atoi(nt_env) : 1;
+    // Plain stores: a lane's four 16-byte stores are a third of the 48 bytes it
+    // owns per instruction; as non-temporal stores those partial lines are not
+    // merged -- WRITE_SIZE 476 MB instead of 403 MB per launch at config 3, the
+    // same time (profiles/r04/pmc_bwd_stream_cfg3.txt; LSI_BWD_NT=1 to compare)
+    static const char* nt_env = getenv("LSI_BWD_NT");
+    a.nt = nt_env ? atoi(nt_env) : 0;
   }
   const bool has_mask = (d->flags & LSI_HAS_MASK) != 0;
   a.mask = has_mask ? mask : nullptr; a.g_mask = has_mask ? g_mask : nullptr;

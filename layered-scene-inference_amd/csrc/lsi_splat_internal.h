@@ -80,7 +80,3 @@ int lsi_sweep_launch(const SplatArgs& a, const float2* range, hipStream_t stream
 // kernel) has not been granted `bytes` yet: an eager caller launches the same
 // kernel with the same plan thousands of times (lsi_splat.hip).
 int lsi_ensure_dynamic_lds(const void* fn, size_t bytes);
-
-// Workspace of the STREAM path: arrival counters / flags first (left zero by
-// every launch), partial rows from this offset on (lsi_splat_stream.hip).
-size_t lsi_stream_ws_rows_offset(const LsiSplatDesc* d);

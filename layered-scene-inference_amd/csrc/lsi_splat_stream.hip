@@ -1709,10 +1709,6 @@ static XLayout stream_exchange_layout(const LsiSplatDesc* d, int R) {
   return x;
 }
 
-size_t lsi_stream_ws_rows_offset(const LsiSplatDesc* d) {
-  return stream_exchange_layout(d, 1).count_bytes;
-}
-
 size_t lsi_stream_workspace_bytes(const LsiSplatDesc* d) {
   const XLayout x = stream_exchange_layout(d, 1);  // worst case: 1-row bands
   return x.count_bytes + x.part_bytes;

@@ -76,12 +76,6 @@ struct S2Args {
   float bg;                        // bg weight of one layer's canvas
   int R, wmax, qcap, cap, ilv;     // band rows, window cells, queue, table, row interleave
   int hf;                          // halo rows first (see BandOrder)
-  // Exchange bands (xch): a band reads only the source rows whose footprint
-  // STARTS in it and hands the row it spills into its lower neighbour over
-  // through the workspace (see the kernel)
-  int xch;
-  float4* xrow;                    // [B][bands][Wt] partial rows
-  int* xflag;                      // [B][bands] "row is there" (left zero)
   int ep;                          // epilogue stores: 0 scalar, 1 16-byte, 2 16-byte write-through, 3 16-byte nt
   int nsplit, lsub;                // units handed out lsub layers per ticket
   float inv_gx, inv_nseg;
@@ -388,21 +382,6 @@ __device__ __forceinline__ void s2_store4(float* p, float x, float y, float z, f
     *reinterpret_cast<v4*>(p) = v;
   }
 }
-// Hand-off through memory between workgroups (the exchange bands' spill rows):
-// 16-byte write-through stores and L1-bypassing loads (`sc1`), coherent across
-// CUs and XCDs without cache maintenance (MI355X_MICROARCH.md, visibility).
-__device__ __forceinline__ void s2_store4_sc1(float4* p, float4 v) {
-  typedef float v4 __attribute__((ext_vector_type(4)));
-  const v4 t = {v.x, v.y, v.z, v.w};
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(t) : "memory");
-}
-__device__ __forceinline__ float4 s2_load4_sc1(const float4* p) {
-  typedef float v4 __attribute__((ext_vector_type(4)));
-  v4 t;
-  asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)"
-               : "=v"(t) : "v"(p) : "memory");
-  return make_float4(t.x, t.y, t.z, t.w);
-}
 struct Px { float4 d4, t0, t1, t2; };
 typedef float s2_f4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 s2_ld_nt(const float* p) {
@@ -448,37 +427,23 @@ __global__ __launch_bounds__(MAXT) void splat_stream2_kernel(S2Args a) {
   // touches them: floor(Y) in [row0 - 1, row0 + rows - 1]
   const int row0 = band * R;
   const int rows = min(R, Ht - row0);
-  // Exchange bands (compose instance; a.xch): a source row belongs to the band
-  // its footprint's upper row k = floor(Y) falls into; the lower row k + 1 of
-  // the band's last source rows is the NEXT band's first row: the tile has one
-  // more row for it (`rows_t`), published to that band through the workspace
-  // as soon as its last contribution is merged -- no source row is read (or
-  // projected) twice, and at s = 0.5 a band has 2 R source rows: a multiple of
-  // the wave count in units.  The first band also keeps k = -1 (the image's
-  // top row of footprints); the last band's spill leaves the image.
-  const bool XCH = !BOTH && a.xch != 0;
-  const bool has_out = XCH && (row0 + rows < Ht);
-  const int rows_t = rows + (has_out ? 1 : 0);
-  const int k_lo = (XCH && band > 0) ? row0 : row0 - 1, k_hi = row0 + rows - 1;
+  const int k_lo = row0 - 1, k_hi = row0 + rows - 1;
 
   // ---- LDS carve ---------------------------------------------------------
   const int WHS = ((WMAX / 2 + 15) & ~15) + 8;  // slots per window half
   const int WCELLS = 2 * WHS;
   float4* const rb_all = reinterpret_cast<float4*>(smem_raw);    // [NW][WCELLS]
   const int NT = BOTH ? a.L : 1;                                  // tiles
-  const int TR = R + (a.xch ? 1 : 0);                             // rows of a tile
-  float4* const tile4 = rb_all + NW * WCELLS;                     // [NT][TR][Wt]
-  Task* const task = reinterpret_cast<Task*>(tile4 + NT * TR * Wt);  // [cap]
+  float4* const tile4 = rb_all + NW * WCELLS;                     // [NT][R][Wt]
+  Task* const task = reinterpret_cast<Task*>(tile4 + NT * R * Wt);  // [cap]
   TaskX* const taskx = reinterpret_cast<TaskX*>(task + a.cap);    // [cap]
-  // ctl: [0] ticket, [1] table arrivals, [2] merged spill units, [3] spill
-  // units of the band, [4] spill row published, [5..7] spare
-  int* const ctl = reinterpret_cast<int*>(taskx + a.cap);         // [8]
-  int* const locks = ctl + 8;                                     // [NT * TR]
+  int* const ctl = reinterpret_cast<int*>(taskx + a.cap);         // [4]: ticket, table arrivals
+  int* const locks = ctl + 4;                                     // [NT * R]
   const int Q = a.qcap;
-  float4* const qv_all = reinterpret_cast<float4*>(ctl + ((8 + NT * TR + 3) & ~3));
+  float4* const qv_all = reinterpret_cast<float4*>(ctl + ((4 + NT * R + 3) & ~3));
   int* const qc_all = reinterpret_cast<int*>(qv_all + NW * Q);
   unsigned char* const sc_all = reinterpret_cast<unsigned char*>(qc_all + NW * Q);
-  int* const clk = reinterpret_cast<int*>(sc_all + ((NW * WMAX + 15) & ~15));  // CELL: [NT*TR*Wt]
+  int* const clk = reinterpret_cast<int*>(sc_all + ((NW * WMAX + 15) & ~15));  // CELL: [NT*R*Wt]
   const unsigned clk_addr = (unsigned)(uintptr_t)clk;
   float4* const rb = rb_all + wave * WCELLS;
   float4* const qv = qv_all + wave * Q;
@@ -569,9 +534,9 @@ __global__ __launch_bounds__(MAXT) void splat_stream2_kernel(S2Args a) {
   // ---- LDS init and the opening barrier: nothing here needs M ---------------
   {
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int ncl = BOTH ? NT * R * Wt : rows_t * Wt;
+    const int ncl = BOTH ? NT * R * Wt : rows * Wt;
     for (int i = tid; i < NW * WCELLS + ncl; i += T) rb_all[i] = z4;  // windows + tiles
-    for (int i = tid; i < 8 + NT * TR; i += T) ctl[i] = (i == 0) ? NW : 0;  // tickets, arrivals, locks
+    for (int i = tid; i < 4 + NT * R; i += T) ctl[i] = (i == 0) ? NW : 0;  // tickets, arrivals, locks
     if (CELL)
       for (int i = tid; i < ncl; i += T) clk[i] = 0;
   }
@@ -770,20 +735,12 @@ __global__ __launch_bounds__(MAXT) void splat_stream2_kernel(S2Args a) {
     }
   };
   // tickets [c0 + first, c0 + n): one ticket per thread
-  // (exchange bands) the spill row can be published as soon as the units that
-  // reach it are merged: counted while the table is filled -- if the table
-  // holds every ticket; else the row is published when the band is done
-  const bool early_ok = has_out && ntask <= CAPT;
-  auto spills = [&](const Task& ta) {
-    return early_ok && ta.row0 == rows - 1 && ta.wy1 != 0.0f;
-  };
   auto fill_table = [&](const int c0, const int first, const int n) {
     for (int sl = first + tid; sl < n; sl += T) {
       Task ta; TaskX tx;
       make_task(c0 + sl, ta, tx);
       task[sl] = ta;
       taskx[sl] = tx;
-      if (spills(ta)) atomicAdd(&ctl[3], 1);
     }
   };
   // The wave's own table entry, its share of the other tickets, and "arrived":
@@ -793,10 +750,7 @@ __global__ __launch_bounds__(MAXT) void splat_stream2_kernel(S2Args a) {
     if (wave < nchunk) {
       Task ta; TaskX tx;
       make_task(wave, ta, tx);
-      if (lane == 0) {
-        task[wave] = ta; taskx[wave] = tx;
-        if (spills(ta)) atomicAdd(&ctl[3], 1);
-      }
+      if (lane == 0) { task[wave] = ta; taskx[wave] = tx; }
     }
     fill_table(0, NW, nchunk);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -817,6 +771,12 @@ __global__ __launch_bounds__(MAXT) void splat_stream2_kernel(S2Args a) {
   float qb[4] = {0.f, 0.f, 0.f, 0.f};
   bool lane_dead = false;   // this lane's pixels of the current unit are past the row end
   int qn = 0;
+#ifdef S2X_STAMPS
+  unsigned route_n[4] = {0u, 0u, 0u, 0u};  // items by route: A, B, B' (folded), C (general)
+#define S2_ROUTE(k) (route_n[k] += 1u)
+#else
+#define S2_ROUTE(k)
+#endif
   // merge: the lane's window slots (cells lane, lane + 64, ...)
   const int mslot = (lane >> 1) + (lane & 1) * WHS;
 
@@ -861,25 +821,9 @@ __global__ __launch_bounds__(MAXT) void splat_stream2_kernel(S2Args a) {
     for (int k = 0; k < 4; ++k) {
       const int r = t_row0 + (k >> 1);
       const float c = ((k & 1) ? wx[1] : wx[0]) * ((k >> 1) ? wy[1] : wy[0]);
-      const bool ok = pred && (c > 1.0e-3f) && r >= 0 && r < rows_t;
+      const bool ok = pred && (c > 1.0e-3f) && r >= 0 && r < rows;
       push(ok, (t_lay + r) * Wt + ((k & 1) ? cx[1] : cx[0]),
            make_float4(V.x * c, V.y * c, V.z * c, V.w * c));
-    }
-  };
-
-  // (exchange bands) tile row `rows` -> the lower neighbour's slot of the
-  // workspace, by the calling wave (first = lane, step = 64) or by the whole
-  // workgroup (tid, T); the flag follows the acknowledged stores
-  const int xslot = b * (int)gridDim.x + band;
-  auto publish_spill = [&](const int first, const int step) {
-    float4* const dst = a.xrow + (size_t)(xslot + 1) * Wt;
-    const float4* const src = tile4 + (size_t)rows * Wt;
-    for (int c = first; c < Wt; c += step) s2_store4_sc1(dst + c, src[c]);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (step != 64) __syncthreads();
-    if (first == 0) {
-      __hip_atomic_store(&a.xflag[xslot + 1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      ctl[4] = 1;
     }
   };
 
@@ -909,15 +853,15 @@ __global__ __launch_bounds__(MAXT) void splat_stream2_kernel(S2Args a) {
       wymax = fmaxf(wy0, wy1);
       wlo_f = (float)t_wlo;
       const int rmax = t_row0 + ((wy1 > wy0) ? 1 : 0);
-      has_max = S2_RFL(((wymax != wymin) && rmax >= 0 && rmax < rows_t) ? 1 : 0);
+      has_max = S2_RFL(((wymax != wymin) && rmax >= 0 && rmax < rows) ? 1 : 0);
       rmax_row = S2_RFL(rmax);
       wspan = (unsigned)max(t_wwin - 2, 0);
       win_ok = t_wwin >= 2 ? 1 : 0;
       wspanA = (unsigned)max(t_wwin - 4, 0);
       fast_ok = S2_RFL((win_ok && tmin <= 0.5f) ? 1 : 0);
       fastA_ok = S2_RFL((t_wwin >= 4 && tmin <= 0.5f) ? 1 : 0);
-      use_a = S2_RFL((wy0 != 0.f && t_row0 >= 0 && t_row0 < rows_t) ? 1 : 0);
-      use_b = S2_RFL((wy1 != 0.f && t_row0 + 1 >= 0 && t_row0 + 1 < rows_t) ? 1 : 0);
+      use_a = S2_RFL((wy0 != 0.f && t_row0 >= 0 && t_row0 < rows) ? 1 : 0);
+      use_b = S2_RFL((wy1 != 0.f && t_row0 + 1 >= 0 && t_row0 + 1 < rows) ? 1 : 0);
     }
     float x0v[4], w0v[4], w1v[4];
     float4 Vv[4];  // route A: the lane's 4 cell sums; else V of its 4 pixels
@@ -1052,6 +996,7 @@ __global__ __launch_bounds__(MAXT) void splat_stream2_kernel(S2Args a) {
     const int next_tag = issue(cur);  // the set takes the item NSETS ahead
     if (live) {
       if (routeA) {
+        S2_ROUTE(0);
         const int par = cl0 & 1, hlf = cl0 >> 1;
         float4* ce = rb + hlf + par * WHS;              // cell cl0 (and cl0 + 2)
         float4* co = rb + hlf + par + (1 - par) * WHS;  // cell cl0 + 1 (and + 3)
@@ -1088,6 +1033,7 @@ __global__ __launch_bounds__(MAXT) void splat_stream2_kernel(S2Args a) {
         }
         if (S2_RFL((inwin == ~0ull && fast_ok) ? 1 : 0)) {
           const bool fold = regular != ~0ull;
+          S2_ROUTE(fold ? 2 : 1);
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             float w0 = w0v[i], w1 = w1v[i];
@@ -1131,6 +1077,7 @@ __global__ __launch_bounds__(MAXT) void splat_stream2_kernel(S2Args a) {
             }
           }
         } else {
+        S2_ROUTE(3);
         // ---- per pixel (one copy of the code; the pixel's values are
         // selected).  In-window lanes whose cells are distinct add directly;
         // folded fields elect the lanes of a cell one at a time through a byte
@@ -1268,14 +1215,6 @@ __global__ __launch_bounds__(MAXT) void splat_stream2_kernel(S2Args a) {
           if (use_a) s2_unlock_row(locks, t_lay + t_row0, lane);
 #endif
         }
-        // (exchange bands) the band's last contribution to the row it spills
-        // into its lower neighbour: this wave hands the row over
-        if (!BOTH && early_ok && use_b && t_row0 + 1 == rows) {
-          table_ready();  // (ctl[3] is final once every wave has filled its share)
-          int cnt = 0;
-          if (lane == 0) cnt = atomicAdd(&ctl[2], 1) + 1;
-          if (S2_RFL(cnt) == S2_RFL(ctl[3])) publish_spill(lane, 64);
-        }
       }
       if (BOTH) t_lay += R;  // the unit's next item is its next layer
     }
@@ -1301,86 +1240,9 @@ __global__ __launch_bounds__(MAXT) void splat_stream2_kernel(S2Args a) {
     ld_done = 0;
     __syncthreads();
   }
-  // (exchange bands) the first wave that runs out of work takes the upper
-  // neighbour's spill row -- published long ago unless that band is far behind
-  // -- into this band's first row, under the row's lock, while the other waves
-  // finish their units: off the critical path.  Not there after a few polls:
-  // left to the whole workgroup behind the closing barrier.
-  if (XCH && !CELL && band > 0) {
-    int mine = 0;
-    if (lane == 0) mine = atomicCAS(&ctl[5], 0, 1) == 0 ? 1 : 0;
-    if (S2_RFL(mine)) {
-      int* const flag = a.xflag + xslot;
-      int there = 0;
-      if (lane == 0) {
-        for (int spins = 0; spins < 48; ++spins) {
-          if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-            there = 1;
-            break;
-          }
-          __builtin_amdgcn_s_sleep(16);
-        }
-      }
-      if (S2_RFL(there)) {
-        typedef float v4 __attribute__((ext_vector_type(4)));
-        const float4* const srcr = a.xrow + (size_t)xslot * Wt;
-        s2_lock_row(locks, 0, lane);
-        for (int c0 = 0; c0 < Wt; c0 += 4 * 64) {  // four loads in flight per lane
-          v4 v[4];
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const int c = min(c0 + 64 * k + lane, Wt - 1);
-            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v[k]) : "v"(srcr + c) : "memory");
-          }
-          asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]) : : "memory");
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const int c = c0 + 64 * k + lane;
-            if (c < Wt) {
-              float4 t = tile4[c];
-              t.x += v[k].x; t.y += v[k].y; t.z += v[k].z; t.w += v[k].w;
-              tile4[c] = t;
-            }
-          }
-        }
-        s2_unlock_row(locks, 0, lane);
-        if (lane == 0) {
-          __hip_atomic_store(flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          ctl[6] = 1;
-        }
-      }
-    }
-  }
   S2_STAMP(4);
   __syncthreads();  // every window is merged: the tile is complete
   S2_STAMP(5);
-  if (XCH) {
-    if (has_out && ctl[4] == 0) publish_spill(tid, T);  // (not handed over early)
-    if (band > 0 && ctl[6] == 0) {
-      // the upper neighbour's spill into this band's first row: published when
-      // that band merged its last two source rows -- normally long ago
-      int* const flag = a.xflag + xslot;
-      if (tid == 0) {
-        int spins = 0;
-        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 &&
-               ++spins < (1 << 22))
-          __builtin_amdgcn_s_sleep(8);
-      }
-      __syncthreads();
-      const float4* const srcr = a.xrow + (size_t)xslot * Wt;
-      for (int c = tid; c < Wt; c += T) {
-        const float4 v = s2_load4_sc1(srcr + c);
-        float4 t = tile4[c];
-        t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
-        tile4[c] = t;
-      }
-      // left zero for the next launch (this band is the flag's only reader)
-      if (tid == 0)
-        __hip_atomic_store(flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __syncthreads();
-    }
-  }
-
   // ---- epilogue: (tile + background) normalised, each output written once --
   // (a.ep: 0 scalar stores; 1 / 2 / 3 four cells per lane, plain / write-through
   // / non-temporal; 4 / 5 whole lines per store instruction, plain / non-temporal)
@@ -1623,16 +1485,22 @@ __global__ __launch_bounds__(MAXT) void splat_stream2_kernel(S2Args a) {
     }
   }
   S2_STAMP(6);
+#ifdef S2X_STAMPS
+  if (stamp && lane == 0)  // slot 7: the wave's items by route, 16 bits each
+    stamp[7] = (long long)((unsigned long long)min(route_n[0], 65535u) |
+                           ((unsigned long long)min(route_n[1], 65535u) << 16) |
+                           ((unsigned long long)min(route_n[2], 65535u) << 32) |
+                           ((unsigned long long)min(route_n[3], 65535u) << 48));
+#endif
 }
 
 size_t s2_lds_bytes(int R, int Wt, int nw, int wmax, int cap, int qcap, int cell,
-                    int nt = 1, int xch = 0) {
+                    int nt = 1) {
   const int whs = ((wmax / 2 + 15) & ~15) + 8;
-  const int tr = R + (xch ? 1 : 0);
-  return (size_t)nw * 2 * whs * 16 + (size_t)nt * tr * Wt * 16 +
+  return (size_t)nw * 2 * whs * 16 + (size_t)nt * R * Wt * 16 +
          (size_t)cap * (sizeof(Task) + sizeof(TaskX)) +
-         (size_t)((8 + nt * tr + 3) & ~3) * 4 + (size_t)nw * qcap * 20 +
-         (size_t)((nw * wmax + 15) & ~15) + (cell ? (size_t)nt * tr * Wt * 4 : 0) + 16;
+         (size_t)((4 + nt * R + 3) & ~3) * 4 + (size_t)nw * qcap * 20 +
+         (size_t)((nw * wmax + 15) & ~15) + (cell ? (size_t)nt * R * Wt * 4 : 0) + 16;
 }
 
 struct S2Plan { int R, nw, cell, cap, qcap, ilv, hf, nsplit, lsub; size_t lds; double est; };
@@ -1645,20 +1513,18 @@ struct S2Plan { int R, nw, cell, cap, qcap, ilv, hf, nsplit, lsub; size_t lds; d
 // apart) and whole rounds of workgroups: so one workgroup per CU (the LDS tile
 // allows only one) in ONE round, as many waves as fit, the tallest band that
 // still gives every CU a workgroup.
-int s2_plan_search(const LsiSplatDesc* d, int wmax, int maxnw, bool both, int xch,
-                   S2Plan* out);
+int s2_plan_search(const LsiSplatDesc* d, int wmax, int maxnw, bool both, S2Plan* out);
 
 // The plan depends on the call's geometry only: remembered per geometry, so
 // that an eager caller (one launch per Python call) does not pay the search
 // again (~80 candidate plans) on every launch.
-int s2_plan(const LsiSplatDesc* d, int wmax, int maxnw, bool both, int xch, S2Plan* out) {
+int s2_plan(const LsiSplatDesc* d, int wmax, int maxnw, bool both, S2Plan* out) {
   struct Key { int v[14]; };
   struct Entry { Key k; S2Plan p; };
   static std::mutex mu;
   static std::vector<Entry> memo;
   Key k;
-  const int kv[14] = {d->L, d->B, d->H, d->W, d->Ht, d->Wt, wmax, maxnw,
-                      (both ? 1 : 0) | (xch ? 2 : 0),
+  const int kv[14] = {d->L, d->B, d->H, d->W, d->Ht, d->Wt, wmax, maxnw, both ? 1 : 0,
                       d->tune_rows, d->tune_threads, d->reserved, 0,
                       d->tune_window & LSI_STREAM_FLAG_BITS};
   memcpy(k.v, kv, sizeof(kv));
@@ -1668,7 +1534,7 @@ int s2_plan(const LsiSplatDesc* d, int wmax, int maxnw, bool both, int xch, S2Pl
     for (const Entry& e : memo)
       if (memcmp(e.k.v, k.v, sizeof(k.v)) == 0) { *out = e.p; return LSI_OK; }
   }
-  const int rc = s2_plan_search(d, wmax, maxnw, both, xch, out);
+  const int rc = s2_plan_search(d, wmax, maxnw, both, out);
   if (rc == LSI_OK) {
     std::lock_guard<std::mutex> g(mu);
     if (memo.size() >= 64) memo.erase(memo.begin());
@@ -1677,8 +1543,7 @@ int s2_plan(const LsiSplatDesc* d, int wmax, int maxnw, bool both, int xch, S2Pl
   return rc;
 }
 
-int s2_plan_search(const LsiSplatDesc* d, int wmax, int maxnw, bool both, int xch,
-                   S2Plan* out) {
+int s2_plan_search(const LsiSplatDesc* d, int wmax, int maxnw, bool both, S2Plan* out) {
   const int nt = both ? d->L : 1;
   const int nseg = (d->W + SEG - 1) / SEG;
   static const char* cap_env = getenv("LSI_STREAM_LDS_CAP");
@@ -1725,9 +1590,9 @@ int s2_plan_search(const LsiSplatDesc* d, int wmax, int maxnw, bool both, int xc
       if (d->tune_threads <= 0 && c > tickets && c > 2) continue;
       const int cap = (tickets + 15) / 16 * 16;
       int q = 64;
-      while (q >= 16 && s2_lds_bytes(R, d->Wt, c, wmax, cap, q, cell, nt, xch) > lds_cap) q /= 2;
+      while (q >= 16 && s2_lds_bytes(R, d->Wt, c, wmax, cap, q, cell, nt) > lds_cap) q /= 2;
       if (q < 16) continue;
-      const size_t lds = s2_lds_bytes(R, d->Wt, c, wmax, cap, q, cell, nt, xch);
+      const size_t lds = s2_lds_bytes(R, d->Wt, c, wmax, cap, q, cell, nt);
       long k = (long)(160 * 1024 / lds);          // co-resident workgroups per CU
       if (k > maxnw / c) k = maxnw / c;
       if (k < 1) k = 1;
@@ -1736,12 +1601,10 @@ int s2_plan_search(const LsiSplatDesc* d, int wmax, int maxnw, bool both, int xc
       const double conc = fmin((double)nwg, slots);   // workgroups running together
       // microseconds: streaming share of the chip (a CU alone cannot pull more
       // than ~CU_GBPS), or the waves' own latency chains (2 items in flight)
-      // (exchange bands read R / s source rows, halo bands (R + 1) / s)
-      const double rd_rows = xch ? (double)R / d->trg_downsampling : (double)srows;
-      const double bytes = rd_rows * nseg * d->L * 4096.0;
+      const double bytes = (double)srows * nseg * d->L * 4096.0;
       const double gbps = fmin(CU_GBPS / (double)k, CHIP_GBPS / conc);
       const double t_stream = bytes / (gbps * 1e3);
-      const double t_lat = ceil((xch ? rd_rows * nseg : (double)nunit) * d->L / c) * 1.1;
+      const double t_lat = ceil((double)nunit * d->L / c) * 1.1;
       const double t_wg = 3.0 + fmax(t_stream, t_lat) + 0.5 +
                           (double)R * d->Wt / (c * 64.0) * 0.02;
       const double est = rounds * t_wg + (nwg < (long)NCU ? 0.0 : 0.0);
@@ -1758,9 +1621,9 @@ int s2_plan_search(const LsiSplatDesc* d, int wmax, int maxnw, bool both, int xc
   static const bool verbose = getenv("LSI_STREAM_VERBOSE") != nullptr;
   if (verbose)
     fprintf(stderr, "lsi stream2 plan: R=%d waves=%d %s-locks table=%d queue=%d "
-            "interleave=%d split=%dx%d est=%.1f us lds=%zu%s\n", best.R, best.nw,
+            "interleave=%d split=%dx%d est=%.1f us lds=%zu\n", best.R, best.nw,
             best.cell ? "cell" : "row", best.cap, best.qcap, best.ilv,
-            best.nsplit, best.lsub, best.est, best.lds, xch ? " exchange-bands" : "");
+            best.nsplit, best.lsub, best.est, best.lds);
   return LSI_OK;
 }
 
@@ -1801,43 +1664,7 @@ int lsi_stream2_launch(const SplatArgs& a, int wmax, hipStream_t stream,
   S2Plan plan;
   // (one tile per layer: both outputs, the disparity pass, per-layer outputs alone)
   const bool both = disp_pass || a.out_img_c != nullptr || !(d->flags & LSI_COMPOSE);
-  // Exchange bands (composed view): every workgroup of the launch must be
-  // resident -- a band waits for its upper neighbour's spill row --, and the
-  // workspace must hold the flags and one row per band.
-  int xch = 0;
-  size_t xrow_off = 0;
-  {
-    static const char* x_env = getenv("LSI_S2_XCH");  // experiments: 0 = halo bands
-    static int ncu = 0;
-    static const char* ncu_env = getenv("LSI_S2_NCU");  // (dry runs without a device)
-    if (ncu == 0 && ncu_env) ncu = atoi(ncu_env);
-    if (ncu == 0) {
-      int dev = 0, n = 0;
-      if (hipGetDevice(&dev) == hipSuccess &&
-          hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess)
-        ncu = n > 0 ? n : -1;
-      else
-        ncu = -1;
-    }
-    if (!both && (x_env ? atoi(x_env) : 1) && a.canvas && ncu > 0 &&
-        ((uintptr_t)a.canvas & 15) == 0 &&
-        s2_plan(d, wmax, LSI_S2_MAXT / 64, both, 1, &plan) == LSI_OK) {
-      const long nb = (d->Ht + plan.R - 1) / plan.R;
-      const long k = (long)(160 * 1024 / plan.lds) > 0 ? (long)(160 * 1024 / plan.lds) : 1;
-      xrow_off = lsi_stream_ws_rows_offset(d);
-      if (nb * d->B <= (long)ncu * k && nb * d->B * (long)sizeof(int) <= (long)xrow_off &&
-          a.ws_bytes >= xrow_off + (size_t)nb * d->B * d->Wt * 16 +
-                            ((d->reserved & 4) ? (size_t)nb * d->B * 16 * 8 * 8 : 0))
-        xch = 1;
-    }
-  }
-  if (!xch && s2_plan(d, wmax, LSI_S2_MAXT / 64, both, 0, &plan) != LSI_OK)
-    return LSI_EINVAL;
-  // the flags must be zero when the launch starts (and are left zero): cleared
-  // here unless the caller promises a kept workspace (lsi_hip.h, LSI_WS_KEEP)
-  if (xch && !(d->flags & LSI_WS_KEEP) &&
-      hipMemsetAsync(a.canvas, 0, xrow_off, stream) != hipSuccess)
-    return LSI_ELAUNCH;
+  if (s2_plan(d, wmax, LSI_S2_MAXT / 64, both, &plan) != LSI_OK) return LSI_EINVAL;
   S2Args k;
   k.tex = a.tex; k.disp = a.disp; k.M = a.M;
   k.out_img = a.out_img; k.out_wts = a.out_wts;
@@ -1858,10 +1685,6 @@ int lsi_stream2_launch(const SplatArgs& a, int wmax, hipStream_t stream,
   k.R = plan.R; k.wmax = wmax; k.qcap = plan.qcap; k.cap = plan.cap;
   k.ilv = plan.ilv;
   k.hf = plan.hf;
-  k.xch = xch;
-  k.xflag = xch ? reinterpret_cast<int*>(a.canvas) : nullptr;
-  k.xrow = xch ? reinterpret_cast<float4*>(reinterpret_cast<char*>(a.canvas) + xrow_off)
-               : nullptr;
   {
     static const char* ep_env = getenv("LSI_S2_EPILOGUE");
     // 5: whole 128-byte lines per store instruction, non-temporal.  Measured at
@@ -1883,7 +1706,7 @@ int lsi_stream2_launch(const SplatArgs& a, int wmax, hipStream_t stream,
   k.inv_nseg = 1.0f / (float)k.nseg;
   k.stamps = nullptr;
 #ifdef S2X_STAMPS
-  // (the last bytes of the workspace: the exchange bands use its start)
+  // (the last bytes of the workspace)
   if ((d->reserved & 4) && a.canvas &&
       a.ws_bytes >= (size_t)nbands * d->B * 16 * 8 * 8)
     k.stamps = reinterpret_cast<long long*>(

@@ -1,0 +1,122 @@
+"""torch.autograd binding of the MFMA 3x3 convolution over 32 input channels
+(csrc/lsi_conv.hip; include/lsi_hip.h: lsi_conv3x3_c32_fwd) -- the
+full-resolution layers of the LDI heads (reference nets.py:104-111, 150-158)
+on bf16 channels-last activations.
+
+  conv3x3_c32(x, weight)            32 -> 16 | 32 channels, bf16 out (pre batch norm)
+  conv3x3_c32_sigmoid(x, weight, bias)   32 -> <= 4 channels, bias + sigmoid, fp32 RGBD pixels
+
+Forward and the data gradient of the 32 -> 32 layer run on the hand-written
+kernel (the data gradient of a stride-1 SAME convolution is the same
+convolution with the weights flipped and transposed); weight / bias gradients
+(reductions over all pixels) and the data gradient of the thin prediction layer
+go through aten.convolution_backward (MIOpen).
+"""
+import torch
+
+from lsi import _C
+
+
+def supported(x, cin, cout, k, stride, pred):
+  """bf16 channels-last activations on the GPU, 3x3 stride 1, 32 input
+  channels, widths that are multiples of 16 pixels."""
+  if not (x.is_cuda and x.dim() == 4 and x.dtype == torch.bfloat16):
+    return False
+  if k != 3 or stride != 1 or cin != 32 or x.shape[1] != 32 or x.shape[3] % 16:
+    return False
+  if pred:
+    if not 1 <= cout <= 4:
+      return False
+  elif cout not in (16, 32):
+    return False
+  return (x.is_contiguous(memory_format=torch.channels_last) and
+          x.data_ptr() % 16 == 0)
+
+
+def _launch(x, weight, cout, mode, bias=None):
+  """mode 0: 32 -> cout, bf16 out; 1: prediction head (bias, sigmoid, fp32 RGBD
+  pixels); 2: data gradient of the 32 -> 32 layer.  `weight`: the layer's
+  parameter (cout x 32 x 3 x 3); the kernel reads it as fp32 and rounds to bf16
+  itself -- no packing or casting launches."""
+  n, _, h, w = x.shape
+  dev = x.device
+  weight = weight.detach()
+  if weight.dtype != torch.float32 or not weight.is_contiguous():
+    weight = weight.float().contiguous()
+  if mode == 1:
+    out = torch.empty((n, 4, h, w), dtype=torch.float32, device=dev,
+                      memory_format=torch.channels_last)
+  else:
+    out = torch.empty((n, cout, h, w), dtype=torch.bfloat16, device=dev,
+                      memory_format=torch.channels_last)
+  rc = _C.lib().lsi_conv3x3_c32_fwd(n, h, w, cout, mode, _C.ptr(x), _C.ptr(weight),
+                                    _C.ptr(bias), 1.0, _C.ptr(out),
+                                    _C.stream_ptr(dev))
+  _C.check(rc, 'lsi_conv3x3_c32_fwd')
+  return out
+
+
+class _Conv3x3C32(torch.autograd.Function):
+  """32 -> cout (16 | 32) channels, no bias, bf16 out."""
+
+  @staticmethod
+  def forward(ctx, x, weight):
+    ctx.save_for_backward(x, weight)
+    return _launch(x, weight, weight.shape[0], 0)
+
+  @staticmethod
+  def backward(ctx, g):
+    x, weight = ctx.saved_tensors
+    g = g.contiguous(memory_format=torch.channels_last)
+    gx = gw = None
+    cout = weight.shape[0]
+    if ctx.needs_input_grad[0]:
+      if cout == 32 and g.dtype == torch.bfloat16 and g.data_ptr() % 16 == 0:
+        # dL/dx = conv(g, W flipped in space, transposed in channels): mode 2
+        gx = _launch(g, weight, 32, 2)
+      else:
+        gx = torch.ops.aten.convolution_backward(
+            g, x, weight.to(g.dtype), None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+            [True, False, False])[0]
+    if ctx.needs_input_grad[1]:
+      gw = torch.ops.aten.convolution_backward(
+          g, x, weight.to(g.dtype), None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+          [False, True, False])[1].to(weight.dtype)
+    return gx, gw
+
+
+class _Conv3x3C32Sigmoid(torch.autograd.Function):
+  """32 -> cout (<= 4) channels + bias + sigmoid, fp32 out N x 4 x H x W
+  (channels last: RGBD pixels; channels past cout hold sigmoid(0))."""
+
+  @staticmethod
+  def forward(ctx, x, weight, bias):
+    cout = weight.shape[0]
+    y = _launch(x, weight, cout, 1,
+                None if bias is None else bias.detach().float().contiguous())
+    ctx.save_for_backward(x, weight, y)
+    ctx.has_bias = bias is not None
+    return y[:, :cout] if cout < 4 else y
+
+  @staticmethod
+  def backward(ctx, g):
+    x, weight, y = ctx.saved_tensors
+    cout = weight.shape[0]
+    ys = y[:, :cout]
+    gz = (g * ys * (1.0 - ys)).to(torch.bfloat16).contiguous(
+        memory_format=torch.channels_last)
+    mask = [ctx.needs_input_grad[0], ctx.needs_input_grad[1],
+            ctx.has_bias and ctx.needs_input_grad[2]]
+    gx, gw, gb = torch.ops.aten.convolution_backward(
+        gz, x, weight.to(torch.bfloat16), [cout] if ctx.has_bias else None, [1, 1],
+        [1, 1], [1, 1], False, [0, 0], 1, mask)
+    return (gx, None if gw is None else gw.to(weight.dtype),
+            None if gb is None else gb.to(weight.dtype))
+
+
+def conv3x3_c32(x, weight):
+  return _Conv3x3C32.apply(x, weight)
+
+
+def conv3x3_c32_sigmoid(x, weight, bias):
+  return _Conv3x3C32Sigmoid.apply(x, weight, bias)

@@ -41,6 +41,10 @@ def _same_pad(n, k, stride):
 # symmetric SAME padding inside the convolution (see SlimConv2d);
 # LSI_IMPLICIT_PAD=0 pads explicitly
 IMPLICIT_PAD = os.environ.get('LSI_IMPLICIT_PAD', '1') != '0'
+# The 3x3 convolutions over 32 channels at full resolution (`upcnv1b`, `pred_l`
+# of every LDI layer) on the hand-written MFMA kernel (csrc/lsi_conv.hip) when
+# the activations are bf16 channels-last on the GPU; LSI_MFMA_CONV=0: MIOpen
+MFMA_CONV = os.environ.get('LSI_MFMA_CONV', '1') != '0'
 # bf16 batch norm on large maps under autocast (LSI_BF16_BN=0 restores fp32)
 BF16_BATCH_NORM = os.environ.get('LSI_BF16_BN', '1') != '0'
 # batch norm + ReLU of the conv layers as the fused HIP kernels (csrc/lsi_bn.hip)
@@ -155,6 +159,18 @@ class SlimConv2d(nn.Module):
     self.activation = activation
 
   def forward(self, x):
+    if MFMA_CONV and x.is_cuda and x.dtype == torch.bfloat16:
+      from lsi.nnutils import _hip_conv  # pylint: disable=g-import-not-at-top
+      cout, cin = self.conv.weight.shape[:2]
+      head = self.bn is None and self.activation == 'sigmoid'
+      if (head or self.bn is not None) and _hip_conv.supported(
+          x, cin, cout, self.k, self.stride, head):
+        if head:    # bias + sigmoid inside the kernel, fp32 RGBD pixels out
+          return _hip_conv.conv3x3_c32_sigmoid(x, self.conv.weight, self.conv.bias)
+        x = _hip_conv.conv3x3_c32(x, self.conv.weight)
+        if self.activation == 'relu':
+          return _bn_relu(self.bn, x)
+        return self.bn(x)
     ph = _same_pad(x.shape[2], self.k, self.stride)
     pw = _same_pad(x.shape[3], self.k, self.stride)
     # Symmetric SAME padding (the stride-1 layers) goes into the convolution:

@@ -127,31 +127,11 @@ def test_kitti_configs_disparity_output_and_backward_full_size(workload, batch, 
   del out
   kw = dict(trg_downsampling=0.5, bg_layer_disp=bg, max_disp=md, zbuf_scale=ZB)
   pred = torch.cat([tex, disp], dim=-1)
-  grads = {}
-  for stream in ('1', '0'):
-    monkeypatch.setenv('LSI_BWD_STREAM', stream)
-    p = pred.to(dev).requires_grad_(True)
-    img, wts, img_c, wts_c = ldi.forward_splat_both(
-        [p[..., 0:3], None, p[..., 3:4]], mat, **kw)
-    if stream == '1':
-      per_layer = ref_cpu.forward_splat(tex.numpy(), None, disp.numpy(), mat.numpy(),
-                                        0.5, bg, md, ZB, False, want_disp=False)
-      _check((img.detach(), wts.detach()), per_layer, False)
-      _check((img_c.detach(), wts_c.detach()), want, False)
-    g = torch.Generator().manual_seed(3)
-    ci = torch.rand(img.shape, generator=g).to(dev)
-    cc = torch.rand(img_c.shape, generator=g).to(dev)
-    ((img * ci).sum() + (img_c * cc).sum() + 1e-3 * torch.log(wts_c).sum()).backward()
-    grads[stream] = p.grad.cpu().double().numpy()
-    del p, img, wts, img_c, wts_c
-  scale = np.abs(grads['0']).max() + 1e-30
-  assert np.abs(grads['1'] - grads['0']).max() <= 2e-5 * scale
-  # (4) both kernels against fp64 autograd of the reference's op graph
-  # (oracle/lsi_torch_ref.py) on whole batch elements -- the first, one in the
-  # middle and the last: 3 x L x 196 608 source pixels (2.4 M at config 3);
-  # batch elements are independent, so the oracle needs only their data.  The
-  # bar is stated on each kernel's own distance from fp64, not on their
-  # distance from each other.
+  # fp64 autograd of the reference's op graph (oracle/lsi_torch_ref.py) on whole
+  # batch elements -- the first, one in the middle and the last: 3 x L x 196 608
+  # source pixels (2.4 M at config 3); batch elements are independent, so the
+  # oracle needs only their data.
+  import lsi_oracle as O
   import lsi_torch_ref as TR
   sel = sorted({0, batch // 2, batch - 1})
   t64 = tex[:, sel].double().requires_grad_(True)
@@ -166,10 +146,35 @@ def test_kitti_configs_disparity_output_and_backward_full_size(workload, batch, 
   ((img_l * ci[:, sel].double()).sum() + (img_k * cc[:, sel].double()).sum() +
    1e-3 * torch.log(wts_k).sum()).backward()
   ref = torch.cat([t64.grad, d64.grad], dim=-1).numpy()
+  exact = [t.detach().float() for t in (img_l, wts_l, img_k, wts_k)]
+  grads = {}
+  # `own`: the backward kernels read the outputs the fp32 forward produced (what
+  # training does); `exact`: those of the selected elements replaced by the
+  # oracle's, rounded once to fp32 -- the backward arithmetic alone
+  for feed in ('own', 'exact'):
+    for stream in ('1', '0'):
+      monkeypatch.setenv('LSI_BWD_STREAM', stream)
+      p = pred.to(dev).requires_grad_(True)
+      outs = ldi.forward_splat_both([p[..., 0:3], None, p[..., 3:4]], mat, **kw)
+      img, wts, img_c, wts_c = outs
+      if feed == 'own' and stream == '1':
+        per_layer = ref_cpu.forward_splat(tex.numpy(), None, disp.numpy(), mat.numpy(),
+                                          0.5, bg, md, ZB, False, want_disp=False)
+        _check((img.detach(), wts.detach()), per_layer, False)
+        _check((img_c.detach(), wts_c.detach()), want, False)
+      if feed == 'exact':
+        for o, e in zip(outs, exact):
+          o.data[:, sel] = e.to(dev)
+      ((img * ci.to(dev)).sum() + (img_c * cc.to(dev)).sum() +
+       1e-3 * torch.log(wts_c).sum()).backward()
+      grads[feed, stream] = p.grad.cpu().double().numpy()
+      del p, img, wts, img_c, wts_c, outs
+  # (3) streamed against gather kernel, everywhere
+  scale = np.abs(grads['own', '0']).max() + 1e-30
+  assert np.abs(grads['own', '1'] - grads['own', '0']).max() <= 2e-5 * scale
+  # (4) each kernel against fp64, where a pixel's floor / clamp / clip decisions
+  # are the same in fp32 and fp64 (lsi_oracle.decisions_are_robust)
   scale64 = np.abs(ref).max() + 1e-30
-  # (compared where a pixel's floor / clamp / clip decisions are the same in
-  # fp32 and fp64: lsi_oracle.decisions_are_robust)
-  import lsi_oracle as O
   h, w = tex.shape[2:4]
   firm = np.stack([O.decisions_are_robust(mat[sel].numpy(), disp[l, sel, :, :, 0].numpy(),
                                           0.5, h // 2, w // 2, md)
@@ -177,7 +182,16 @@ def test_kitti_configs_disparity_output_and_backward_full_size(workload, batch, 
   assert firm.mean() > 0.95
   err = {k: float((np.abs(v[:, sel] - ref) * firm).max() / scale64)
          for k, v in grads.items()}
-  print('backward vs fp64 autograd, %s, %d source pixels: streamed %.2e, gather %.2e '
-        '(of the largest gradient entry)' % (workload, ref[..., 0].size, err['1'],
-                                             err['0']))
-  assert err['1'] <= 2e-5 and err['0'] <= 2e-5, err
+  print('backward vs fp64 autograd, %s, %d source pixels (of the largest gradient '
+        'entry): fed the exact forward outputs streamed %.2e gather %.2e; fed their '
+        'own fp32 forward outputs streamed %.2e gather %.2e' % (
+            workload, ref[..., 0].size, err['exact', '1'], err['exact', '0'],
+            err['own', '1'], err['own', '0']))
+  # the backward arithmetic: 2e-5; with the fp32 forward's outputs (weights
+  # 1e-4 relative, RGB 2e-5 absolute: the forward's own bars) the disparity
+  # gradient -- a difference of nearly equal corner terms times M[0][3] * s =
+  # 118 -- amplifies their error: bounded at 1e-2 of the largest entry
+  assert err['exact', '1'] <= 2e-5 and err['exact', '0'] <= 2e-5, err
+  assert err['own', '1'] <= 1e-2 and err['own', '0'] <= 1e-2, err
+
+

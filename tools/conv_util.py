@@ -21,7 +21,7 @@ import torch.nn.functional as F
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'layered-scene-inference_amd'))
 import ldi_enc_dec as script
-from lsi.nnutils import nets
+from lsi.nnutils import nets, _hip_conv
 
 PEAK = {True: 2.5e15, False: 157.3e12}
 
@@ -103,13 +103,34 @@ def main():
     tfb = bench(fb)
     tb = max(tfb - tf, 1e-9)
     bflops = flops * (2.0 if idx > 0 else 1.0)
-    rows.append({
+    # the hand-written MFMA kernel (csrc/lsi_conv.hip) where it applies
+    own = {}
+    head = isinstance(mod, nets.SlimConv2d) and mod.bn is None and mod.activation == 'sigmoid'
+    if (not transposed and bf16 and
+        _hip_conv.supported(x.detach(), cin, cout, k, getattr(mod, 'stride', 1), head)):
+      xd = x.detach()
+      if head:
+        bias = torch.zeros(cout, device=dev)
+        t_own = bench(lambda: _hip_conv.conv3x3_c32_sigmoid(xd, w.detach(), bias))
+      else:
+        t_own = bench(lambda: _hip_conv.conv3x3_c32(xd, w.detach()))
+      xg = x.detach().requires_grad_(True)
+      def fb_own():
+        yy = (_hip_conv.conv3x3_c32_sigmoid(xg, w, bias) if head
+              else _hip_conv.conv3x3_c32(xg, w))
+        yy.backward(g.to(yy.dtype))
+        xg.grad = None; w.grad = None
+      t_own_fb = bench(fb_own)
+      own = {'own_fwd_us': t_own * 1e6, 'own_fwd_tflops': flops / t_own / 1e12,
+             'own_fwd_mfma_util': flops / t_own / PEAK[bf16],
+             'own_bwd_us': max(t_own_fb - t_own, 1e-9) * 1e6}
+    rows.append({**own, **{
         'layer': names.get(mod, '?'), 'in': list(ishape), 'out': list(oshape),
         'k': k, 'transposed': transposed, 'gflop_fwd': flops / 1e9,
         'fwd_us': tf * 1e6, 'fwd_tflops': flops / tf / 1e12,
         'fwd_mfma_util': flops / tf / PEAK[bf16],
         'bwd_us': tb * 1e6, 'bwd_tflops': bflops / tb / 1e12,
-        'bwd_mfma_util': bflops / tb / PEAK[bf16]})
+        'bwd_mfma_util': bflops / tb / PEAK[bf16]}})
     tot_f += flops; tot_b += bflops; t_f += tf; t_b += tb
   out = {
       'dtype': 'bf16' if bf16 else 'fp32', 'peak_flops': PEAK[bf16],

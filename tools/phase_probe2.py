@@ -22,7 +22,8 @@ batch //= int(sys.argv[4]) if len(sys.argv) > 4 else 1
 dev = torch.device('cuda:0')
 sets = []
 for i in range(3):
-  tex, disp, mat = bench.make_inputs(nl, batch, h, w, cams, max_disp, 1000 + i, dev)
+  tex, disp, mat = bench.make_inputs(nl, batch, h, w, cams, max_disp, 1000 + i, dev,
+                                     os.environ.get('LSI_PROBE_DISP', 'smooth'))
   sets.append((tex, disp))
 r = bench.Renderer(sets[0][0], sets[0][1], mat, max_disp, bg, 'stream', rows, threads, sets[1:])
 r.desc.reserved = 4
@@ -44,6 +45,12 @@ t = r.ws[base:].view(torch.int64).view(-1, 16, 8).cpu().numpy().astype(np.float6
 wg_used = t[:, 0, 0] != 0
 t = t[wg_used]
 act = t[:, :, 0] != 0                      # waves that exist
+# slot 7: items by route (A: 4 pre-summed cells per lane; B: per pixel, distinct
+# cells; B': per pixel, lanes of a cell elected one at a time; C: general)
+rt = t[:, :, 7].astype(np.uint64)
+routes = [int(((rt >> np.uint64(16 * k)) & np.uint64(0xffff))[act].sum()) for k in range(4)]
+print('items by route  A %d  B %d  B\' %d  C %d  (%.1f / %.1f / %.1f / %.1f %%)' % (
+    tuple(routes) + tuple(100.0 * r / max(sum(routes), 1) for r in routes)))
 t0 = t[:, :, 0][act].min()
 us = (t - t0) / 100.0
 print('workgroups', len(t), 'waves per WG', int(act.sum(axis=1).max()))
