@@ -8,7 +8,7 @@
 #    combined with other trace domains) of the stream and sweep kernels.
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 timeout 900 python $R/bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
@@ -44,8 +44,10 @@ bash $R/tools/pmc_cmd.sh splat_bwd_stream_kernel python $R/tools/time_bwd.py > $
 bash $R/tools/pmc_cmd.sh "768, true" python $R/tools/time_bwd.py > $OUT/pmc_fwd_both_cfg3.txt 2>&1
 cat $OUT/bwd_both_disp_cfg3.json $OUT/pmc_bwd_stream_cfg3.txt $OUT/pmc_fwd_both_cfg3.txt
 for d in rough stress; do timeout 200 python $R/bench.py --disp $d --no-cpu-baseline --no-extra --traffic off > $OUT/bench_cfg3_$d.json 2>> $OUT/bench_default.err; done
-LSI_HIP_LIB=stamps python $R/tools/phase_probe2.py cfg3 > $OUT/timeline_cfg3.txt 2>&1
-LSI_HIP_LIB=stamps python $R/tools/phase_probe2.py cfg3 0 0 8 > $OUT/timeline_cfg3_shard_of_8.txt 2>&1
+# wall-clock timelines + items by route (stamps build: tools/build_variant.sh stamps lsi_splat_stream2.hip -DS2X_STAMPS)
+LSI_HIP_LIB=stamps python $R/tools/phase_probe2.py cfg3 2>&1 | grep -v amdgpu > $OUT/timeline_cfg3.txt
+LSI_HIP_LIB=stamps python $R/tools/phase_probe2.py cfg3 0 0 8 2>&1 | grep -v amdgpu > $OUT/timeline_cfg3_shard_of_8.txt
+bash $R/tools/pmc_calib.sh > $OUT/pmc_calibration.txt 2>&1
 rm -rf $OUT/kt/*/ $OUT/kt4/*/ 2>/dev/null
 find $OUT -name "*.csv" -size +2M -delete
 cat $OUT/bench_default.json
