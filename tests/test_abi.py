@@ -90,6 +90,14 @@ def test_rowband_precondition_and_workspace(built_lib):
   assert lib.lsi_splat_bwd_workspace_bytes(ctypes.byref(d)) == 2 * 2 * 16 * 48 * 16
   bad = _desc(_C, L=0)
   assert lib.lsi_splat_workspace_bytes(ctypes.byref(bad)) == 0
+  # a descriptor that names its path asks for that path's need only: the
+  # any-pose path keeps 8 disparity ranges per (layer, view), STREAM counters
+  # and boundary rows -- not the ATOMIC canvases
+  d.flags = 1
+  d.path = _C.LSI_PATH_TILE
+  assert lib.lsi_splat_workspace_bytes(ctypes.byref(d)) == 2 * 2 * 8 * 8
+  d.path = _C.LSI_PATH_STREAM
+  assert lib.lsi_splat_workspace_bytes(ctypes.byref(d)) == stream_need(1)
 
 
 def test_argument_errors_are_reported_before_any_launch(built_lib):

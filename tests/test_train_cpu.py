@@ -267,3 +267,26 @@ def nets_module():
   sys.path.insert(0, PKG)
   from lsi.nnutils import nets
   return nets
+
+
+def test_strict_restore_tolerates_only_the_constant_fc_statistics():
+  """Checkpoints written before SlimFC carried (constant, never updated)
+  moving statistics still restore; anything else missing or unexpected is an
+  error (train_utils.Trainer.strict_restore)."""
+  import torch
+  from lsi.nnutils import nets, train_utils
+  torch.manual_seed(0)
+  model = torch.nn.Sequential(nets.SlimFC(6, 4), nets.SlimFC(4, 3))
+  state = model.state_dict()
+  old = {k: v for k, v in state.items()
+         if not (k.endswith('moving_mean') or k.endswith('moving_variance'))}
+  assert len(old) < len(state)
+  fresh = torch.nn.Sequential(nets.SlimFC(6, 4), nets.SlimFC(4, 3))
+  train_utils.Trainer.strict_restore(fresh, old)
+  assert torch.equal(fresh[0].fc.weight, model[0].fc.weight)
+  broken = dict(old)
+  broken.pop('0.fc.weight')
+  with pytest.raises(RuntimeError, match='missing'):
+    train_utils.Trainer.strict_restore(fresh, broken)
+  with pytest.raises(RuntimeError, match='unexpected'):
+    train_utils.Trainer.strict_restore(fresh, dict(old, extra=torch.zeros(1)))
