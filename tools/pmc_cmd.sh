@@ -12,9 +12,16 @@ for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_WAVES" "
   python3 - <<PY
 import csv,glob,collections
 a=collections.defaultdict(list)
+g=collections.defaultdict(list)
 for f in glob.glob("/tmp/pqc/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "$KN" in r["Kernel_Name"]: a[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        if "$KN" in r["Kernel_Name"]:
+            a[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            # the same kernel launched with different grids (e.g. lsi_splat_bwd and
+            # lsi_splat_bwd_both): also per grid size
+            g[(r.get("Grid_Size", "?"), r["Counter_Name"])].append(float(r["Counter_Value"]))
 print({k: round(sum(v[len(v)//2:])/len(v[len(v)//2:])) for k,v in a.items()}, 'launches', {k: len(v) for k,v in a.items()}.popitem()[1] if a else 0)
+if len(set(k[0] for k in g)) > 1:
+    for k in sorted(g): print('   grid', k[0], k[1], round(sum(g[k])/len(g[k])), 'launches', len(g[k]))
 PY
 done
