@@ -368,6 +368,24 @@ __device__ __noinline__ void s2_flush_queue(unsigned tile_off, unsigned locks_of
   if (rowA >= 0) unlock(rowA);
 }
 
+// Folded fields: several lanes of a wave name the same window cell and must add
+// one after the other.  `cnt` is the wave's table of one byte per window cell
+// (four cells per word, zero between uses): ONE returning integer LDS add per
+// lane yields its rank among the lanes of its cell (a wave has 64 lanes: a byte
+// never carries into its neighbour); the caller runs rounds k = 0, 1, ... in
+// which the lanes of rank k add (distinct cells within a round), then clears
+// the words it touched.  (Round 3 elected one lane per cell and round through a
+// byte written and read back: two more LDS operations per round.)
+__device__ __forceinline__ int s2_cell_rank(unsigned char* cnt, int cell, bool act) {
+  if (!act) return -1;
+  const unsigned sh = 8u * ((unsigned)cell & 3u);
+  const unsigned old = atomicAdd(reinterpret_cast<unsigned*>(cnt + (cell & ~3)), 1u << sh);
+  return (int)((old >> sh) & 0xffu);
+}
+__device__ __forceinline__ void s2_cell_rank_reset(unsigned char* cnt, int cell, bool act) {
+  if (act) *reinterpret_cast<unsigned*>(cnt + (cell & ~3)) = 0u;
+}
+
 // 16-byte output store by epilogue mode (S2Args.ep): 1 plain, 2 write-through
 // (sc1), 3 non-temporal (what the launcher picks: see lsi_common.h)
 __device__ __forceinline__ void s2_store4(float* p, float x, float y, float z, float w,
@@ -539,6 +557,8 @@ __global__ __launch_bounds__(MAXT) void splat_stream2_kernel(S2Args a) {
     for (int i = tid; i < 4 + NT * R; i += T) ctl[i] = (i == 0) ? NW : 0;  // tickets, arrivals, locks
     if (CELL)
       for (int i = tid; i < ncl; i += T) clk[i] = 0;
+    for (int i = tid; i < (NW * WMAX + 3) / 4; i += T)  // the waves' cell-rank tables
+      reinterpret_cast<unsigned*>(sc_all)[i] = 0u;
   }
   __syncthreads();
   float m[8];
@@ -1059,21 +1079,18 @@ __global__ __launch_bounds__(MAXT) void splat_stream2_kernel(S2Args a) {
               *cell1 = s2_fma4(*cell1, V, w1);
               S2_FENCE();
             } else {
-              bool pending = true;
-              for (;;) {
-                if (__ballot(pending) == 0ull) break;
-                if (pending) sc[clv[i]] = (unsigned char)lane;
-                S2_FENCE();
-                const bool won = pending && sc[clv[i]] == (unsigned char)lane;
-                S2_FENCE();
-                if (won) {
+              // the lanes of a cell take turns: one returning LDS add gives every
+              // lane its rank among them (s2_cell_rank), round k is rank k's
+              const int rank = s2_cell_rank(sc, clv[i], true);
+              for (int k = 0; __ballot(rank >= k) != 0ull; ++k) {
+                if (rank == k) {
                   *cell = s2_fma4(*cell, V, w0);
                   S2_FENCE();
                   *cell1 = s2_fma4(*cell1, V, w1);
                 }
                 S2_FENCE();
-                pending = pending && !won;
               }
+              s2_cell_rank_reset(sc, clv[i], true);
             }
           }
         } else {
@@ -1127,21 +1144,16 @@ __global__ __launch_bounds__(MAXT) void splat_stream2_kernel(S2Args a) {
             }
             S2_FENCE();
           } else if (inw_mask != 0ull) {
-            bool pending = inw;
-            for (;;) {
-              if (__ballot(pending) == 0ull) break;
-              if (pending) sc[cl] = (unsigned char)lane;
-              S2_FENCE();
-              const bool won = pending && sc[cl] == (unsigned char)lane;
-              S2_FENCE();
-              if (won) {
+            const int rank = s2_cell_rank(sc, cl, inw);
+            for (int k = 0; __ballot(rank >= k) != 0ull; ++k) {
+              if (rank == k) {
                 *cell = s2_fma4(*cell, V, w0);
                 S2_FENCE();
                 *cell1 = s2_fma4(*cell1, V, w1);
               }
               S2_FENCE();
-              pending = pending && !won;
             }
+            s2_cell_rank_reset(sc, cl, inw);
           }
         }
         }
