@@ -341,6 +341,22 @@ __device__ __forceinline__ void cell_unlock(unsigned a0) {
   asm volatile("ds_write_b32 %0, %1" : : "v"(a0), "v"(zero) : "memory");
 }
 
+// Folded fields: the lanes of a wave that name the same window cell add one
+// after the other.  `cnt`: the wave's table of one byte per window cell (four
+// cells per word, zero between uses).  One returning integer LDS add gives a
+// lane its rank among the lanes of its cell (64 lanes: a byte never carries);
+// round k is rank k's turn, then the words touched are cleared.  (As in
+// lsi_splat_stream2.hip; round 4.)
+__device__ __forceinline__ int cell_rank(unsigned char* cnt, int cell, bool act) {
+  if (!act) return -1;
+  const unsigned sh = 8u * ((unsigned)cell & 3u);
+  const unsigned old = atomicAdd(reinterpret_cast<unsigned*>(cnt + (cell & ~3)), 1u << sh);
+  return (int)((old >> sh) & 0xffu);
+}
+__device__ __forceinline__ void cell_rank_reset(unsigned char* cnt, int cell, bool act) {
+  if (act) *reinterpret_cast<unsigned*>(cnt + (cell & ~3)) = 0u;
+}
+
 template <int LAYOUT, bool SIMPLE, int MODE, bool FULL, int MAXT = LSI_STREAM_MAXT>  // LAYOUT 0: channels-last, 1: planar
 __global__ __launch_bounds__(MAXT) void splat_stream_kernel(SplatArgs a,
                                                            StreamCfg cfg) {
@@ -509,6 +525,8 @@ __global__ __launch_bounds__(MAXT) void splat_stream_kernel(SplatArgs a,
   // ---- one-time init ------------------------------------------------------
   for (int i = tid; i < NW * WCELLS; i += T)
     rb_all[i] = make_float4(0.f, 0.f, 0.f, 0.f);  // windows start (and are left) zero
+  for (int i = tid; i < (NW * WMAX + 3) / 4; i += T)  // the waves' cell-rank tables
+    reinterpret_cast<unsigned*>(sc_all)[i] = 0u;
   for (int i = tid; i < rows * Wt; i += T)
     tile4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   if (cfg.both)
@@ -1273,21 +1291,18 @@ __global__ __launch_bounds__(MAXT) void splat_stream_kernel(SplatArgs a,
                 }
                 LSI_COMPILER_FENCE();
               } else {
-                bool pending = FULL || inrange;
-                for (;;) {
-                  if (__ballot(pending) == 0ull) break;
-                  if (pending) sc[clv[i]] = (unsigned char)lane;
-                  LSI_COMPILER_FENCE();
-                  const bool won = pending && sc[clv[i]] == (unsigned char)lane;
-                  LSI_COMPILER_FENCE();
-                  if (won) {
+                // the lanes of a cell take turns by rank (cell_rank below)
+                const bool act = FULL || inrange;
+                const int rank = cell_rank(sc, clv[i], act);
+                for (int k = 0; __ballot(rank >= k) != 0ull; ++k) {
+                  if (rank == k) {
                     *cell = f4_fma(*cell, V, w0);
                     LSI_COMPILER_FENCE();
                     *cell1 = f4_fma(*cell1, V, w1);
                   }
                   LSI_COMPILER_FENCE();
-                  pending = pending && !won;
                 }
+                cell_rank_reset(sc, clv[i], act);
               }
             }
           } else {
@@ -1343,23 +1358,18 @@ __global__ __launch_bounds__(MAXT) void splat_stream_kernel(SplatArgs a,
                 }
                 LSI_COMPILER_FENCE();
               } else if (inw_mask != 0ull) {
-                // some lanes may share a left cell: rounds of election through
-                // a byte per cell; the winners of a round have distinct cells
-                bool pending = inw;
-                for (;;) {
-                  if (__ballot(pending) == 0ull) break;
-                  if (pending) sc[cl] = (unsigned char)lane;
-                  LSI_COMPILER_FENCE();
-                  const bool won = pending && sc[cl] == (unsigned char)lane;
-                  LSI_COMPILER_FENCE();
-                  if (won) {
+                // some lanes may share a left cell: they take turns by rank;
+                // the lanes of one round have distinct cells
+                const int rank = cell_rank(sc, cl, inw);
+                for (int k = 0; __ballot(rank >= k) != 0ull; ++k) {
+                  if (rank == k) {
                     *cell = f4_fma(*cell, V, w0);
                     LSI_COMPILER_FENCE();
                     *cell1 = f4_fma(*cell1, V, w1);
                   }
                   LSI_COMPILER_FENCE();
-                  pending = pending && !won;
                 }
+                cell_rank_reset(sc, cl, inw);
               }
             }
           }

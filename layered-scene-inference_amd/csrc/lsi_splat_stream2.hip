@@ -1573,7 +1573,8 @@ int s2_plan_search(const LsiSplatDesc* d, int wmax, int maxnw, bool both, S2Plan
     const long nwg = (long)((d->Ht + R - 1) / R) * d->B;
     const int srows = (int)ceilf((float)(R + 1) / d->trg_downsampling);
     const int ilv = srows >= 15 ? 1 : 0;
-    const int nrow = s2_rows_padded(srows, ilv, hf);
+    // (the table holds either order: halo rows first or not is decided per plan)
+    const int nrow = max(s2_rows_padded(srows, ilv, hf), s2_rows_padded(srows, ilv, 0));
     const int nunit = nrow * nseg;
     // (both outputs: every item merges, and a merge under cell locks costs more
     // LDS operations than one under two row locks: 204 vs 184 us at config 3)
@@ -1623,7 +1624,13 @@ int s2_plan_search(const LsiSplatDesc* d, int wmax, int maxnw, bool both, S2Plan
       if (best.nw == 0 || est < best.est - 1e-9 ||
           (est <= best.est * 1.0001 && R > best.R)) {
         best.est = est; best.R = R; best.nw = c; best.cell = cell;
-        best.cap = cap; best.qcap = q; best.lds = lds; best.ilv = ilv; best.hf = hf;
+        best.cap = cap; best.qcap = q; best.lds = lds; best.ilv = ilv;
+        // halo rows first only when the 4 * nseg halo units are the waves' own
+        // first units (taken by wave index, all workgroups in step): with more
+        // of them (config 5: 24 for 12 waves) the second round is no longer
+        // aligned between neighbours and every one of them merges into the
+        // band's first or last tile row (config 5: 92.4 us without, 94.3 with)
+        best.hf = (hf && 4 * nseg <= c) ? hf : 0;
         best.nsplit = nsplit; best.lsub = lsub;
       }
     }
