@@ -643,11 +643,20 @@ def main():
     else:
       # (RCCL prints a version banner on stdout when its communicator comes up:
       # stdout is kept for the one JSON line, the banner goes to stderr)
-      with stdout_to_stderr():
-        dist.init_process_group('nccl', rank=rank, world_size=world,
-                                device_id=torch.device('cuda', local_rank))
-        dist.barrier()
-        torch.cuda.synchronize()
+      if os.environ.get('LSI_BENCH_SHARE_GPU') == '1':
+        # (tests: all ranks on device 0 of a one-GPU box, rendezvous over gloo
+        # -- RCCL refuses two ranks on one device; the N > 1 control flow is
+        # the same: split, barriers, max over ranks, the weak leg)
+        local_rank = 0
+        with stdout_to_stderr():   # (gloo announces its peers on stdout)
+          dist.init_process_group('gloo', rank=rank, world_size=world)
+          dist.barrier()
+      else:
+        with stdout_to_stderr():
+          dist.init_process_group('nccl', rank=rank, world_size=world,
+                                  device_id=torch.device('cuda', local_rank))
+          dist.barrier()
+          torch.cuda.synchronize()
   nl, h, w, batch, per_gpu, cams, max_disp, bg = WORKLOADS[args.workload]
   # (--shard-of N times what one GPU of a strong-scaling N-rank run renders)
   b_local, scaling = shard_batch(

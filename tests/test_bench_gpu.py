@@ -69,3 +69,29 @@ def test_bench_line_as_a_rank_of_torch_distributed_run(built_lib):
   assert rec['config']['launch'] == 'graph'
   per_rank = rec['roofline']['avg_launch_us_per_rank']
   assert per_rank['min'] <= per_rank['max']
+
+
+def test_two_ranks_split_the_batch_and_add_the_weak_figure(built_lib):
+  """The driver's N > 1 line on a one-GPU box: two ranks share device 0
+  (LSI_BENCH_SHARE_GPU: gloo rendezvous, RCCL refuses two ranks per device) --
+  the batch is split over the ranks (`scaling: strong`), rank 0 prints ONE JSON
+  line whose `value` counts both ranks' views and `extra.weak` holds the figure
+  of the same run with the whole batch on every rank."""
+  if not torch.cuda.is_available():
+    pytest.fail('gpu test selected but no ROCm device is visible')
+  env = {k: v for k, v in os.environ.items()
+         if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+  env['LSI_BENCH_SHARE_GPU'] = '1'
+  out = subprocess.run(
+      [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+       '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port',
+       str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps',
+       '5', '--warmup', '2', '--no-cpu-baseline', '--no-extra', '--traffic', 'off'],
+      env=env, capture_output=True, text=True, timeout=900)
+  assert out.returncode == 0, out.stderr[-3000:]
+  rec = _one_json_line(out)
+  assert rec['n_gpus'] == 2 and rec['scaling'] == 'strong'
+  assert 'batch 16 per GPU (32 total)' in rec['config']['workload']
+  assert rec['value'] > 0 and abs(rec['value'] - 32 * 5 / (rec['ms_per_step'] * 5e-3)) < 1e-6 * rec['value']
+  weak = rec['extra']['weak']
+  assert weak['scaling'] == 'weak' and weak['views_per_gpu'] == 32 and weak['value'] > 0
