@@ -456,6 +456,26 @@ int lsi_conv3x3_c32_fwd(int32_t N, int32_t H, int32_t W, int32_t cout, int32_t m
                         const void* x, const float* weight, const float* bias,
                         float scale3, void* out, lsi_stream_t stream);
 
+/*
+ * Backward of the prediction head `pred_l` (nets.py:150-158; TF autodiff of
+ * conv + bias + sigmoid): y = sigmoid(conv(x, W) + b), cout <= 4.
+ *   g, y: fp32 N x H x W x 4 (the incoming gradient and the forward's output,
+ *   RGBD pixels; channels >= cout ignored); x: bf16 N x H x W x 32 (needed for
+ *   g_wb); weight: fp32 cout x 32 x 3 x 3.
+ *   g_x (may be NULL): bf16 N x H x W x 32, the data gradient (MFMA, K = 9 taps
+ *   x 4 channels).  g_wb (may be NULL): fp32 [cout * 288 + cout], weight
+ *   gradient cout x 32 x 3 x 3 followed by the bias gradient; written (not
+ *   added to).  sigmoid'(z) * g is formed in fp32 registers and never written.
+ *   workspace (needed with g_wb): lsi_conv3x3_pred_bwd_workspace_bytes() bytes,
+ *   4-byte aligned -- the workgroups' partial sums, folded by a second kernel
+ *   (LSI_EWORKSPACE if smaller).
+ */
+size_t lsi_conv3x3_pred_bwd_workspace_bytes(void);
+int lsi_conv3x3_pred_bwd(int32_t N, int32_t H, int32_t W, int32_t cout, const float* g,
+                         const float* y, const void* x, const float* weight, void* g_x,
+                         float* g_wb, void* workspace, size_t workspace_bytes,
+                         lsi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -8,9 +8,12 @@ on bf16 channels-last activations.
 
 Forward and the data gradient of the 32 -> 32 layer run on the hand-written
 kernel (the data gradient of a stride-1 SAME convolution is the same
-convolution with the weights flipped and transposed); weight / bias gradients
-(reductions over all pixels) and the data gradient of the thin prediction layer
-go through aten.convolution_backward (MIOpen).
+convolution with the weights flipped and transposed); its weight gradient (a
+reduction over all pixels with K = pixels) goes through
+aten.convolution_backward (MIOpen).  The prediction head is hand-written end to
+end: lsi_conv3x3_pred_bwd forms sigmoid'(z) * g in registers, computes the data
+gradient on the matrix cores and the 4 x 288 + 4 weight / bias gradients on the
+vector unit.
 """
 import torch
 
@@ -85,6 +88,20 @@ class _Conv3x3C32(torch.autograd.Function):
     return gx, gw
 
 
+_PRED_WS = {}
+
+
+def _pred_workspace(dev):
+  """Partial sums of the head's weight gradient: one buffer per (device,
+  stream), never dropped (kernels of earlier launches may still use it)."""
+  key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+  ws = _PRED_WS.get(key)
+  if ws is None:
+    nbytes = _C.lib().lsi_conv3x3_pred_bwd_workspace_bytes()
+    ws = _PRED_WS[key] = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=dev)
+  return ws
+
+
 class _Conv3x3C32Sigmoid(torch.autograd.Function):
   """32 -> cout (<= 4) channels + bias + sigmoid, fp32 out N x 4 x H x W
   (channels last: RGBD pixels; channels past cout hold sigmoid(0))."""
@@ -102,6 +119,35 @@ class _Conv3x3C32Sigmoid(torch.autograd.Function):
   def backward(ctx, g):
     x, weight, y = ctx.saved_tensors
     cout = weight.shape[0]
+    n, _, h, w = x.shape
+    if cout == 4 and g.dtype == torch.float32:
+      # lsi_conv3x3_pred_bwd: gz = g * y * (1 - y) is formed in registers; the
+      # data gradient on the matrix cores (K = 9 taps x 4 channels), weight and
+      # bias gradients on the vector unit (fp32 gz; per-workgroup partials in the
+      # workspace, folded by a second kernel)
+      g = g.contiguous(memory_format=torch.channels_last)
+      dev = x.device
+      gx = (torch.empty((n, 32, h, w), dtype=torch.bfloat16, device=dev,
+                        memory_format=torch.channels_last)
+            if ctx.needs_input_grad[0] else None)
+      want_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
+      gwb = ws = None
+      if want_w:
+        gwb = torch.empty((cout * 288 + cout,), dtype=torch.float32, device=dev)
+        ws = _pred_workspace(dev)
+      wt = weight.detach()
+      if wt.dtype != torch.float32 or not wt.is_contiguous():
+        wt = wt.float().contiguous()
+      rc = _C.lib().lsi_conv3x3_pred_bwd(n, h, w, cout, _C.ptr(g), _C.ptr(y), _C.ptr(x),
+                                         _C.ptr(wt), _C.ptr(gx), _C.ptr(gwb),
+                                         _C.ptr(ws), 0 if ws is None else ws.numel() * 4,
+                                         _C.stream_ptr(dev))
+      _C.check(rc, 'lsi_conv3x3_pred_bwd')
+      gw = gb = None
+      if want_w:
+        gw = gwb[:cout * 288].view(cout, 32, 3, 3).to(weight.dtype)
+        gb = gwb[cout * 288:].to(weight.dtype) if ctx.has_bias else None
+      return gx, gw, gb
     ys = y[:, :cout]
     gz = (g * ys * (1.0 - ys)).to(torch.bfloat16).contiguous(
         memory_format=torch.channels_last)

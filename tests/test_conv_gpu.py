@@ -61,9 +61,10 @@ def test_prediction_head_bias_sigmoid_rgbd_pixels(shape, dev):
   assert float((got - want).abs().max()) <= 2e-5
 
 
-def test_gradients_of_both_layers(dev):
+@pytest.mark.parametrize('shape', [(2, 20, 32), (1, 70, 144)])
+def test_gradients_of_both_layers(shape, dev):
   from lsi.nnutils import _hip_conv
-  n, h, w = 2, 20, 32
+  n, h, w = shape
   g = torch.Generator().manual_seed(5)
   for head in (False, True):
     cout = 4 if head else 32
