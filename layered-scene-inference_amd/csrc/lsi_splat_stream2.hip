@@ -1515,7 +1515,7 @@ size_t s2_lds_bytes(int R, int Wt, int nw, int wmax, int cap, int qcap, int cell
          (size_t)((nw * wmax + 15) & ~15) + (cell ? (size_t)nt * R * Wt * 4 : 0) + 16;
 }
 
-struct S2Plan { int R, nw, cell, cap, qcap, ilv, hf, nsplit, lsub; size_t lds; double est; };
+struct S2Plan { int R, nw, cell, cap, qcap, ilv, hf, nsplit, lsub, nunit; size_t lds; double est; };
 
 // Band height, waves per workgroup, how many row-segment units are handed out
 // layer by layer.  Grounded in measurements (profiles/r03/): a launch streams
@@ -1567,8 +1567,11 @@ int s2_plan_search(const LsiSplatDesc* d, int wmax, int maxnw, bool both, S2Plan
   const int hf = hf_env ? atoi(hf_env) : 1;
   const double NCU = 256.0, CHIP_GBPS = 5700.0, CU_GBPS = 32.0;
   S2Plan best; best.est = -1.0; best.nw = 0;
-  for (int R = 1; R <= 64; R *= 2) {
-    if (d->tune_rows > 0 && R != d->tune_rows) continue;
+  // Band heights: powers of two; tune_rows asks for any one height.  (Bands
+  // need not divide the image: the last one is shorter.)
+  for (int Rp = 1; Rp <= 64; Rp *= 2) {
+    const int R = d->tune_rows > 0 ? d->tune_rows : Rp;
+    if (d->tune_rows > 0 && Rp > 1) break;
     if (d->tune_rows <= 0 && R > 1 && R / 2 >= d->Ht) break;
     const long nwg = (long)((d->Ht + R - 1) / R) * d->B;
     const int srows = (int)ceilf((float)(R + 1) / d->trg_downsampling);
@@ -1631,7 +1634,7 @@ int s2_plan_search(const LsiSplatDesc* d, int wmax, int maxnw, bool both, S2Plan
         // aligned between neighbours and every one of them merges into the
         // band's first or last tile row (config 5: 92.4 us without, 94.3 with)
         best.hf = (hf && 4 * nseg <= c) ? hf : 0;
-        best.nsplit = nsplit; best.lsub = lsub;
+        best.nsplit = nsplit; best.lsub = lsub; best.nunit = nunit;
       }
     }
   }
@@ -1652,6 +1655,20 @@ int s2_plan_search(const LsiSplatDesc* d, int wmax, int maxnw, bool both, S2Plan
 #ifndef LSI_S2_MAXT
 #define LSI_S2_MAXT 768
 #endif
+
+// 16 waves x one register set instead of 12 x two (lsi_stream2_launch): for
+// bands with fewer than two units per wave.  Such a launch is all start and
+// tail -- a wave's second item in flight buys nothing when it has one or two
+// units in all, four more waves take a quarter of the units off the others.
+// Measured (profiles/r04/ab_wide.txt, same box, 12 x 2 -> 16 x 1): 4-view shard
+// of config 3 (18 units per band) 22.6 -> 20.9 us, config 2 18.4 -> 16.6;
+// 8-view shard (30 units) 30.6 -> 31.1, 16-view shard 48.1 -> 47.6, config 3
+// 80.9 -> 80.8, config 5 (108 units, 6 segments per row) 88.4 -> 93.6.
+bool s2_wide(const S2Plan& narrow) {
+  static const char* env = getenv("LSI_S2_WIDE");  // experiments: 0 / 1
+  if (env) return atoi(env) != 0;
+  return narrow.nunit < 2 * (LSI_S2_MAXT / 64);
+}
 
 }  // namespace
 
@@ -1683,7 +1700,12 @@ int lsi_stream2_launch(const SplatArgs& a, int wmax, hipStream_t stream,
   S2Plan plan;
   // (one tile per layer: both outputs, the disparity pass, per-layer outputs alone)
   const bool both = disp_pass || a.out_img_c != nullptr || !(d->flags & LSI_COMPOSE);
+  // Two builds of the kernel: 12 waves with two register sets (two items in
+  // flight per wave), or 16 waves with one (<= 128 VGPRs).  Same bytes in flight
+  // per CU; see s2_wide() for where each wins.
   if (s2_plan(d, wmax, LSI_S2_MAXT / 64, both, &plan) != LSI_OK) return LSI_EINVAL;
+  const bool wide = s2_wide(plan);
+  if (wide && s2_plan(d, wmax, 1024 / 64, both, &plan) != LSI_OK) return LSI_EINVAL;
   S2Args k;
   k.tex = a.tex; k.disp = a.disp; k.M = a.M;
   k.out_img = a.out_img; k.out_wts = a.out_wts;
@@ -1735,7 +1757,9 @@ int lsi_stream2_launch(const SplatArgs& a, int wmax, hipStream_t stream,
   const bool ragged = d->W % SEG != 0;  // the last segment of a row is partial
   // <NSETS, cell locks, MAXT, both outputs, RGBD pixels, partial last segment>
   // (row locks with both outputs: s2_plan never picks cell locks there)
-#define S2_FN(C, B, P, R) (const void*)splat_stream2_kernel<LSI_S2_NSETS, C, LSI_S2_MAXT, B, P, R>
+#define S2_FN(C, B, P, R)                                                             \
+  (wide ? (const void*)splat_stream2_kernel<1, C, 1024, B, P, R>                         \
+        : (const void*)splat_stream2_kernel<LSI_S2_NSETS, C, LSI_S2_MAXT, B, P, R>)
 #define S2_PICK(C, B) (pack ? (ragged ? S2_FN(C, B, true, true) : S2_FN(C, B, true, false)) \
                             : (ragged ? S2_FN(C, B, false, true) : S2_FN(C, B, false, false)))
   const void* fn = both ? S2_PICK(false, true)
