@@ -476,6 +476,25 @@ int lsi_conv3x3_pred_bwd(int32_t N, int32_t H, int32_t W, int32_t cout, const fl
                          float* g_wb, void* workspace, size_t workspace_bytes,
                          lsi_stream_t stream);
 
+/*
+ * Weight gradient of a 3x3 stride-1 SAME convolution on channels-last bf16
+ * tensors (reference nets.py:104-111, the `upcnv*b` layers of the LDI heads; TF
+ * autodiff of slim.conv2d):
+ *   g_weight[co][ci][ky][kx] = sum over n, y, x of
+ *       gy[n][y][x][co] * x[n][y + ky - 1][x + kx - 1][ci]        (zero outside)
+ *   x: bf16 N x H x W x cin, gy: bf16 N x H x W x cout (16-byte aligned),
+ *   g_weight: fp32 cout x cin x 3 x 3, written (not added to).  cin and cout
+ *   multiples of 32 (LSI_EUNSUPPORTED otherwise).  MFMA with K = pixels,
+ *   operands transposed by the LDS transpose read; fp32 accumulation.
+ *   workspace: lsi_conv3x3_wgrad_workspace_bytes(...) bytes, 16-byte aligned
+ *   (partial sums of the pixel blocks; LSI_EWORKSPACE if smaller).
+ */
+size_t lsi_conv3x3_wgrad_workspace_bytes(int32_t N, int32_t H, int32_t W, int32_t cin,
+                                         int32_t cout);
+int lsi_conv3x3_wgrad(int32_t N, int32_t H, int32_t W, int32_t cin, int32_t cout,
+                      const void* x, const void* gy, float* g_weight, void* workspace,
+                      size_t workspace_bytes, lsi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -77,6 +77,8 @@ SIGNATURES = {
     'lsi_scatter_add': (ctypes.c_int, [_I32, _I64, _I64] + [_VP] * 4),
     'lsi_bilinear_fwd': (ctypes.c_int, [_I32] * 6 + [_VP] * 4),
     'lsi_conv3x3_pred_bwd_workspace_bytes': (_SZ, []),
+    'lsi_conv3x3_wgrad_workspace_bytes': (_SZ, [_I32] * 5),
+    'lsi_conv3x3_wgrad': (ctypes.c_int, [_I32] * 5 + [_VP] * 4 + [_SZ, _VP]),
     'lsi_conv3x3_pred_bwd': (ctypes.c_int, [_I32] * 4 + [_VP] * 7 + [_SZ, _VP]),
     'lsi_conv3x3_c32_fwd': (ctypes.c_int, [_I32] * 5 + [_VP] * 3 + [_F32, _VP, _VP]),
     'lsi_projection_matrices': (ctypes.c_int, [_I32] + [_VP] * 4 + [_I32, _VP]),

@@ -9,8 +9,10 @@ on bf16 channels-last activations.
 Forward and the data gradient of the 32 -> 32 layer run on the hand-written
 kernel (the data gradient of a stride-1 SAME convolution is the same
 convolution with the weights flipped and transposed); its weight gradient (a
-reduction over all pixels with K = pixels) goes through
-aten.convolution_backward (MIOpen).  The prediction head is hand-written end to
+GEMM with K = all pixels) on lsi_conv3x3_wgrad (csrc/lsi_conv_wgrad.hip: both
+operands transposed by the LDS transpose read), which also takes the weight
+gradients of the other 3x3 layers at full and half resolution
+(conv3x3_lib_own_wgrad: forward and data gradient on MIOpen).  The prediction head is hand-written end to
 end: lsi_conv3x3_pred_bwd forms sigmoid'(z) * g in registers, computes the data
 gradient on the matrix cores and the 4 x 288 + 4 weight / bias gradients on the
 vector unit.
@@ -82,10 +84,85 @@ class _Conv3x3C32(torch.autograd.Function):
             g, x, weight.to(g.dtype), None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
             [True, False, False])[0]
     if ctx.needs_input_grad[1]:
-      gw = torch.ops.aten.convolution_backward(
-          g, x, weight.to(g.dtype), None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
-          [False, True, False])[1].to(weight.dtype)
+      gw = _weight_grad(x, g, weight)
     return gx, gw
+
+
+# ---- weight gradient on the matrix cores (csrc/lsi_conv_wgrad.hip) ---------------
+WGRAD_MIN_PIXELS = 200000  # below: aten (measured break-even ~100 k pixels, tools/time_wgrad.py)
+_WGRAD_WS = {}
+
+
+def wgrad_supported(x, cin, cout, k, stride):
+  """3x3 stride-1 layers on bf16 channels-last GPU activations with channel
+  counts that are multiples of 32, at resolutions where the K = pixels GEMM
+  fills the chip (lsi_conv3x3_wgrad: 72 us against MIOpen's 227 at 8x32x256x768,
+  108 against 238 at 8x96x128x384; a tie at 8x192x64x192)."""
+  return (x.is_cuda and x.dim() == 4 and x.dtype == torch.bfloat16 and k == 3 and
+          stride == 1 and cin % 32 == 0 and cout % 32 == 0 and x.shape[1] == cin and
+          x.shape[0] * x.shape[2] * x.shape[3] >= WGRAD_MIN_PIXELS and
+          x.is_contiguous(memory_format=torch.channels_last) and x.data_ptr() % 16 == 0)
+
+
+def _wgrad_workspace(dev, nbytes):
+  """Partial sums of the pixel blocks: per (device, stream) the largest buffer
+  asked for so far; smaller ones stay alive (kernels in flight may use them)."""
+  key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+  bufs = _WGRAD_WS.setdefault(key, [])
+  if not bufs or bufs[-1].numel() * 4 < nbytes:
+    bufs.append(torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=dev))
+  return bufs[-1]
+
+
+def _weight_grad(x, g, weight):
+  """dL/dW of a 3x3 stride-1 SAME convolution: lsi_conv3x3_wgrad where it
+  applies, aten.convolution_backward (MIOpen) elsewhere."""
+  cout, cin = weight.shape[:2]
+  if (wgrad_supported(x, cin, cout, 3, 1) and g.dtype == torch.bfloat16 and
+      g.data_ptr() % 16 == 0 and g.is_contiguous(memory_format=torch.channels_last)):
+    n, _, h, w = x.shape
+    dev = x.device
+    lib = _C.lib()
+    nbytes = lib.lsi_conv3x3_wgrad_workspace_bytes(n, h, w, cin, cout)
+    ws = _wgrad_workspace(dev, nbytes)
+    gw = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=dev)
+    rc = lib.lsi_conv3x3_wgrad(n, h, w, cin, cout, _C.ptr(x), _C.ptr(g), _C.ptr(gw),
+                               _C.ptr(ws), ws.numel() * 4, _C.stream_ptr(dev))
+    _C.check(rc, 'lsi_conv3x3_wgrad')
+    return gw.to(weight.dtype)
+  return torch.ops.aten.convolution_backward(
+      g, x, weight.to(g.dtype), None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+      [False, True, False])[1].to(weight.dtype)
+
+
+class _Conv3x3LibOwnWgrad(torch.autograd.Function):
+  """A 3x3 stride-1 SAME convolution without bias whose forward and data
+  gradient stay on the library (MIOpen) and whose weight gradient runs on
+  lsi_conv3x3_wgrad: the layers of the heads the forward kernel does not take
+  (`upcnv2b`: 96 -> 64 at half resolution)."""
+
+  @staticmethod
+  def forward(ctx, x, weight):
+    ctx.save_for_backward(x, weight)
+    return torch.ops.aten.convolution(x, weight.to(x.dtype), None, [1, 1], [1, 1], [1, 1],
+                                      False, [0, 0], 1)
+
+  @staticmethod
+  def backward(ctx, g):
+    x, weight = ctx.saved_tensors
+    g = g.contiguous(memory_format=torch.channels_last)
+    gx = gw = None
+    if ctx.needs_input_grad[0]:
+      gx = torch.ops.aten.convolution_backward(
+          g, x, weight.to(g.dtype), None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+          [True, False, False])[0]
+    if ctx.needs_input_grad[1]:
+      gw = _weight_grad(x, g, weight)
+    return gx, gw
+
+
+def conv3x3_lib_own_wgrad(x, weight):
+  return _Conv3x3LibOwnWgrad.apply(x, weight)
 
 
 _PRED_WS = {}

@@ -171,6 +171,15 @@ class SlimConv2d(nn.Module):
         if self.activation == 'relu':
           return _bn_relu(self.bn, x)
         return self.bn(x)
+      if (self.bn is not None and torch.is_grad_enabled() and
+          self.conv.weight.requires_grad and
+          _hip_conv.wgrad_supported(x, cin, cout, self.k, self.stride)):
+        # forward and data gradient on the library, weight gradient on the
+        # matrix-core kernel (K = pixels)
+        x = _hip_conv.conv3x3_lib_own_wgrad(x, self.conv.weight)
+        if self.activation == 'relu':
+          return _bn_relu(self.bn, x)
+        return self.bn(x)
     ph = _same_pad(x.shape[2], self.k, self.stride)
     pw = _same_pad(x.shape[3], self.k, self.stride)
     # Symmetric SAME padding (the stride-1 layers) goes into the convolution:

@@ -100,3 +100,65 @@ def test_unsupported_shapes_stay_on_the_library(dev):
   assert not _hip_conv.supported(x[:, :, :, :8], 32, 32, 3, 1, False)  # width 8
   assert not _hip_conv.supported(x.contiguous(), 32, 32, 3, 1, False) or \
       x.contiguous().is_contiguous(memory_format=torch.channels_last)
+
+
+def _cl(t):
+  return t.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+
+
+@pytest.mark.parametrize('shape', [
+    (2, 20, 48, 32, 32),     # n, h, w, cin, cout
+    (1, 37, 100, 64, 64),    # widths that are not multiples of the 64-pixel strip / 32-pixel chunk
+    (1, 33, 70, 96, 64),     # three input-channel blocks, rows past one 32-row block
+    (2, 8, 16, 32, 96),      # output-channel blocks of 32
+    (1, 5, 7, 64, 128),      # output-channel blocks of 64, an image smaller than a chunk
+])
+def test_weight_gradient_kernel_matches_the_fp32_reference(shape, dev):
+  """lsi_conv3x3_wgrad (MFMA, K = pixels, operands through the LDS transpose
+  read) against torch's fp32 weight gradient of the same bf16 operands: exact
+  products, fp32 sums in another order (1e-5 of the largest entry)."""
+  from lsi import _C
+  n, h, w, cin, cout = shape
+  g = torch.Generator().manual_seed(11)
+  x = _cl(torch.randn((n, cin, h, w), generator=g).to(dev))
+  gy = _cl(torch.randn((n, cout, h, w), generator=g).to(dev))
+  lib = _C.lib()
+  nbytes = lib.lsi_conv3x3_wgrad_workspace_bytes(n, h, w, cin, cout)
+  ws = torch.empty((nbytes // 4,), device=dev)
+  gw = torch.full((cout, cin, 3, 3), float('nan'), device=dev)
+  rc = lib.lsi_conv3x3_wgrad(n, h, w, cin, cout, _C.ptr(x), _C.ptr(gy), _C.ptr(gw),
+                             _C.ptr(ws), nbytes, _C.stream_ptr(dev))
+  assert rc == 0
+  want = torch.nn.grad.conv2d_weight(x.float(), (cout, cin, 3, 3), gy.float(), padding=1)
+  scale = float(want.abs().max())
+  assert float((gw - want).abs().max()) <= 1e-5 * scale
+  # a workspace one byte short, unsupported channel counts
+  assert lib.lsi_conv3x3_wgrad(n, h, w, cin, cout, _C.ptr(x), _C.ptr(gy), _C.ptr(gw),
+                               _C.ptr(ws), nbytes - 1, _C.stream_ptr(dev)) == -3  # LSI_EWORKSPACE
+  assert lib.lsi_conv3x3_wgrad(n, h, w, 48, cout, _C.ptr(x), _C.ptr(gy), _C.ptr(gw),
+                               _C.ptr(ws), nbytes, _C.stream_ptr(dev)) == -5  # LSI_EUNSUPPORTED
+
+
+def test_library_convolution_with_the_own_weight_gradient(dev, monkeypatch):
+  """conv3x3_lib_own_wgrad (forward and data gradient on MIOpen, weight
+  gradient on the kernel) against fp32 autograd of the same operands."""
+  from lsi.nnutils import _hip_conv
+  monkeypatch.setattr(_hip_conv, 'WGRAD_MIN_PIXELS', 0)
+  g = torch.Generator().manual_seed(12)
+  n, h, w, cin, cout = 2, 24, 40, 96, 64
+  x = _cl(torch.randn((n, cin, h, w), generator=g).to(dev)).requires_grad_(True)
+  wt = (torch.randn((cout, cin, 3, 3), generator=g) * 0.05).to(dev).requires_grad_(True)
+  c = torch.randn((n, cout, h, w), generator=g).to(dev)
+  assert _hip_conv.wgrad_supported(x, cin, cout, 3, 1)
+  y = _hip_conv.conv3x3_lib_own_wgrad(x, wt)
+  (y.float() * c).sum().backward()
+  x2 = x.detach().float().requires_grad_(True)
+  w2 = wt.detach().to(torch.bfloat16).float().requires_grad_(True)
+  z = F.conv2d(x2, w2, None, 1, 1)
+  (z * c).sum().backward()
+  assert float((y.float() - z).abs().max()) <= 2.0 ** -7 * float(z.abs().max())
+  for got, want in ((x.grad, x2.grad), (wt.grad, w2.grad)):
+    assert float((got.float() - want).abs().max()) <= 2.0 ** -6 * float(want.abs().max())
+  # below the size threshold the layer stays on the library
+  monkeypatch.setattr(_hip_conv, 'WGRAD_MIN_PIXELS', 10 ** 9)
+  assert not _hip_conv.wgrad_supported(x, cin, cout, 3, 1)

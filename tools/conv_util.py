@@ -124,6 +124,16 @@ def main():
       own = {'own_fwd_us': t_own * 1e6, 'own_fwd_tflops': flops / t_own / 1e12,
              'own_fwd_mfma_util': flops / t_own / PEAK[bf16],
              'own_bwd_us': max(t_own_fb - t_own, 1e-9) * 1e6}
+    elif (not transposed and bf16 and isinstance(mod, nets.SlimConv2d) and mod.bn is not None and
+          _hip_conv.wgrad_supported(x.detach(), cin, cout, k, mod.stride)):
+      # forward and data gradient on the library, weight gradient on lsi_conv3x3_wgrad
+      xg = x.detach().requires_grad_(True)
+      def fb_own():
+        yy = _hip_conv.conv3x3_lib_own_wgrad(xg, w)
+        yy.backward(g)
+        xg.grad = None; w.grad = None
+      t_own_fb = bench(fb_own)
+      own = {'own_bwd_us': max(t_own_fb - tf, 1e-9) * 1e6, 'own': 'weight gradient only'}
     rows.append({**own, **{
         'layer': names.get(mod, '?'), 'in': list(ishape), 'out': list(oshape),
         'k': k, 'transposed': transposed, 'gflop_fwd': flops / 1e9,
