@@ -89,7 +89,8 @@ class _Conv3x3C32(torch.autograd.Function):
 
 
 # ---- weight gradient on the matrix cores (csrc/lsi_conv_wgrad.hip) ---------------
-WGRAD_MIN_PIXELS = 200000  # below: aten (measured break-even ~100 k pixels, tools/time_wgrad.py)
+import os
+WGRAD_MIN_PIXELS = int(os.environ.get('LSI_WGRAD_MIN_PIXELS', '200000'))  # below: aten (tools/time_wgrad.py)
 _WGRAD_WS = {}
 
 

@@ -46,7 +46,15 @@ __global__ __launch_bounds__(1024) void rd(const float* __restrict__ tex,
     const long px = ((long)l * 32 + b) * ((long)H * W + padpx) + (long)(ya + r) * W + sg * 256 + 4 * lane;
     const float4* pd = reinterpret_cast<const float4*>(disp + px);
     const float4* pt = reinterpret_cast<const float4*>(tex + 3 * px);
-    s.d = pd[0]; s.t0 = pt[0]; s.t1 = pt[1]; s.t2 = pt[2];
+    if (touch < 0) {
+      // contiguous variant: every texture load instruction covers 1 KiB (lane
+      // k reads bytes 16 k .. of the segment's 3 KiB; the lane's own pixels
+      // would then need a cross-lane exchange)
+      const float4* ps = reinterpret_cast<const float4*>(tex + 3 * (px - 4 * lane));
+      s.d = pd[0]; s.t0 = ps[lane]; s.t1 = ps[64 + lane]; s.t2 = ps[128 + lane];
+    } else {
+      s.d = pd[0]; s.t0 = pt[0]; s.t1 = pt[1]; s.t2 = pt[2];
+    }
   };
   float4 acc = make_float4(0, 0, 0, 0);
   auto consume = [&](Set& s) {
@@ -145,6 +153,17 @@ int main() {
       run<2>(tex, disp, out, 4, 768, 4, 1, alu, 0, 100 * K, 0, 1, 0);
       run<2>(tex, disp, out, 4, 768, 4, 1, alu, 0, 100 * K, 0, 0, 4160);
     }
+    return 0;
+  }
+  if (getenv("MB6_CONTIG")) {
+    printf("--- texture loads: lane-strided 48 B (touch 0, the kernel's) vs 1 KiB per instruction (touch -1)\n");
+    for (int rep = 0; rep < 2; ++rep)
+      for (int alu : {0, 40, 75})
+        for (int touch : {0, -1}) {
+          run<2>(tex, disp, out, 32, 768, 32, 1, alu, 1, 100 * K, touch);
+          run<1>(tex, disp, out, 32, 1024, 32, 1, alu, 1, 100 * K, touch);
+        }
+    for (int touch : {0, -1}) run<2>(tex, disp, out, 4, 768, 4, 1, 40, 0, 100 * K, touch);
     return 0;
   }
   if (getenv("MB6_TOUCH")) {
