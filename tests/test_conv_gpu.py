@@ -112,6 +112,8 @@ def _cl(t):
     (1, 33, 70, 96, 64),     # three input-channel blocks, rows past one 32-row block
     (2, 8, 16, 32, 96),      # output-channel blocks of 32
     (1, 5, 7, 64, 128),      # output-channel blocks of 64, an image smaller than a chunk
+    (2, 256, 768, 32, 32),   # the training step's full-resolution layer (two images)
+    (2, 128, 384, 96, 64),   # ... and its half-resolution layer
 ])
 def test_weight_gradient_kernel_matches_the_fp32_reference(shape, dev):
   """lsi_conv3x3_wgrad (MFMA, K = pixels, operands through the LDS transpose
