@@ -1656,18 +1656,41 @@ int s2_plan_search(const LsiSplatDesc* d, int wmax, int maxnw, bool both, S2Plan
 #define LSI_S2_MAXT 768
 #endif
 
-// 16 waves x one register set instead of 12 x two (lsi_stream2_launch): for
-// bands with fewer than two units per wave.  Such a launch is all start and
-// tail -- a wave's second item in flight buys nothing when it has one or two
-// units in all, four more waves take a quarter of the units off the others.
-// Measured (profiles/r04/ab_wide.txt, same box, 12 x 2 -> 16 x 1): 4-view shard
-// of config 3 (18 units per band) 22.6 -> 20.9 us, config 2 18.4 -> 16.6;
-// 8-view shard (30 units) 30.6 -> 31.1, 16-view shard 48.1 -> 47.6, config 3
-// 80.9 -> 80.8, config 5 (108 units, 6 segments per row) 88.4 -> 93.6.
-bool s2_wide(const S2Plan& narrow) {
-  static const char* env = getenv("LSI_S2_WIDE");  // experiments: 0 / 1
-  if (env) return atoi(env) != 0;
-  return narrow.nunit < 2 * (LSI_S2_MAXT / 64);
+// 16 waves x one register set (<= 128 VGPRs) instead of 12 x two
+// (lsi_stream2_launch).  Measured, same box, 12 x 2 -> 16 x 1
+// (profiles/r04/ab_wide.txt):
+//  * bands with fewer than two units per wave are all start and tail -- a
+//    wave's second item in flight buys nothing when it has one or two units in
+//    all, four more waves take a quarter of the units off the others: 4-view
+//    shard of config 3 (18 units per band) 22.6 -> 20.9 us, config 2 18.4 -> 16.6;
+//  * smooth disparity fields at larger launches are bandwidth-bound and tie or
+//    lose a little (16 items in flight per CU instead of 24): config 3 81.2 ->
+//    81.5, 81.4 -> 81.4, 79.9 -> 80.7 us on three boxes, 16-view shard 48.1 ->
+//    47.6, 8-view shard 30.6 -> 31.1;
+//  * folded / i.i.d. fields (routes B' / C: the item loop is bound by vector and
+//    LDS work, which more waves hide) gain 12 - 15 %: config 3 140.7 -> 119.3 /
+//    152.5 -> 130.7 us, its shards 80.3 -> 70.5, 52.6 -> 46.7, 38.0 -> 34.7;
+//  * where 16 waves do not fit next to the tile (config 5: the plan stays at
+//    12) the one-register-set build loses: 88.4 -> 93.6 us.
+// The planner cannot see the field: by itself it takes 16 x 1 for the small
+// bands only; tune_threads > 768 asks for it anywhere (bench.py --threads 1024,
+// forward_splat(threads=1024): the choice for rough fields), tune_threads <= 768
+// for 12 x 2; LSI_S2_WIDE=0/1 forces one for experiments.
+bool s2_choose(const LsiSplatDesc* d, int wmax, bool both, S2Plan* plan, bool* wide) {
+  static const char* env = getenv("LSI_S2_WIDE");
+  S2Plan narrow, wideplan;
+  const int rc_n = d->tune_threads > LSI_S2_MAXT
+                       ? LSI_EINVAL : s2_plan(d, wmax, LSI_S2_MAXT / 64, both, &narrow);
+  const int rc_w = (d->tune_threads > 0 && d->tune_threads <= LSI_S2_MAXT)
+                       ? LSI_EINVAL : s2_plan(d, wmax, 1024 / 64, both, &wideplan);
+  bool w = rc_w == LSI_OK &&
+           (rc_n != LSI_OK || (wideplan.nw > LSI_S2_MAXT / 64 &&
+                               narrow.nunit < 2 * (LSI_S2_MAXT / 64)));
+  if (env && d->tune_threads <= 0) w = atoi(env) != 0 ? rc_w == LSI_OK : rc_n != LSI_OK;
+  if (!w && rc_n != LSI_OK) return false;
+  *plan = w ? wideplan : narrow;
+  *wide = w;
+  return true;
 }
 
 }  // namespace
@@ -1701,11 +1724,9 @@ int lsi_stream2_launch(const SplatArgs& a, int wmax, hipStream_t stream,
   // (one tile per layer: both outputs, the disparity pass, per-layer outputs alone)
   const bool both = disp_pass || a.out_img_c != nullptr || !(d->flags & LSI_COMPOSE);
   // Two builds of the kernel: 12 waves with two register sets (two items in
-  // flight per wave), or 16 waves with one (<= 128 VGPRs).  Same bytes in flight
-  // per CU; see s2_wide() for where each wins.
-  if (s2_plan(d, wmax, LSI_S2_MAXT / 64, both, &plan) != LSI_OK) return LSI_EINVAL;
-  const bool wide = s2_wide(plan);
-  if (wide && s2_plan(d, wmax, 1024 / 64, both, &plan) != LSI_OK) return LSI_EINVAL;
+  // flight per wave), or 16 waves with one (<= 128 VGPRs); see s2_choose().
+  bool wide = false;
+  if (!s2_choose(d, wmax, both, &plan, &wide)) return LSI_EINVAL;
   S2Args k;
   k.tex = a.tex; k.disp = a.disp; k.M = a.M;
   k.out_img = a.out_img; k.out_wts = a.out_wts;

@@ -613,6 +613,15 @@ def test_stream_compact_instance_routes(kind, shape, dev, ref_cpu):
     np.testing.assert_allclose(img.cpu().numpy(), want['img'], rtol=0,
                                atol=IMG_ATOL)
     np.testing.assert_allclose(wts.cpu().numpy(), want['wts'], rtol=WTS_RTOL)
+  # both builds of the kernel by request: tune_threads <= 768 -> 12 waves x two
+  # register sets, > 768 -> 16 waves x one (by itself the planner takes the
+  # second for bands with fewer than two units per wave)
+  for threads in (768, 1024, 320, 960):
+    for rows in (0, 8):
+      img, wts = run(band_rows=rows, threads=threads)
+      np.testing.assert_allclose(img.cpu().numpy(), want['img'], rtol=0,
+                                 atol=IMG_ATOL)
+      np.testing.assert_allclose(wts.cpu().numpy(), want['wts'], rtol=WTS_RTOL)
 
 
 @pytest.mark.parametrize('kind', ['smooth', 'iid', 'outside', 'clampy'])
