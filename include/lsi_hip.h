@@ -464,13 +464,14 @@ int lsi_conv3x3_c32_fwd(int32_t N, int32_t H, int32_t W, int32_t cout, int32_t m
  *   g_wb); weight: fp32 cout x 32 x 3 x 3.
  *   g_x (may be NULL): bf16 N x H x W x 32, the data gradient (MFMA, K = 9 taps
  *   x 4 channels).  g_wb (may be NULL): fp32 [cout * 288 + cout], weight
- *   gradient cout x 32 x 3 x 3 followed by the bias gradient; written (not
- *   added to).  sigmoid'(z) * g is formed in fp32 registers and never written.
- *   workspace (needed with g_wb): lsi_conv3x3_pred_bwd_workspace_bytes() bytes,
- *   4-byte aligned -- the workgroups' partial sums, folded by a second kernel
- *   (LSI_EWORKSPACE if smaller).
+ *   gradient cout x 32 x 3 x 3 followed by the bias gradient (matrix cores, K =
+ *   pixels, sigmoid'(z) * g as bf16 hi + lo); written (not added to).
+ *   sigmoid'(z) * g is formed in fp32 registers and never written.
+ *   workspace (needed with g_wb): lsi_conv3x3_pred_bwd_workspace_bytes(N, H, W)
+ *   bytes, 16-byte aligned -- the pixel blocks' partial sums, folded by a second
+ *   kernel (LSI_EWORKSPACE if smaller).
  */
-size_t lsi_conv3x3_pred_bwd_workspace_bytes(void);
+size_t lsi_conv3x3_pred_bwd_workspace_bytes(int32_t N, int32_t H, int32_t W);
 int lsi_conv3x3_pred_bwd(int32_t N, int32_t H, int32_t W, int32_t cout, const float* g,
                          const float* y, const void* x, const float* weight, void* g_x,
                          float* g_wb, void* workspace, size_t workspace_bytes,

@@ -167,8 +167,8 @@ struct PredBwdArgs {
   const float* g;    // N x H x W x 4 (only the first `cout` channels count)
   const float* y;    // N x H x W x 4 (the forward's output)
   const float* w;    // cout x 32 x 3 x 3
-  const __bf16* x;   // N x H x W x 32 (weight gradient)
-  void* out;         // data: bf16 N x H x W x 32; weight: fp32 [cout*288 + cout] (+=)
+  const __bf16* x;   // (unused by the data gradient)
+  void* out;         // bf16 N x H x W x 32
   int N, H, W, cout;
 };
 
@@ -239,172 +239,26 @@ __global__ __launch_bounds__(256) void pred_bwd_data_kernel(PredBwdArgs a) {
 }
 
 // Weight and bias gradient of the head: gW[co][ci][tap] = sum over pixels of
-// gz[p][co] * x[p + tap][ci], gb[co] = sum gz[p][co] -- a reduction over all
-// N H W pixels into 4 x 288 + 4 numbers.  N = 4 output channels leaves nothing
-// for a matrix tile (and both MFMA operands would want 8 consecutive PIXELS of
-// one channel, the transpose of the channels-last layout); on the vector unit:
-// the nine taps are the workgroup's nine waves, lane (pixel slot = lane / 4,
-// channel block = lane % 4) holds 8 input channels of its shifted pixel (one
-// 16-byte load) and ONE channel of the pixel's gz (the four lanes of a pixel
-// exchange them with DPP quad permutes): 32 multiply-adds as 16 v_pk_fma_f32
-// into 32 accumulators.  Workgroups loop over strips of 16 columns x 32 rows,
-// four rows multiplied while the next four are in flight; at
-// the end the 16 pixel slots are summed with shuffles and every workgroup
-// writes its 4 x 288 + 4 partial sums to the workspace.  A first version added
-// them to the result with fp32 atomics: 1.5 M atomics onto 1156 addresses cost
-// 350 - 500 us (tools/time_pred_bwd.py); pred_bwd_reduce_kernel sums the
-// partials instead.  gz stays fp32 (MIOpen's path rounds it to bf16 first).
-constexpr int PW_STRIDE = 1160;  // floats per workgroup in the workspace (>= 4 * 288 + 4)
-constexpr int PW_MAXWG = 424;    // strip sets: x 9 waves ~ 15 per CU (110 VGPRs: 4 per SIMD), a multiple of 8
-
-// One item of the weight kernel: four rows of a strip, as loaded by one lane --
-// its channel of g and y (the four lanes of a pixel exchange the products) and 8
-// input channels of the shifted pixel.
-struct PredRows {
-  float g[4], y[4];
-  bf16x8 v[4];
-  bool m[4];
-};
-
-__device__ __forceinline__ float quad_bcast(float v, int k) {
-  const int i = __builtin_bit_cast(int, v);
-  int r;
-  switch (k) {  // quad_perm(k, k, k, k)
-    case 0: r = __builtin_amdgcn_mov_dpp(i, 0x00, 0xf, 0xf, false); break;
-    case 1: r = __builtin_amdgcn_mov_dpp(i, 0x55, 0xf, 0xf, false); break;
-    case 2: r = __builtin_amdgcn_mov_dpp(i, 0xaa, 0xf, 0xf, false); break;
-    default: r = __builtin_amdgcn_mov_dpp(i, 0xff, 0xf, 0xf, false); break;
-  }
-  return __builtin_bit_cast(float, r);
-}
-
-__global__ __launch_bounds__(192) void pred_bwd_weight_kernel(PredBwdArgs a, int nstrip,
-                                                              float* part) {
-  const int lane = threadIdx.x & 63;
-  // workgroup = the three taps of one kernel row over one set of strips; the
-  // three rows of a set are workgroups b, b + 8, b + 16: the same XCD (b % 8),
-  // dispatched together -- their re-reads of x are L2 hits
-  const int wset = (blockIdx.x / 24) * 8 + (blockIdx.x & 7), nset = gridDim.x / 3;
-  const int tap = __builtin_amdgcn_readfirstlane(3 * ((blockIdx.x >> 3) % 3) + (threadIdx.x >> 6));
-  const int ps = lane >> 2, cb = lane & 3;
-  const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-  f32x2 acc[8][2];
-#pragma unroll
-  for (int c = 0; c < 8; ++c) acc[c][0] = acc[c][1] = f32x2{0.f, 0.f};
-  f32x2 gb[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
-  const int sx = a.W / 16, sy = (a.H + CV_ROWS - 1) / CV_ROWS;
-  // items = (strip of this workgroup, group of four rows); the loads of item
-  // i + 1 are in flight while item i is multiplied
-  constexpr int GPS = CV_ROWS / 4;
-  const int nitem = wset < nstrip ? GPS * ((nstrip - wset + nset - 1) / nset) : 0;
-  // Branch-free buffer loads from clamped addresses (row offsets in scalar
-  // registers, 32-bit lane offsets: no 64-bit address per load in flight); what lies outside the image -- the row of
-  // gz, the shifted row or column of x, channels >= cout -- is removed by
-  // zeroing gz (`m`), which is exact: the bias sum is taken by the centre tap,
-  // whose shifted pixel is the pixel itself.
-  const unsigned npix = (unsigned)a.N * a.H * a.W;
-  const __amdgpu_buffer_rsrc_t rg_ =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.g), 0, npix * 16u, 0x00020000);
-  const __amdgpu_buffer_rsrc_t ry_ =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.y), 0, npix * 16u, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rx_ =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.x), 0, npix * 64u, 0x00020000);
-  auto load_item = [&](int it_, PredRows& p) {
-    const int it = min(it_, nitem - 1);  // (the last prefetch is never used)
-    const int sidx = wset + (it / GPS) * nset;
-    // (integer division runs on the vector unit: pin the results to scalars)
-    const int n = __builtin_amdgcn_readfirstlane(sidx / (sx * sy)), r = sidx - n * sx * sy;
-    const int ry = __builtin_amdgcn_readfirstlane(r / sx);
-    const int yb = ry * CV_ROWS + 4 * (it % GPS);
-    const int x = (r - ry * sx) * 16 + ps, xx = x + dx;
-    const bool lin = xx >= 0 && xx < a.W && cb < a.cout;
-    const unsigned poff = 4u * (4 * x + min(cb, a.cout - 1));  // bytes
-    const unsigned xoff = 2u * (32 * min(max(xx, 0), a.W - 1) + 8 * cb);
-    const int row0 = n * a.H;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int yu = yb + u, yy = yu + dy;
-      // byte offsets of the rows (< 4 GiB: checked by the launcher), scalar
-      const unsigned rg = __builtin_amdgcn_readfirstlane(
-          (unsigned)(row0 + min(yu, a.H - 1)) * (unsigned)a.W * 16u);
-      const unsigned rx = __builtin_amdgcn_readfirstlane(
-          (unsigned)(row0 + min(max(yy, 0), a.H - 1)) * (unsigned)a.W * 64u);
-      p.g[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg_, poff, rg, 0));
-      p.y[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry_, poff, rg, 0));
-      p.v[u] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rx_, xoff, rx, 0));
-      p.m[u] = lin && yu < a.H && yy >= 0 && yy < a.H;
-    }
-  };
-  auto mul_item = [&](const PredRows& p) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const float gz = p.m[u] ? p.g[u] * p.y[u] * (1.0f - p.y[u]) : 0.0f;
-      const f32x2 zl = {quad_bcast(gz, 0), quad_bcast(gz, 1)};
-      const f32x2 zh = {quad_bcast(gz, 2), quad_bcast(gz, 3)};
-      gb[0] += zl;
-      gb[1] += zh;
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const float xv = (float)p.v[u][c];
-        const f32x2 x2 = {xv, xv};
-        acc[c][0] = __builtin_elementwise_fma(zl, x2, acc[c][0]);
-        acc[c][1] = __builtin_elementwise_fma(zh, x2, acc[c][1]);
-      }
-    }
-  };
-  if (nitem > 0) {  // (a set past the last strip writes zeros)
-    PredRows pa, pb;
-    load_item(0, pa);
-    for (int it = 0; it < nitem; it += 2) {
-      load_item(it + 1, pb);
-      mul_item(pa);
-      load_item(it + 2, pa);
-      mul_item(pb);
-    }
-  }
-  // sum over the 16 pixel slots (lanes with equal lane % 4); lane cb of the wave
-  // writes its 8 channels x 4 outputs: part[(co * 32 + ci) * 9 + tap]
-  float* const out = part + (size_t)wset * PW_STRIDE;
-#pragma unroll
-  for (int c = 0; c < 8; ++c)
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      float v = acc[c][k >> 1][k & 1];
-      for (int o = 4; o < 64; o <<= 1) v += __shfl_xor(v, o);
-      if (ps == 0 && k < a.cout) out[(k * 32 + 8 * cb + c) * 9 + tap] = v;
-    }
-  if (tap == 4) {  // the bias gradient: every pixel once (each of its 4 lanes holds it)
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      float v = cb == 0 ? gb[k >> 1][k & 1] : 0.0f;
-      for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o);
-      if (lane == 0 && k < a.cout) out[a.cout * 288 + k] = v;
-    }
-  }
-}
-
-// g_wb[o] = sum over the workgroups' partials: 64 outputs x 16 row groups per
-// workgroup, the groups folded through LDS.  Writes (the caller need not clear).
-__global__ __launch_bounds__(1024) void pred_bwd_reduce_kernel(const float* part, int nwg,
-                                                               int nout, float* out) {
-  __shared__ float red[16][64];
-  const int o = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
-  float s = 0.0f;
-  if (o < nout)
-    for (int w = grp; w < nwg; w += 16) s += part[(size_t)w * PW_STRIDE + o];
-  red[grp][threadIdx.x & 63] = s;
-  __syncthreads();
-  if (grp == 0 && o < nout) {
-    float t = 0.0f;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) t += red[k][threadIdx.x];
-    out[o] = t;
-  }
-}
+// gz[p][co] * x[p + tap][ci], gb[co] = sum gz[p][co] -- a GEMM with K = all
+// pixels: the weight-gradient kernel of lsi_conv_wgrad.hip (operands through the
+// LDS transpose read) with gz formed while a row is staged.  Four outputs fill
+// 4 of the matrix tile's 16 rows; rows 4 .. 7 carry what rounding gz to bf16
+// left (hi + lo: ~16 mantissa bits; MIOpen's path rounds gz to bf16 once), the
+// bias gradient is one more product with a fragment of ones.  History at
+// 8 x 256 x 768 (tools/time_pred_bwd.py): on the vector unit with fp32 atomics
+// into the result 496 us (1.5 M atomics onto 1156 addresses); one tap per wave,
+// per-workgroup partial sums + reduce kernel, DPP gz exchange, four-row prefetch
+// through buffer loads 132 us; on the matrix cores: see DESIGN.md 4.6.
 
 int launch_rc() { return hipGetLastError() == hipSuccess ? LSI_OK : LSI_ELAUNCH; }
 
 }  // namespace
+
+// (lsi_conv_wgrad.hip)
+size_t lsi_pred_wgrad_workspace_bytes(int N, int H, int W, int cout);
+int lsi_pred_wgrad_launch(int N, int H, int W, int cout, const float* g, const float* y,
+                          const void* x, float* g_wb, void* workspace, size_t workspace_bytes,
+                          hipStream_t stream);
 
 extern "C" int lsi_conv3x3_c32_fwd(int32_t N, int32_t H, int32_t W, int32_t cout,
                                    int32_t mode, const void* x, const float* weight,
@@ -435,8 +289,9 @@ extern "C" int lsi_conv3x3_c32_fwd(int32_t N, int32_t H, int32_t W, int32_t cout
   return launch_rc();
 }
 
-extern "C" size_t lsi_conv3x3_pred_bwd_workspace_bytes(void) {
-  return (size_t)PW_MAXWG * PW_STRIDE * sizeof(float);
+extern "C" size_t lsi_conv3x3_pred_bwd_workspace_bytes(int32_t N, int32_t H, int32_t W) {
+  if (N <= 0 || H <= 0 || W <= 0) return 0;
+  return lsi_pred_wgrad_workspace_bytes(N, H, W, 4);
 }
 
 extern "C" int lsi_conv3x3_pred_bwd(int32_t N, int32_t H, int32_t W, int32_t cout,
@@ -448,34 +303,21 @@ extern "C" int lsi_conv3x3_pred_bwd(int32_t N, int32_t H, int32_t W, int32_t cou
     return LSI_EINVAL;
   if (!g || !y || !weight || (!g_x && !g_wb) || (g_wb && (!x || !workspace))) return LSI_ENULL;
   if (((uintptr_t)g & 15) || ((uintptr_t)y & 15) || ((uintptr_t)x & 15) ||
-      ((uintptr_t)g_x & 15) || ((uintptr_t)workspace & 3))
+      ((uintptr_t)g_x & 15) || ((uintptr_t)workspace & 15))
     return LSI_EINVAL;
-  if (g_wb && workspace_bytes < lsi_conv3x3_pred_bwd_workspace_bytes()) return LSI_EWORKSPACE;
-  if (g_wb && (uint64_t)N * H * W * 64 >= (1ull << 32)) return LSI_EUNSUPPORTED;  // 32-bit offsets
-  PredBwdArgs a;
-  a.g = g; a.y = y; a.w = weight; a.x = reinterpret_cast<const __bf16*>(x);
-  a.N = N; a.H = H; a.W = W; a.cout = cout;
+  if (g_wb && workspace_bytes < lsi_pred_wgrad_workspace_bytes(N, H, W, cout))
+    return LSI_EWORKSPACE;
   if (g_x) {
+    PredBwdArgs a;
+    a.g = g; a.y = y; a.w = weight; a.x = reinterpret_cast<const __bf16*>(x);
+    a.N = N; a.H = H; a.W = W; a.cout = cout;
     a.out = g_x;
     const dim3 grid((W / 16 + 3) / 4, (H + CV_ROWS - 1) / CV_ROWS, N), block(256);
     hipLaunchKernelGGL(pred_bwd_data_kernel, grid, block, 0, (hipStream_t)stream, a);
     if (launch_rc() != LSI_OK) return LSI_ELAUNCH;
   }
-  if (g_wb) {
-    a.out = nullptr;
-    const int nstrip = N * (W / 16) * ((H + CV_ROWS - 1) / CV_ROWS);
-    // equal shares: sets of ceil(nstrip / PW_MAXWG) strips, rounded up to whole
-    // groups of 8 sets (sets past the last strip write zero partials)
-    const int per = (nstrip + PW_MAXWG - 1) / PW_MAXWG;
-    const int nwg = (((nstrip + per - 1) / per) + 7) / 8 * 8;
-    const int nout = cout * 288 + cout;
-    float* const part = reinterpret_cast<float*>(workspace);
-    hipLaunchKernelGGL(pred_bwd_weight_kernel, dim3(3 * nwg), dim3(192), 0,
-                       (hipStream_t)stream, a, nstrip, part);
-    if (launch_rc() != LSI_OK) return LSI_ELAUNCH;
-    hipLaunchKernelGGL(pred_bwd_reduce_kernel, dim3((nout + 63) / 64), dim3(1024), 0,
-                       (hipStream_t)stream, part, nwg, nout, g_wb);
-    if (launch_rc() != LSI_OK) return LSI_ELAUNCH;
-  }
+  if (g_wb)
+    return lsi_pred_wgrad_launch(N, H, W, cout, g, y, x, g_wb, workspace, workspace_bytes,
+                                 (hipStream_t)stream);
   return LSI_OK;
 }

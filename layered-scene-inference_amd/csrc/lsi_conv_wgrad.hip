@@ -58,6 +58,11 @@ struct WgradArgs {
   float* part;       // [pixel blocks][Cout][Cin][9]
   int N, H, W, Cin, Cout;
   int nstrip, nrowblk;
+  // PRED (the prediction head, 32 -> cout <= 4 + bias + sigmoid): gy = g y (1 - y)
+  // is formed while the row is staged, from the incoming gradient and the saved
+  // output (fp32 RGBD pixels, N x H x W x 4)
+  const float* g;
+  const float* yf;
 };
 
 // elements per pixel in LDS: the channels, padded to an odd multiple of 32 bytes
@@ -77,7 +82,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const __bf16* p, int t, int g) {
 // CO16: Cout / 16; NW: waves; SW: strip width (pixels, a multiple of 32).
 // A workgroup takes 32 input channels (two tiles): blockIdx.y, and 16 CO16
 // output channels: blockIdx.z.
-template <int CO16, int NW, int SW>
+template <int CO16, int NW, int SW, bool PRED = false>
 __global__ __launch_bounds__(NW * 64) void conv3x3_wgrad_kernel(WgradArgs a) {
   constexpr int T = NW * 64;
   constexpr int CIB = 2;                 // input-channel tiles per workgroup
@@ -85,7 +90,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_wgrad_kernel(WgradArgs a) {
   constexpr int GS = padded(CO16 * 16);  // (gy row)
   constexpr int XROW = (SW + 2) * XS;
   constexpr int NXP = (SW + 2) * CIB * 2, XP = (NXP + T - 1) / T;  // 16-byte pieces
-  constexpr int NGP = SW * CO16 * 2, GP = (NGP + T - 1) / T;
+  constexpr int NGP = SW * CO16 * 2, GP = PRED ? 2 : (NGP + T - 1) / T;
   constexpr int NPAIR = 9 * CIB, PB = (NPAIR + NW - 1) / NW;
   __shared__ __attribute__((aligned(16))) __bf16 xs[4 * XROW];    // rows y - 1 .. y + 2: slot row & 3
   __shared__ __attribute__((aligned(16))) __bf16 gs[2 * SW * GS];  // rows y, y + 1: slot row & 1
@@ -100,6 +105,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_wgrad_kernel(WgradArgs a) {
   const int x0 = st * SW, y0 = rb * WG_ROWS, y1 = min(a.H, y0 + WG_ROWS);
   const int c0 = blockIdx.y * (CIB * 16);  // first input channel
   const int o0 = blockIdx.z * (CO16 * 16);  // first output channel
+  static_assert(!PRED || (CO16 == 1 && SW <= T), "PRED: one tile of output channels, a thread per pixel");
   const int H = a.H, W = a.W;
   const size_t img = (size_t)n * H;
 
@@ -127,6 +133,16 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_wgrad_kernel(WgradArgs a) {
     }
   };
   auto load_g = [&](int yy, u32x4 (&r)[GP]) {
+    if (PRED) {  // thread = pixel: the gradient and the saved output, fp32 RGBD
+      const int xx = x0 + tid;
+      r[0] = r[1] = u32x4{0u, 0u, 0u, 0u};
+      if (tid < SW && yy < y1 && xx < W) {
+        const size_t pix = (img + yy) * W + xx;
+        r[0] = __builtin_bit_cast(u32x4, *reinterpret_cast<const f32x4*>(a.g + 4 * pix));
+        r[1] = __builtin_bit_cast(u32x4, *reinterpret_cast<const f32x4*>(a.yf + 4 * pix));
+      }
+      return;
+    }
 #pragma unroll
     for (int k = 0; k < GP; ++k) {
       const int piece = tid + k * T;
@@ -140,6 +156,25 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_wgrad_kernel(WgradArgs a) {
   };
   auto store_g = [&](int yy, const u32x4 (&r)[GP]) {
     __bf16* const grow = gs + (yy & 1) * (SW * GS);
+    if (PRED) {
+      // gz = g y (1 - y) in fp32, stored as bf16 hi (channels 0 .. 3) + lo
+      // (channels 4 .. 7: what the rounding to bf16 left); channels 8 .. 15 zero.
+      // The matrix tile has 16 rows for 4 outputs: the second bf16 is free.
+      if (tid < SW) {
+        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        const f32x4 gv = __builtin_bit_cast(f32x4, r[0]), yv = __builtin_bit_cast(f32x4, r[1]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float gz = k < a.Cout ? gv[k] * yv[k] * (1.0f - yv[k]) : 0.0f;
+          const __bf16 hi = (__bf16)gz;
+          v[k] = hi;
+          v[4 + k] = (__bf16)(gz - (float)hi);
+        }
+        *reinterpret_cast<bf16x8*>(grow + tid * GS) = v;
+        *reinterpret_cast<u32x4*>(grow + tid * GS + 8) = u32x4{0u, 0u, 0u, 0u};
+      }
+      return;
+    }
 #pragma unroll
     for (int k = 0; k < GP; ++k) {
       const int piece = tid + k * T;
@@ -149,6 +184,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_wgrad_kernel(WgradArgs a) {
   };
 
   f32x4 acc[PB][CO16];
+  f32x4 accb = {0.f, 0.f, 0.f, 0.f};  // PRED: row sums of gz = the bias gradient (last wave)
 #pragma unroll
   for (int j = 0; j < PB; ++j)
 #pragma unroll
@@ -189,6 +225,11 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_wgrad_kernel(WgradArgs a) {
             acc[j][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bf, acc[j][m], 0, 0, 0);
         }
       }
+      if (PRED && wave == NW - 1) {  // B = ones: every column of D is the row sum
+        const __bf16 one = (__bf16)1.0f;
+        const bf16x8 ones = {one, one, one, one, one, one, one, one};
+        accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], ones, accb, 0, 0, 0);
+      }
     }
   };
   for (int y = y0; y < y1; y += 2) {
@@ -208,6 +249,28 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_wgrad_kernel(WgradArgs a) {
   }
 
   // accumulator of lane (t, g), register r: co = 16 m + 4 g + r, ci = 16 c + t
+  if (PRED) {
+    // rows 0 .. 3 (lanes g = 0) hold the hi parts, rows 4 .. 7 (g = 1) the lo
+    // parts: out[(co * 32 + ci) * 9 + tap], the bias gradient behind the weights
+    const int nout = a.Cout * 288 + a.Cout;
+    float* const out = a.part + (size_t)blockIdx.x * nout;
+#pragma unroll
+    for (int j = 0; j < PB; ++j) {
+      const int p = wave + j * NW;
+      const int tap = p / CIB, c = p - tap * CIB;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = acc[j][0][r] + __shfl_down(acc[j][0][r], 16);
+        if (p < NPAIR && g == 0 && r < a.Cout) out[(r * 32 + 16 * c + t) * 9 + tap] = v;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float v = accb[r] + __shfl_down(accb[r], 16);
+      if (wave == NW - 1 && lane == 0 && r < a.Cout) out[a.Cout * 288 + r] = v;
+    }
+    return;
+  }
   float* const out = a.part + (size_t)blockIdx.x * a.Cout * a.Cin * 9;
 #pragma unroll
   for (int j = 0; j < PB; ++j) {
@@ -261,6 +324,34 @@ int pixel_blocks(int N, int H, int W) {
 
 }  // namespace
 
+// The prediction head's weight + bias gradient (lsi_conv3x3_pred_bwd,
+// lsi_conv.hip): the same kernel with gy = g y (1 - y) formed while a row is
+// staged; g_wb = [cout * 288 + cout], written.
+size_t lsi_pred_wgrad_workspace_bytes(int N, int H, int W, int cout) {
+  return (size_t)pixel_blocks(N, H, W) * (cout * 288 + cout) * sizeof(float);
+}
+int lsi_pred_wgrad_launch(int N, int H, int W, int cout, const float* g, const float* y,
+                          const void* x, float* g_wb, void* workspace, size_t workspace_bytes,
+                          hipStream_t stream) {
+  if (workspace_bytes < lsi_pred_wgrad_workspace_bytes(N, H, W, cout)) return LSI_EWORKSPACE;
+  WgradArgs a;
+  a.x = reinterpret_cast<const __bf16*>(x);
+  a.gy = nullptr;
+  a.g = g;
+  a.yf = y;
+  a.part = reinterpret_cast<float*>(workspace);
+  a.N = N; a.H = H; a.W = W; a.Cin = 32; a.Cout = cout;
+  a.nstrip = (W + WG_SW - 1) / WG_SW;
+  a.nrowblk = (H + WG_ROWS - 1) / WG_ROWS;
+  const int nblk = pixel_blocks(N, H, W), nout = cout * 288 + cout;
+  hipLaunchKernelGGL((conv3x3_wgrad_kernel<1, 4, WG_SW, true>), dim3(nblk), dim3(256), 0, stream,
+                     a);
+  if (hipGetLastError() != hipSuccess) return LSI_ELAUNCH;
+  hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((nout + 63) / 64), dim3(1024), 0, stream,
+                     a.part, nblk, nout, g_wb);
+  return hipGetLastError() == hipSuccess ? LSI_OK : LSI_ELAUNCH;
+}
+
 extern "C" size_t lsi_conv3x3_wgrad_workspace_bytes(int32_t N, int32_t H, int32_t W,
                                                     int32_t cin, int32_t cout) {
   if (N <= 0 || H <= 0 || W <= 0 || cin <= 0 || cout <= 0) return 0;
@@ -282,6 +373,7 @@ extern "C" int lsi_conv3x3_wgrad(int32_t N, int32_t H, int32_t W, int32_t cin, i
   a.x = reinterpret_cast<const __bf16*>(x);
   a.gy = reinterpret_cast<const __bf16*>(gy);
   a.part = reinterpret_cast<float*>(workspace);
+  a.g = a.yf = nullptr;
   a.N = N; a.H = H; a.W = W; a.Cin = cin; a.Cout = cout;
   a.nstrip = (W + WG_SW - 1) / WG_SW;
   a.nrowblk = (H + WG_ROWS - 1) / WG_ROWS;

@@ -76,7 +76,7 @@ SIGNATURES = {
     'lsi_splat_generic_bwd': (ctypes.c_int, [_I32] * 6 + [_VP] * 6),
     'lsi_scatter_add': (ctypes.c_int, [_I32, _I64, _I64] + [_VP] * 4),
     'lsi_bilinear_fwd': (ctypes.c_int, [_I32] * 6 + [_VP] * 4),
-    'lsi_conv3x3_pred_bwd_workspace_bytes': (_SZ, []),
+    'lsi_conv3x3_pred_bwd_workspace_bytes': (_SZ, [_I32] * 3),
     'lsi_conv3x3_wgrad_workspace_bytes': (_SZ, [_I32] * 5),
     'lsi_conv3x3_wgrad': (ctypes.c_int, [_I32] * 5 + [_VP] * 4 + [_SZ, _VP]),
     'lsi_conv3x3_pred_bwd': (ctypes.c_int, [_I32] * 4 + [_VP] * 7 + [_SZ, _VP]),

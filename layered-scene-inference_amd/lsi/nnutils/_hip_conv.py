@@ -13,9 +13,9 @@ GEMM with K = all pixels) on lsi_conv3x3_wgrad (csrc/lsi_conv_wgrad.hip: both
 operands transposed by the LDS transpose read), which also takes the weight
 gradients of the other 3x3 layers at full and half resolution
 (conv3x3_lib_own_wgrad: forward and data gradient on MIOpen).  The prediction head is hand-written end to
-end: lsi_conv3x3_pred_bwd forms sigmoid'(z) * g in registers, computes the data
-gradient on the matrix cores and the 4 x 288 + 4 weight / bias gradients on the
-vector unit.
+end: lsi_conv3x3_pred_bwd forms sigmoid'(z) * g in registers and computes the
+data gradient (K = 9 taps x 4 channels) and the 4 x 288 + 4 weight / bias
+gradients (K = pixels) on the matrix cores.
 """
 import torch
 
@@ -166,18 +166,10 @@ def conv3x3_lib_own_wgrad(x, weight):
   return _Conv3x3LibOwnWgrad.apply(x, weight)
 
 
-_PRED_WS = {}
-
-
-def _pred_workspace(dev):
-  """Partial sums of the head's weight gradient: one buffer per (device,
-  stream), never dropped (kernels of earlier launches may still use it)."""
-  key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
-  ws = _PRED_WS.get(key)
-  if ws is None:
-    nbytes = _C.lib().lsi_conv3x3_pred_bwd_workspace_bytes()
-    ws = _PRED_WS[key] = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=dev)
-  return ws
+def _pred_workspace(dev, n, h, w):
+  """Partial sums of the head's weight gradient (the same never-dropped buffers
+  as the other weight gradients)."""
+  return _wgrad_workspace(dev, _C.lib().lsi_conv3x3_pred_bwd_workspace_bytes(n, h, w))
 
 
 class _Conv3x3C32Sigmoid(torch.autograd.Function):
@@ -201,8 +193,9 @@ class _Conv3x3C32Sigmoid(torch.autograd.Function):
     if cout == 4 and g.dtype == torch.float32:
       # lsi_conv3x3_pred_bwd: gz = g * y * (1 - y) is formed in registers; the
       # data gradient on the matrix cores (K = 9 taps x 4 channels), weight and
-      # bias gradients on the vector unit (fp32 gz; per-workgroup partials in the
-      # workspace, folded by a second kernel)
+      # bias gradients on the matrix cores too (K = pixels, gz as bf16 hi + lo;
+      # partial sums of the pixel blocks in the workspace, folded by a second
+      # kernel)
       g = g.contiguous(memory_format=torch.channels_last)
       dev = x.device
       gx = (torch.empty((n, 32, h, w), dtype=torch.bfloat16, device=dev,
@@ -212,7 +205,7 @@ class _Conv3x3C32Sigmoid(torch.autograd.Function):
       gwb = ws = None
       if want_w:
         gwb = torch.empty((cout * 288 + cout,), dtype=torch.float32, device=dev)
-        ws = _pred_workspace(dev)
+        ws = _pred_workspace(dev, n, h, w)
       wt = weight.detach()
       if wt.dtype != torch.float32 or not wt.is_contiguous():
         wt = wt.float().contiguous()

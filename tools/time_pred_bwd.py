@@ -12,7 +12,7 @@ y = torch.rand(n, 4, h, w, device=dev).contiguous(memory_format=torch.channels_l
 wt = torch.randn(4, 32, 3, 3, device=dev) * 0.1
 gx = torch.empty(n, 32, h, w, device=dev, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
 gwb = torch.zeros(4 * 288 + 4, device=dev)
-ws = torch.empty(_C.lib().lsi_conv3x3_pred_bwd_workspace_bytes() // 4, device=dev)
+ws = torch.empty(_C.lib().lsi_conv3x3_pred_bwd_workspace_bytes(n, h, w) // 4, device=dev)
 lib = _C.lib()
 def run(a, b):
   rc = lib.lsi_conv3x3_pred_bwd(n, h, w, 4, _C.ptr(g), _C.ptr(y), _C.ptr(x), _C.ptr(wt),
