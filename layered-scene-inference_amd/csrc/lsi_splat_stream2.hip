@@ -1681,8 +1681,12 @@ bool s2_choose(const LsiSplatDesc* d, int wmax, bool both, S2Plan* plan, bool* w
   S2Plan narrow, wideplan;
   const int rc_n = d->tune_threads > LSI_S2_MAXT
                        ? LSI_EINVAL : s2_plan(d, wmax, LSI_S2_MAXT / 64, both, &narrow);
+  // (tune_threads > 768 names the build, not a wave count: as many of the 16
+  // waves as fit next to the tile)
+  LsiSplatDesc dw = *d;
+  if (dw.tune_threads > LSI_S2_MAXT) dw.tune_threads = 0;
   const int rc_w = (d->tune_threads > 0 && d->tune_threads <= LSI_S2_MAXT)
-                       ? LSI_EINVAL : s2_plan(d, wmax, 1024 / 64, both, &wideplan);
+                       ? LSI_EINVAL : s2_plan(&dw, wmax, 1024 / 64, both, &wideplan);
   bool w = rc_w == LSI_OK &&
            (rc_n != LSI_OK || (wideplan.nw > LSI_S2_MAXT / 64 &&
                                narrow.nunit < 2 * (LSI_S2_MAXT / 64)));
