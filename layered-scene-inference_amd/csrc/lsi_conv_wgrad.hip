@@ -50,7 +50,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
-constexpr int WG_ROWS = 32;  // rows per pixel block
+#ifndef LSI_WG_ROWS
+#define LSI_WG_ROWS 32
+#endif
+constexpr int WG_ROWS = LSI_WG_ROWS;  // rows per pixel block
 
 struct WgradArgs {
   const __bf16* x;   // N x H x W x Cin

@@ -7,9 +7,11 @@ sys.path.insert(0, os.path.join(ROOT, 'layered-scene-inference_amd'))
 from lsi import _C
 dev = torch.device('cuda:0')
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+quick = len(sys.argv) > 2  # second argument: the two training shapes only, no reference
 lib = _C.lib()
-for cin, cout, h, w in ((32, 32, 256, 768), (96, 64, 128, 384), (192, 128, 64, 192), (256, 128, 32, 96),
-                        (128, 128, 32, 96), (512, 256, 16, 48), (32, 96, 70, 100)):
+SHAPES = ((32, 32, 256, 768), (96, 64, 128, 384), (192, 128, 64, 192), (256, 128, 32, 96),
+          (128, 128, 32, 96), (512, 256, 16, 48), (32, 96, 70, 100))
+for cin, cout, h, w in (SHAPES[:2] if quick else SHAPES):
   x = torch.randn(n, cin, h, w, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
   g = torch.randn(n, cout, h, w, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
   gw = torch.empty(cout, cin, 3, 3, device=dev)
@@ -24,8 +26,11 @@ for cin, cout, h, w in ((32, 32, 256, 768), (96, 64, 128, 384), (192, 128, 64, 1
     return torch.ops.aten.convolution_backward(g, x, wt, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
                                                [False, True, False])[1]
   own()
-  want = torch.nn.grad.conv2d_weight(x.float(), (cout, cin, 3, 3), g.float(), padding=1)
-  err = float((gw - want).abs().max()); scale = float(want.abs().max())
+  if quick:
+    err = scale = float('nan')
+  else:
+    want = torch.nn.grad.conv2d_weight(x.float(), (cout, cin, 3, 3), g.float(), padding=1)
+    err = float((gw - want).abs().max()); scale = float(want.abs().max())
   res = []
   for fn in (own, aten):
     for _ in range(3): fn()
