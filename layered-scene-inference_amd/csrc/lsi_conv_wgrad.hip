@@ -18,7 +18,7 @@
 // pixel-major LDS rows that are filled with plain 16-byte copies.
 //
 // Workgroup = (image, strip of SW columns, block of 32 rows) x (block of 32
-// input channels); it walks down its rows with three input rows (one-pixel halo
+// input channels) x (block of 32 or 64 output channels); it walks down its rows with three input rows (one-pixel halo
 // left and right, zero outside the image) and the current gy row in LDS (a
 // fourth x row and a second gy row being filled), the loads of the row after
 // next in flight in registers while a row is multiplied: one barrier per row.
@@ -27,6 +27,11 @@
 // accumulators = the wave's share of the Cout x 32 x 9 result, in registers for
 // the whole block.  Pixel blocks write partial results, conv_wgrad_reduce_kernel
 // sums them into the layer's [Cout][Cin][3][3] fp32 gradient.
+//
+// The prediction head (32 -> 4 + bias + sigmoid, nets.py:150-158) uses the same
+// kernel (PRED): its gy = g y (1 - y) is formed while the row is staged, stored
+// as bf16 hi + lo in the tile's spare rows, the bias gradient is one more
+// product with a fragment of ones (lsi_conv3x3_pred_bwd, lsi_conv.hip).
 //
 // LDS bank layout: a transpose read moves 32 bytes per (row, group); the rows a
 // pass of 32 lanes touches (two groups x four rows) must fall into eight
