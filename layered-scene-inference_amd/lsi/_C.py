@@ -151,11 +151,15 @@ def require_device(*tensors):
 
 
 def ptr(t):
-  return None if t is None else ctypes.c_void_p(t.data_ptr())
+  """Device address for a c_void_p parameter: a plain int (every entry point has
+  its argtypes declared in SIGNATURES, so ctypes converts it itself -- a
+  c_void_p object per argument costs half a microsecond of an eager step that
+  makes hundreds of these calls)."""
+  return None if t is None else t.data_ptr()
 
 
 def stream_ptr(device):
-  return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+  return torch.cuda.current_stream(device).cuda_stream
 
 
 def bg_weight(bg_layer_disp, max_disp, zbuf_scale):

@@ -12,12 +12,21 @@ _WS_LOCK = threading.Lock()
 _WS_FLOATS = 1 << 20      # 4 MiB: covers every layer of the 256 x 768 networks
 
 
-def _workspace(dev, need):
+_WS_NEED = {}
+
+
+def _workspace(dev, stream, npix, c, bf16, groups):
   """Zero-filled once per (device, stream), then kept: the kernels leave their
   arrival counter zero, and calls on one stream are ordered.  A buffer that has
   been handed out is never freed (a captured HIP graph has its address baked
   in): a larger need gets a further buffer, the old one stays alive."""
-  key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+  need = _WS_NEED.get(groups)     # (the size depends on the groups only)
+  if need is None:
+    need = _WS_NEED[groups] = int(_C.lib().lsi_bn_workspace_floats(npix, c, bf16, groups))
+  key = (dev.index, stream)
+  kept = _WS.get(key)
+  if kept is not None and kept[-1].numel() >= need:   # (the largest is last)
+    return kept[-1]
   with _WS_LOCK:
     kept = _WS.setdefault(key, [])
     for ws in kept:
@@ -57,15 +66,19 @@ class _BnRelu(torch.autograd.Function):
     npix = (n // groups) * h * w          # per group: its own statistics
     bf16 = int(x.dtype == torch.bfloat16)
     lib = _C.lib()
-    ws = _workspace(dev, int(lib.lsi_bn_workspace_floats(npix, c, bf16, groups)))
-    y = torch.empty_like(x, memory_format=torch.channels_last)
+    stream = _C.stream_ptr(dev)
+    ws = _workspace(dev, stream, npix, c, bf16, groups)
+    y = torch.empty_like(x)               # (x is channels-last: supported())
     mean_rstd = torch.empty((groups, 2, c), dtype=torch.float32, device=dev)
-    beta_f = beta.detach().float().contiguous()
+    beta_f = beta.detach()
+    if beta_f.dtype != torch.float32 or not beta_f.is_contiguous():
+      beta_f = beta_f.float().contiguous()
     # (N-major storage: the groups are consecutive blocks of npix * C values)
-    rc = lib.lsi_bn_relu_fwd(_C.ptr(x), _C.ptr(y), _C.ptr(beta_f), _C.ptr(ws),
-                             _C.ptr(mean_rstd), npix, c, bf16, int(relu),
-                             float(eps), groups, _C.stream_ptr(dev))
-    _C.check(rc, 'lsi_bn_relu_fwd')
+    rc = lib.lsi_bn_relu_fwd(x.data_ptr(), y.data_ptr(), beta_f.data_ptr(), ws.data_ptr(),
+                             mean_rstd.data_ptr(), npix, c, bf16, int(relu),
+                             float(eps), groups, stream)
+    if rc:
+      _C.check(rc, 'lsi_bn_relu_fwd')
     ctx.save_for_backward(x, beta_f, mean_rstd)
     ctx.relu = int(relu)
     ctx.groups = groups
@@ -79,15 +92,20 @@ class _BnRelu(torch.autograd.Function):
     groups = ctx.groups
     npix = (n // groups) * h * w
     bf16 = int(x.dtype == torch.bfloat16)
-    dy = dy.to(x.dtype).contiguous(memory_format=torch.channels_last)
+    if dy.dtype != x.dtype:
+      dy = dy.to(x.dtype)
+    if not dy.is_contiguous(memory_format=torch.channels_last):
+      dy = dy.contiguous(memory_format=torch.channels_last)
     lib = _C.lib()
-    ws = _workspace(dev, int(lib.lsi_bn_workspace_floats(npix, c, bf16, groups)))
-    dx = torch.empty_like(x, memory_format=torch.channels_last)
+    stream = _C.stream_ptr(dev)
+    ws = _workspace(dev, stream, npix, c, bf16, groups)
+    dx = torch.empty_like(x)
     dbeta = torch.empty((c,), dtype=torch.float32, device=dev)
-    rc = lib.lsi_bn_relu_bwd(_C.ptr(x), _C.ptr(dy), _C.ptr(mean_rstd),
-                             _C.ptr(beta_f), _C.ptr(dx), _C.ptr(dbeta), _C.ptr(ws),
-                             npix, c, bf16, ctx.relu, groups, _C.stream_ptr(dev))
-    _C.check(rc, 'lsi_bn_relu_bwd')
+    rc = lib.lsi_bn_relu_bwd(x.data_ptr(), dy.data_ptr(), mean_rstd.data_ptr(),
+                             beta_f.data_ptr(), dx.data_ptr(), dbeta.data_ptr(), ws.data_ptr(),
+                             npix, c, bf16, ctx.relu, groups, stream)
+    if rc:
+      _C.check(rc, 'lsi_bn_relu_bwd')
     return dx, dbeta, None, None, None
 
 
