@@ -443,8 +443,10 @@ int lsi_bn_relu_bwd(const void* x, const void* dy, const float* mean_rstd,
  * the LDI heads.
  *   mode 0  `upcnv1b` (nets.py:104-111): cout = 16 or 32, output bf16
  *           N x H x W x cout (before batch norm);
- *   mode 1  `pred_l` (nets.py:150-158): cout <= 4, bias, sigmoid, channel 3
- *           times scale3, output fp32 N x H x W x 4 -- RGBD pixels;
+ *   mode 1  `pred_l` (nets.py:150-158): cout <= 4, bias, sigmoid, output fp32
+ *           N x H x W x 4 -- RGBD pixels; scale3 must be 1 (LSI_EINVAL
+ *           otherwise: lsi_conv3x3_pred_bwd reads sigmoid' off the stored
+ *           output; the caller multiplies the disparities by max_disp);
  *   mode 2  the data gradient of mode 0 with cout = 32: the same convolution
  *           with the kernel transposed and flipped (x = the incoming gradient).
  *   x: bf16 N x H x W x 32, channels innermost (torch channels_last), 16-byte

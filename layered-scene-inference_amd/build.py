@@ -47,6 +47,7 @@ def _stale(target, deps):
 
 
 SO_HOOKS = os.path.join(PKG, 'liblsi_hip_hooks.so')
+LAST_BUILD = {}   # object / library -> 'compiled' | 'linked' | 'reused' (last build() call)
 
 
 def build(force=False, verbose=False, hooks=False):
@@ -58,9 +59,13 @@ def build(force=False, verbose=False, hooks=False):
   ext = '.hooks.o' if hooks else '.o'
   flags = HIPCC_FLAGS + (['-DLSI_STREAM_HOOKS=1'] if hooks else [])
   objs, jobs = [], []
+  report = LAST_BUILD
+  report.clear()
   for src in srcs:
     obj = src[:-4] + ext
-    if force or _stale(obj, [src] + HEADERS):
+    stale = force or _stale(obj, [src] + HEADERS)
+    report[os.path.basename(obj)] = 'compiled' if stale else 'reused'
+    if stale:
       cmd = [hipcc()] + flags + ['-c', src, '-o', obj]
       if verbose:
         print(' '.join(cmd))
@@ -69,7 +74,9 @@ def build(force=False, verbose=False, hooks=False):
   for cmd, proc in jobs:
     if proc.wait() != 0:
       raise subprocess.CalledProcessError(proc.returncode, cmd)
-  if force or _stale(so, objs):
+  relink = force or _stale(so, objs)
+  report[os.path.basename(so)] = 'linked' if relink else 'reused'
+  if relink:
     cmd = [hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', so] + objs
     if verbose:
       print(' '.join(cmd))
@@ -80,3 +87,4 @@ def build(force=False, verbose=False, hooks=False):
 if __name__ == '__main__':
   print(build(force='--force' in sys.argv, verbose=True,
               hooks='--hooks' in sys.argv))
+  print(LAST_BUILD)

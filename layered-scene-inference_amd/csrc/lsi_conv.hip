@@ -271,6 +271,9 @@ extern "C" int lsi_conv3x3_c32_fwd(int32_t N, int32_t H, int32_t W, int32_t cout
     return LSI_EINVAL;
   if (!x || !weight || !out) return LSI_ENULL;
   if (((uintptr_t)x & 15) || ((uintptr_t)out & 15)) return LSI_EINVAL;
+  // lsi_conv3x3_pred_bwd forms sigmoid' = y (1 - y) from the stored output: a
+  // scaled channel 3 would give wrong gradients (the caller scales afterwards)
+  if (pred && scale3 != 1.0f) return LSI_EINVAL;
   ConvArgs a;
   a.x = reinterpret_cast<const __bf16*>(x);
   a.w = weight;

@@ -11,6 +11,7 @@ output) -- the kernels take element strides, nothing is copied.
 import collections
 import ctypes
 import threading
+import weakref
 
 import torch
 
@@ -118,8 +119,10 @@ def _device_matrices(src2trg_mat, mat_host, dev):
   if src2trg_mat.is_cuda or dev.type != 'cuda':
     # (a CPU `dev`: the call is about to fail in require_device -- no CPU path)
     return src2trg_mat.detach().to(dev, torch.float32)
-  host = (mat_host if mat_host is not None else
-          src2trg_mat.detach().to('cpu', torch.float32)).contiguous()
+  host = (mat_host if mat_host is not None else src2trg_mat)
+  host = host.detach().to('cpu', torch.float32).contiguous()
+  if host.dim() != 3 or tuple(host.shape[1:]) != (4, 4):
+    raise ValueError('projection matrices must be B x 4 x 4, got %s' % (tuple(host.shape),))
   key = (dev.index, host.numpy().tobytes())
   with _WS_LOCK:
     hit = _MAT_CACHE.get(key)
@@ -379,6 +382,60 @@ def forward_splat_matrix(ldi_src, src2trg_mat, compose_layers=True,
   return img, wts
 
 
+_HOST_COPIES = {}     # id(tensor) -> (weakref, version, fp32 CPU copy)
+_GRID_CHECKED = {}    # id(tensor) -> (weakref, version)
+
+
+def _host_copy(x):
+  """fp32 CPU copy of a camera tensor.  A tensor on the GPU costs one
+  synchronising device-to-host copy (the kernel choice needs the matrices on
+  the host); the copy is remembered for as long as THIS tensor object is alive
+  and its version counter has not moved -- never by address, which the caching
+  allocator hands out again -- so a caller that renders with the same camera
+  tensors again (the two directions of a pair, an evaluation loop) pays it
+  once."""
+  if not x.is_cuda:
+    return x.detach().to('cpu', torch.float32)
+  key = id(x)
+  hit = _HOST_COPIES.get(key)
+  if hit is not None and hit[0]() is x and hit[1] == x._version:
+    return hit[2]
+  host = x.detach().to('cpu', torch.float32)
+  _HOST_COPIES[key] = (weakref.ref(x, lambda _r, k=key: _HOST_COPIES.pop(k, None)),
+                       x._version, host)
+  return host
+
+
+def _check_pixel_grid(pixel_coords_src, disps):
+  """The kernels generate the source coordinates (x + .5, y + .5, 1) themselves;
+  the reference renders whatever `pixel_coords_src` holds (ldi.py:134).  Every
+  reference call site passes helpers.pixel_coords; anything else is refused
+  rather than silently rendered from the grid: shape and the four corner
+  pixels of every batch element are compared (once per tensor object and
+  version).  None means the grid."""
+  if pixel_coords_src is None:
+    return
+  p = pixel_coords_src
+  key = id(p)
+  hit = _GRID_CHECKED.get(key)
+  if hit is not None and hit[0]() is p and hit[1] == p._version:
+    return
+  b, h, w = disps.shape[1:4]
+  if tuple(p.shape) != (b, h, w, 3):
+    raise ValueError('pixel_coords_src must be B x H x W x 3 = %s, got %s'
+                     % ((b, h, w, 3), tuple(p.shape)))
+  corners = p.detach()[:, [0, 0, h - 1, h - 1], [0, w - 1, 0, w - 1], :].to('cpu', torch.float32)
+  want = torch.tensor([[0.5, 0.5, 1.0], [w - 0.5, 0.5, 1.0], [0.5, h - 0.5, 1.0],
+                       [w - 0.5, h - 0.5, 1.0]])
+  if not torch.equal(corners, want.expand(b, 4, 3)):
+    raise NotImplementedError(
+        'forward_splat renders from the pixel-centre grid helpers.pixel_coords('
+        'B, H, W) (what every call site of the reference passes, '
+        'train_utils.py:86-88); other source coordinates are not supported')
+  _GRID_CHECKED[key] = (weakref.ref(p, lambda _r, k=key: _GRID_CHECKED.pop(k, None)),
+                        p._version)
+
+
 def forward_splat(ldi_src,
                   pixel_coords_src,
                   k_s,
@@ -396,10 +453,10 @@ def forward_splat(ldi_src,
 
   Args:
     ldi_src: [textures, masks, disps]; masks may be None (all ones).
-    pixel_coords_src: B x H x W x 3 pixel-centre grid.  The kernels generate
-        (x+0.5, y+0.5, 1) themselves -- the only value the reference's callers
-        pass (helpers.pixel_coords, train_utils.py:86-88); the argument is kept
-        for signature compatibility.
+    pixel_coords_src: B x H x W x 3 pixel-centre grid (or None).  The kernels
+        generate (x+0.5, y+0.5, 1) themselves -- the only value the reference's
+        callers pass (helpers.pixel_coords, train_utils.py:86-88); a tensor
+        that is not that grid raises (_check_pixel_grid).
     k_s, k_t: B x 3 x 3 intrinsics; rot: B x 3 x 3; t: B x 3 x 1.  Camera
         tensors on the CPU avoid a device->host copy when choosing the kernel.
     focal_disps: optional B x 1 x 1 x 1 (reference ldi.py:130-143, lytro data):
@@ -412,10 +469,9 @@ def forward_splat(ldi_src,
     trg_img nl x B x Ht x Wt x 3, trg_wts nl x B x Ht x Wt x 1 (un-normalised)
     [, trg_disp nl x B x Ht x Wt x 1]; nl = 1 if compose_layers else L.
   """
-  del pixel_coords_src
+  _check_pixel_grid(pixel_coords_src, ldi_src[2])
   mat_host = projection.forward_projection_matrix(
-      k_s.detach().to('cpu', torch.float32), k_t.detach().to('cpu', torch.float32),
-      rot.detach().to('cpu', torch.float32), t.detach().to('cpu', torch.float32))
+      _host_copy(k_s), _host_copy(k_t), _host_copy(rot), _host_copy(t))
   if focal_disps is not None:
     tex, masks, disps = ldi_src
     f = focal_disps.detach().to(torch.float32).reshape(-1)

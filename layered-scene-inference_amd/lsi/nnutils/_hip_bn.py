@@ -20,9 +20,13 @@ def _workspace(dev, stream, npix, c, bf16, groups):
   arrival counter zero, and calls on one stream are ordered.  A buffer that has
   been handed out is never freed (a captured HIP graph has its address baked
   in): a larger need gets a further buffer, the old one stays alive."""
-  need = _WS_NEED.get(groups)     # (the size depends on the groups only)
+  nkey = (c, bf16, groups)
+  need = _WS_NEED.get(nkey)
   if need is None:
-    need = _WS_NEED[groups] = int(_C.lib().lsi_bn_workspace_floats(npix, c, bf16, groups))
+    need = int(_C.lib().lsi_bn_workspace_floats(npix, c, bf16, groups))
+    if need <= 0:               # (an unsupported shape: never cached; the entry
+      return _dummy_ws(dev)     #  point itself reports LSI_EINVAL)
+    _WS_NEED[nkey] = need
   key = (dev.index, stream)
   kept = _WS.get(key)
   if kept is not None and kept[-1].numel() >= need:   # (the largest is last)
@@ -34,6 +38,16 @@ def _workspace(dev, stream, npix, c, bf16, groups):
         return ws
     ws = torch.zeros((max(need, _WS_FLOATS),), dtype=torch.float32, device=dev)
     kept.append(ws)
+  return ws
+
+
+_DUMMY = {}
+
+
+def _dummy_ws(dev):
+  ws = _DUMMY.get(dev.index)
+  if ws is None:
+    ws = _DUMMY[dev.index] = torch.zeros((16,), dtype=torch.float32, device=dev)
   return ws
 
 

@@ -168,18 +168,14 @@ class SlimConv2d(nn.Module):
         if head:    # bias + sigmoid inside the kernel, fp32 RGBD pixels out
           return _hip_conv.conv3x3_c32_sigmoid(x, self.conv.weight, self.conv.bias)
         x = _hip_conv.conv3x3_c32(x, self.conv.weight)
-        if self.activation == 'relu':
-          return _bn_relu(self.bn, x)
-        return self.bn(x)
+        return self._bn_act(x)
       if (self.bn is not None and torch.is_grad_enabled() and
           self.conv.weight.requires_grad and
           _hip_conv.wgrad_supported(x, cin, cout, self.k, self.stride)):
         # forward and data gradient on the library, weight gradient on the
         # matrix-core kernel (K = pixels)
         x = _hip_conv.conv3x3_lib_own_wgrad(x, self.conv.weight)
-        if self.activation == 'relu':
-          return _bn_relu(self.bn, x)
-        return self.bn(x)
+        return self._bn_act(x)
     ph = _same_pad(x.shape[2], self.k, self.stride)
     pw = _same_pad(x.shape[3], self.k, self.stride)
     # Symmetric SAME padding (the stride-1 layers) goes into the convolution:
@@ -195,6 +191,10 @@ class SlimConv2d(nn.Module):
       if ph[0] or ph[1] or pw[0] or pw[1]:
         x = F.pad(x, (pw[0], pw[1], ph[0], ph[1]))
       x = self.conv(x)
+    return self._bn_act(x)
+
+  def _bn_act(self, x):
+    """Batch norm (if any) and the activation behind the convolution."""
     if self.bn is not None and self.activation == 'relu':
       return _bn_relu(self.bn, x)
     if self.bn is not None:

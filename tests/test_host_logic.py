@@ -180,3 +180,32 @@ def test_host_projection_matrices_equal_the_torch_ops_bit_for_bit(built_lib):
       slow = fn(k[None], k2[None], rot[None], t[None])[0]   # other ranks: torch
       assert fast.shape == (b, 4, 4) and torch.equal(fast, slow)
   assert projection._host_matrices(k.double(), k2, rot, t, False) is None
+
+
+def test_forward_splat_refuses_source_coordinates_that_are_not_the_pixel_grid():
+  """reference ldi.py:134 renders the caller's pixel_coords_src; the kernels
+  generate the grid, so anything else must raise, not be ignored."""
+  disps = torch.zeros(2, 3, 4, 6, 1)
+  grid = helpers.pixel_coords(3, 4, 6)
+  ldi._check_pixel_grid(None, disps)
+  ldi._check_pixel_grid(grid, disps)
+  ldi._check_pixel_grid(grid, disps)          # (second call: remembered)
+  with pytest.raises(ValueError):
+    ldi._check_pixel_grid(helpers.pixel_coords(3, 4, 5), disps)
+  with pytest.raises(NotImplementedError):
+    ldi._check_pixel_grid(grid + 0.25, disps)
+  moved = grid.clone()
+  ldi._check_pixel_grid(moved, disps)
+  moved[1, 3, 5, 0] += 1.0                    # in-place edit: the version moves
+  with pytest.raises(NotImplementedError):
+    ldi._check_pixel_grid(moved, disps)
+
+
+def test_host_copy_of_cameras_follows_the_tensor_not_its_address():
+  k = torch.eye(3).expand(2, 3, 3).contiguous()
+  a = ldi._host_copy(k)
+  assert a.dtype == torch.float32 and torch.equal(a, k)
+  k64 = k.double()
+  assert ldi._host_copy(k64).dtype == torch.float32
+  # (the cache is only used for GPU tensors; CPU tensors are converted per call)
+  assert not ldi._HOST_COPIES
