@@ -78,8 +78,6 @@ struct S2Args {
   int hf;                          // halo rows first (see BandOrder)
   int ep;                          // epilogue stores: 0 scalar, 1 16-byte, 2 16-byte write-through, 3 16-byte nt
   int nsplit, lsub;                // units handed out lsub layers per ticket
-  int prog;                        // rows written as they complete (no closing barrier)
-  int ord;                         // 1: segment-major ticket order behind the halo units
   float inv_gx, inv_nseg;
   long long* stamps;  // S2X_STAMPS build: [workgroup][wave][8] wall-clock ticks
 };
@@ -154,31 +152,6 @@ __device__ __forceinline__ Unit s2_unit_of(const S2Args& a, const BandOrder& o, 
 // unit -> row of the band (may be a padding row >= nsrc) and segment
 __device__ __forceinline__ int s2_unit_row(const S2Args& a, const BandOrder& o, int u,
                                            int& sg) {
-  if (a.ord == 1) {
-    // Segment-major: behind the halo units, all rows of segment 0 (in the
-    // interleaved row order), then all rows of segment 1, ...  Consecutive
-    // tickets -- and the LAST tickets of a band, the ones in flight when the
-    // band runs dry -- then belong to different rows a fifth of the band apart:
-    // their merges want different row locks.  (Row-major: the last tickets are
-    // the segments of one or two rows.)
-    const int nh = 4 * o.hf * a.nseg;
-    if (u < nh) {
-      sg = u >> 2;
-      const int hr = u & 3;
-      return (hr & 1) ? o.nsrc - 1 - (hr >> 1) : (hr >> 1);
-    }
-    const int nrow = o.nrow_pad - 4 * o.hf;   // rows per segment pass (padded)
-    const int v = u - nh;
-    const int sgv = s2_div_small(v, nrow, __builtin_amdgcn_rcpf((float)nrow));
-    const int yi = v - sgv * nrow;
-    sg = sgv;
-    int r = yi;
-    if (a.ilv) {
-      const int y5 = (int)(((float)yi + 0.5f) * 0.2f);
-      r = (yi - 5 * y5) * o.q5 + y5;
-    }
-    return r < o.nin ? 2 * o.hf + r : o.nsrc;
-  }
   int yi = (int)(((float)u + 0.5f) * a.inv_nseg);
   sg = u - yi * a.nseg;
   int base = 0;
@@ -427,38 +400,6 @@ __device__ __forceinline__ void s2_store4(float* p, float x, float y, float z, f
     *reinterpret_cast<v4*>(p) = v;
   }
 }
-// One finished tile row -> the composed view (ldi.py:167-174): whole 128-byte
-// lines per store instruction, as the closing epilogue writes them (lane q:
-// floats 4q .. 4q + 3 of the row's colour plane = cells f / 3 and f / 3 + 1).
-// One wave; out of line (called once per tile row).  The tile row is handed
-// over as an LDS byte offset (see s2_flush_queue).
-__device__ __noinline__ void s2_write_row(unsigned trow_off, float* oi, float* ow, int Wt,
-                                          float lbg, int lane, int ep_st) {
-  typedef __attribute__((address_space(3))) float LdsFc;
-  const LdsFc* const t = reinterpret_cast<const LdsFc*>(trow_off);
-  const int nq = (3 * Wt) >> 2;
-  for (int q = lane; q < nq; q += 64) {
-    const unsigned f = 4u * (unsigned)q;
-    const unsigned c0 = __umulhi(f, 0xAAAAAAABu) >> 1;  // f / 3
-    const unsigned o = f - 3u * c0;
-    const unsigned c1 = min(c0 + 1u, (unsigned)Wt - 1u);
-    const float ax_ = t[4 * c0], ay_ = t[4 * c0 + 1], az_ = t[4 * c0 + 2], aw_ = t[4 * c0 + 3];
-    const float bx_ = t[4 * c1], by_ = t[4 * c1 + 1], bz_ = t[4 * c1 + 2], bw_ = t[4 * c1 + 3];
-    const float ra = __builtin_amdgcn_rcpf(safe_den(aw_ + lbg));
-    const float rb_ = __builtin_amdgcn_rcpf(safe_den(bw_ + lbg));
-    const float ax = (ax_ + lbg) * ra, ay = (ay_ + lbg) * ra, az = (az_ + lbg) * ra;
-    const float bx = (bx_ + lbg) * rb_, by = (by_ + lbg) * rb_, bz = (bz_ + lbg) * rb_;
-    const float v0 = o == 0 ? ax : (o == 1 ? ay : az);
-    const float v1 = o == 0 ? ay : (o == 1 ? az : bx);
-    const float v2 = o == 0 ? az : (o == 1 ? bx : by);
-    const float v3 = o == 0 ? bx : (o == 1 ? by : bz);
-    s2_store4(oi + f, v0, v1, v2, v3, ep_st);
-  }
-  for (int q = lane; q < (Wt >> 2); q += 64)
-    s2_store4(ow + 4 * q, t[16 * q + 3] + lbg, t[16 * q + 7] + lbg, t[16 * q + 11] + lbg,
-              t[16 * q + 15] + lbg, ep_st);
-}
-
 struct Px { float4 d4, t0, t1, t2; };
 typedef float s2_f4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 s2_ld_nt(const float* p) {
@@ -516,10 +457,8 @@ __global__ __launch_bounds__(MAXT) void splat_stream2_kernel(S2Args a) {
   TaskX* const taskx = reinterpret_cast<TaskX*>(task + a.cap);    // [cap]
   int* const ctl = reinterpret_cast<int*>(taskx + a.cap);         // [4]: ticket, table arrivals
   int* const locks = ctl + 4;                                     // [NT * R]
-  int* const rowcnt = locks + NT * R;                             // [R]: merges a row still expects (+1 until the table is complete)
-  int* const rdy = rowcnt + R;                                    // [R]: finished rows (row + 1) in completion order
   const int Q = a.qcap;
-  float4* const qv_all = reinterpret_cast<float4*>(ctl + ((4 + NT * R + 2 * R + 3) & ~3));
+  float4* const qv_all = reinterpret_cast<float4*>(ctl + ((4 + NT * R + 3) & ~3));
   int* const qc_all = reinterpret_cast<int*>(qv_all + NW * Q);
   unsigned char* const sc_all = reinterpret_cast<unsigned char*>(qc_all + NW * Q);
   int* const clk = reinterpret_cast<int*>(sc_all + ((NW * WMAX + 15) & ~15));  // CELL: [NT*R*Wt]
@@ -615,10 +554,7 @@ __global__ __launch_bounds__(MAXT) void splat_stream2_kernel(S2Args a) {
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     const int ncl = BOTH ? NT * R * Wt : rows * Wt;
     for (int i = tid; i < NW * WCELLS + ncl; i += T) rb_all[i] = z4;  // windows + tiles
-    // tickets, arrivals, [2] rows finished, [3] rows taken for writing, locks,
-    // row counts (1: the table's own token), finished-row list
-    for (int i = tid; i < 4 + NT * R + 2 * R; i += T)
-      ctl[i] = (i == 0) ? NW : ((i >= 4 + NT * R && i < 4 + NT * R + R) ? 1 : 0);
+    for (int i = tid; i < 4 + NT * R; i += T) ctl[i] = (i == 0) ? NW : 0;  // tickets, arrivals, locks
     if (CELL)
       for (int i = tid; i < ncl; i += T) clk[i] = 0;
     for (int i = tid; i < (NW * WMAX + 3) / 4; i += T)  // the waves' cell-rank tables
@@ -697,41 +633,6 @@ __global__ __launch_bounds__(MAXT) void splat_stream2_kernel(S2Args a) {
   // rows than the planner assumed (it does not see the matrices)
   const int CAPT = a.cap;
   int chunk0 = 0, nchunk = min(CAPT, ntask);
-  // Rows written by the waves that have run dry (a.prog; the composed-only
-  // instance with whole-line stores and one table chunk).  rowcnt[r] = merges
-  // tile row r still expects, plus one token of the table itself: every table
-  // entry adds one per row it will merge into (the same predicates as use_a /
-  // use_b below), the wave that completes the table takes the tokens off, every
-  // merge takes one off under the row's lock -- whoever brings a row to zero
-  // appends it to the list of finished rows `rdy`.  A wave that leaves the task
-  // loop takes list slots in order and writes those rows (waiting for a slot
-  // that is not filled yet: it has nothing else to do) until all `rows` slots
-  // are taken.  The band needs no closing barrier and no epilogue: the waves
-  // that run dry first write while the others finish their last units, and
-  // behind a workgroup's last merge there are one or two rows left to write.
-  // (Written by the completing wave itself, in the middle of its loop, the
-  // launch takes 95 us instead of 81: the stores share the loads' counter and
-  // the call waits for them -- profiles/r05/ab_progressive_epilogue.txt.)
-  const bool prog = !BOTH && a.prog != 0 && a.ep >= 4 && ntask <= CAPT;
-  auto row_done = [&](int r) {   // (one lane)
-    const int slot = __hip_atomic_fetch_add(&ctl[2], 1, __ATOMIC_RELAXED,
-                                            __HIP_MEMORY_SCOPE_WORKGROUP);
-    __hip_atomic_store(&rdy[slot], r + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-  };
-  const int ep_st = (a.ep == 3 || a.ep == 5) ? 3 : (a.ep == 2 ? 2 : 1);
-  auto expect = [&](const Task& ta) {
-    if (!prog) return;
-    if (ta.wy0 != 0.f && ta.row0 >= 0 && ta.row0 < rows)
-      __hip_atomic_fetch_add(&rowcnt[ta.row0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    if (ta.wy1 != 0.f && ta.row0 + 1 >= 0 && ta.row0 + 1 < rows)
-      __hip_atomic_fetch_add(&rowcnt[ta.row0 + 1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  };
-  auto write_row = [&](int r) {
-    const size_t P = (size_t)Ht * Wt;
-    const size_t o = (size_t)b * P + (size_t)(row0 + r) * Wt;
-    s2_write_row((unsigned)(uintptr_t)(tile4 + (size_t)r * Wt), a.out_img + 3 * o,
-                 a.out_wts + o, Wt, a.lbg, lane, ep_st);
-  };
 
   // One item of loads into dst; returns its tag: -1 (none), or task slot |
   // bit 20 (first layer of the task) | bit 21 (last).  Always exactly one
@@ -860,7 +761,6 @@ __global__ __launch_bounds__(MAXT) void splat_stream2_kernel(S2Args a) {
       make_task(c0 + sl, ta, tx);
       task[sl] = ta;
       taskx[sl] = tx;
-      expect(ta);
     }
   };
   // The wave's own table entry, its share of the other tickets, and "arrived":
@@ -870,22 +770,12 @@ __global__ __launch_bounds__(MAXT) void splat_stream2_kernel(S2Args a) {
     if (wave < nchunk) {
       Task ta; TaskX tx;
       make_task(wave, ta, tx);
-      if (lane == 0) { task[wave] = ta; taskx[wave] = tx; expect(ta); }
+      if (lane == 0) { task[wave] = ta; taskx[wave] = tx; }
     }
     fill_table(0, NW, nchunk);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    int last = 0;
     if (lane == 0)
-      last = __hip_atomic_fetch_add(&ctl[1], 1, __ATOMIC_ACQ_REL,
-                                    __HIP_MEMORY_SCOPE_WORKGROUP) == NW - 1;
-    if (prog && last) {
-      // the table is complete: the rows' tokens come off (a row no unit merges
-      // into -- none, normally -- is finished as it is: background only)
-      for (int r = 0; r < rows; ++r)
-        if (__hip_atomic_fetch_sub(&rowcnt[r], 1, __ATOMIC_ACQ_REL,
-                                   __HIP_MEMORY_SCOPE_WORKGROUP) == 1)
-          row_done(r);
-    }
+      __hip_atomic_fetch_add(&ctl[1], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
   S2_STAMP(2);
 
@@ -1332,17 +1222,6 @@ __global__ __launch_bounds__(MAXT) void splat_stream2_kernel(S2Args a) {
             if (inside && v.x == 123.456f) trow[c] = v;
 #endif
           }
-        }
-        // rows this merge was the last one of: written out now (see `prog`)
-        if (prog && lane == 0) {
-          if (use_a && __hip_atomic_fetch_sub(&rowcnt[t_row0], 1, __ATOMIC_ACQ_REL,
-                                              __HIP_MEMORY_SCOPE_WORKGROUP) == 1)
-            row_done(t_row0);
-          if (use_b && __hip_atomic_fetch_sub(&rowcnt[t_row0 + 1], 1, __ATOMIC_ACQ_REL,
-                                              __HIP_MEMORY_SCOPE_WORKGROUP) == 1)
-            row_done(t_row0 + 1);
-        }
-        if (!CELL) {
 #ifndef S2X_NOLOCK
           if (use_b) s2_unlock_row(locks, t_lay + t_row0 + 1, lane);
           if (use_a) s2_unlock_row(locks, t_lay + t_row0, lane);
@@ -1374,30 +1253,12 @@ __global__ __launch_bounds__(MAXT) void splat_stream2_kernel(S2Args a) {
     __syncthreads();
   }
   S2_STAMP(4);
-  if (prog) {   // finished rows, in the order they finish, until every slot is taken
-    S2_STAMP(5);
-    for (;;) {
-      int r = 0;
-      if (lane == 0) {
-        const int t = __hip_atomic_fetch_add(&ctl[3], 1, __ATOMIC_RELAXED,
-                                             __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (t < rows) {
-          while ((r = __hip_atomic_load(&rdy[t], __ATOMIC_ACQUIRE,
-                                        __HIP_MEMORY_SCOPE_WORKGROUP)) == 0)
-            __builtin_amdgcn_s_sleep(2);
-        }
-      }
-      r = S2_RFL(r);
-      if (r == 0) break;
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-      write_row(r - 1);
-    }
-  } else {
   __syncthreads();  // every window is merged: the tile is complete
   S2_STAMP(5);
   // ---- epilogue: (tile + background) normalised, each output written once --
   // (a.ep: 0 scalar stores; 1 / 2 / 3 four cells per lane, plain / write-through
   // / non-temporal; 4 / 5 whole lines per store instruction, plain / non-temporal)
+  const int ep_st = (a.ep == 3 || a.ep == 5) ? 3 : (a.ep == 2 ? 2 : 1);
   if (BOTH && a.out_disp) {
     // the disparity pass: every layer's splatted disparity normalised by its own
     // canvas weight, then the maximum over the layers (ldi.py:157-158, 170)
@@ -1635,7 +1496,6 @@ __global__ __launch_bounds__(MAXT) void splat_stream2_kernel(S2Args a) {
       ow[i] = Wsum;
     }
   }
-  }  // (!prog)
   S2_STAMP(6);
 #ifdef S2X_STAMPS
   if (stamp && lane == 0)  // slot 7: the wave's items by route, 16 bits each
@@ -1651,7 +1511,7 @@ size_t s2_lds_bytes(int R, int Wt, int nw, int wmax, int cap, int qcap, int cell
   const int whs = ((wmax / 2 + 15) & ~15) + 8;
   return (size_t)nw * 2 * whs * 16 + (size_t)nt * R * Wt * 16 +
          (size_t)cap * (sizeof(Task) + sizeof(TaskX)) +
-         (size_t)((4 + nt * R + 2 * R + 3) & ~3) * 4 + (size_t)nw * qcap * 20 +
+         (size_t)((4 + nt * R + 3) & ~3) * 4 + (size_t)nw * qcap * 20 +
          (size_t)((nw * wmax + 15) & ~15) + (cell ? (size_t)nt * R * Wt * 4 : 0) + 16;
 }
 
@@ -1724,10 +1584,8 @@ int s2_plan_search(const LsiSplatDesc* d, int wmax, int maxnw, bool both, S2Plan
     int cell = (R <= 8 && nunit <= 40 && !both) ? 1 : 0;
     if (force_cell == 1) cell = 0;
     if (force_cell == 2 && !both) cell = 1;  // (both outputs: row locks only)
-    static const char* nw_env = getenv("LSI_S2_NW");   // experiments: this many waves
     for (int c = maxnw; c >= 2; --c) {
       if (d->tune_threads > 0 && c != (d->tune_threads + 63) / 64) continue;
-      if (nw_env && c != atoi(nw_env)) continue;
       // A unit is all L layers of a row segment on one wave (one merge per
       // unit).  Units are handed out whole up to 6 layers; deeper LDIs in
       // parts of at most 4 layers, so that a wave's last unit stays short.
@@ -1775,8 +1633,7 @@ int s2_plan_search(const LsiSplatDesc* d, int wmax, int maxnw, bool both, S2Plan
         // of them (config 5: 24 for 12 waves) the second round is no longer
         // aligned between neighbours and every one of them merges into the
         // band's first or last tile row (config 5: 92.4 us without, 94.3 with)
-        static const char* hff_env = getenv("LSI_S2_HF_FORCE");
-        best.hf = (hf && (4 * nseg <= c || hff_env)) ? hf : 0;
+        best.hf = (hf && 4 * nseg <= c) ? hf : 0;
         best.nsplit = nsplit; best.lsub = lsub; best.nunit = nunit;
       }
     }
@@ -1794,12 +1651,6 @@ int s2_plan_search(const LsiSplatDesc* d, int wmax, int maxnw, bool both, S2Plan
 
 #ifndef LSI_S2_NSETS
 #define LSI_S2_NSETS 2
-#endif
-#ifndef LSI_S2_PROG_DEFAULT
-#define LSI_S2_PROG_DEFAULT 0
-#endif
-#ifndef LSI_S2_ORD_DEFAULT
-#define LSI_S2_ORD_DEFAULT 0
 #endif
 #ifndef LSI_S2_MAXT
 #define LSI_S2_MAXT 768
@@ -1916,14 +1767,6 @@ int lsi_stream2_launch(const SplatArgs& a, int wmax, hipStream_t stream,
   }
   k.nsplit = plan.nsplit;
   k.lsub = plan.lsub;
-  {
-    static const char* prog_env = getenv("LSI_S2_PROG");
-    static const char* ord_env = getenv("LSI_S2_ORD");
-    // (rows of whole 128-byte lines: a row written on its own leaves no partial
-    // line to its neighbours)
-    k.prog = (prog_env ? atoi(prog_env) : LSI_S2_PROG_DEFAULT) && d->Wt % 32 == 0;
-    k.ord = ord_env ? atoi(ord_env) : LSI_S2_ORD_DEFAULT;
-  }
   const int nbands = (d->Ht + plan.R - 1) / plan.R;
   k.inv_gx = 1.0f / (float)nbands;
   k.inv_nseg = 1.0f / (float)k.nseg;
