@@ -498,6 +498,52 @@ int lsi_conv3x3_wgrad(int32_t N, int32_t H, int32_t W, int32_t cin, int32_t cout
                       const void* x, const void* gy, float* g_weight, void* workspace,
                       size_t workspace_bytes, lsi_stream_t stream);
 
+/*
+ * Convolutions of the encoder-decoder and the LDI heads on the matrix cores
+ * (reference nets.py:29-70 encoder, 73-114 decoder_simple, 244-348 U-Net:
+ * slim.conv2d k x k stride 1 | 2 with TF `SAME` padding, slim.conv2d_transpose
+ * 4 x 4 stride 2; TF autodiff for the data gradients) as implicit GEMMs
+ * (v_mfma_f32_16x16x32_bf16, fp32 accumulation) on bf16 channels-last tensors.
+ * LsiConvDesc describes the FORWARD convolution
+ *   out[n][oy][ox][co] = sum x[n][oy*stride + ky - pad_t][ox*stride + kx - pad_l][ci]
+ *                            * weight[co][ci][ky][kx]            (zero outside)
+ *   x: bf16 N x H x W x Cin, out: bf16 N x OH x OW x Cout (16-byte aligned),
+ *   weight: the layer's fp32 parameter Cout x Cin x KH x KW (rounded to bf16 on
+ *   the way into the kernel's operand order, as torch.autocast rounds it: see
+ *   lsi_conv2d_pack below).
+ *   Cin, Cout multiples of 32; KH, KW <= 7; stride 1 or 2; pad < kernel size
+ *   (LSI_EUNSUPPORTED otherwise: lsi_conv2d_supported() tells beforehand).
+ * lsi_conv2d_bwd_data: gx[n][iy][ix][ci] = the transpose of the above applied
+ *   to gy (N x OH x OW x Cout) -- for stride 2 as four stride-1 sums over the
+ *   sub-kernels of the input pixels' parity classes, no zero-stuffed tensor.
+ * A transposed convolution (torch ConvTranspose2d(Cin_T, Cout_T, k, stride,
+ * padding p), weight Cin_T x Cout_T x k x k, input N x h x w x Cin_T) IS the
+ * data gradient of the forward convolution {H = stride h, W = stride w,
+ * Cin = Cout_T, OH = h, OW = w, Cout = Cin_T, pad_t = pad_l = p} with the same
+ * weight memory: its forward is lsi_conv2d_bwd_data of that descriptor, its
+ * data gradient lsi_conv2d_fwd.
+ * The weights enter in the kernels' operand order, bf16 [tap][out ch][in ch]:
+ * lsi_conv2d_pack(d, mode, weight, packed, ...) writes it from the layer's fp32
+ * parameter -- mode 0 for lsi_conv2d_fwd, mode 1 for lsi_conv2d_bwd_data (roles
+ * of the channels swapped, taps in parity-class order) -- into
+ * lsi_conv2d_packed_bytes(d) bytes (16-byte aligned; LSI_EWORKSPACE if
+ * smaller).  A caller whose weights have not changed may keep the packed form.
+ */
+typedef struct LsiConvDesc {
+  int32_t N, H, W, Cin;    /* input  N x H x W x Cin   */
+  int32_t OH, OW, Cout;    /* output N x OH x OW x Cout */
+  int32_t KH, KW, stride;  /* kernel size; 1 or 2       */
+  int32_t pad_t, pad_l;    /* zero rows / columns before the input (TF SAME: total / 2) */
+} LsiConvDesc;
+int lsi_conv2d_supported(const LsiConvDesc* d);
+size_t lsi_conv2d_packed_bytes(const LsiConvDesc* d);
+int lsi_conv2d_pack(const LsiConvDesc* d, int32_t mode, const float* weight, void* packed,
+                    size_t packed_bytes, lsi_stream_t stream);
+int lsi_conv2d_fwd(const LsiConvDesc* d, const void* x, const void* packed, void* out,
+                   lsi_stream_t stream);
+int lsi_conv2d_bwd_data(const LsiConvDesc* d, const void* gy, const void* packed, void* gx,
+                        lsi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,455 @@
+// Convolutions of the encoder-decoder and the LDI heads as implicit GEMMs on
+// the matrix cores (gfx950, v_mfma_f32_16x16x32_bf16, fp32 accumulation):
+// reference nets.py:29-70, 73-114, 244-348 -- slim.conv2d (k x k, stride 1 | 2,
+// TF `SAME` padding) and slim.conv2d_transpose (4 x 4, stride 2) on bf16
+// channels-last activations, forward and data gradient.
+//
+// One kernel, `conv_igemm_kernel`, computes
+//     out[n][i * os + ooy][j * os + oox][co] =
+//         sum over taps t, channels ci of  x[n][i * s + dy_t][j * s + dx_t][ci] * Wp[t][co][ci]
+// for a list of taps (dy_t, dx_t) with zero outside the input.  Everything the
+// network needs is that with a tap list:
+//   * forward, stride s:       dy = ky - pad_t, dx = kx - pad_l, os = 1;
+//   * data gradient, stride 1: the same sum over the incoming gradient with
+//     dy = pad_t - ky and the channel roles swapped (Wp[t][ci][co]);
+//   * data gradient, stride 2 (= the forward of a transposed convolution): the
+//     input pixels of one parity class (iy, ix) = (2 i + p, 2 j + q) receive
+//     only the taps with ky = p + pad_t (mod 2), from gradient pixel
+//     i + (p + pad_t - ky) / 2: four launches, each a stride-1 sum over a
+//     sub-kernel (2 x 2 taps for the 4 x 4 transposed convolutions) writing
+//     every second pixel (os = 2) -- no zero-stuffed input, no wasted products;
+//   * the data gradient of a transposed convolution is the forward with s = 2.
+//
+// Layout.  One pixel's 32 consecutive channels are 64 contiguous bytes = the
+// K of ONE MFMA.  The weights are the A operand (16 output channels x 32 input
+// channels), the pixels the B operand (lane l: pixel l & 15, channels
+// 8 (l >> 4) .. + 7), so that the accumulator of lane l is four consecutive
+// output channels of one pixel: channels-last stores without a transpose.
+//
+// Workgroup = 4 waves = a tile of (4 RW) rows x 16 columns of output pixels x BN
+// output channels (BN = 64 | 32); wave w owns rows w RW .. + RW - 1.  Per chunk
+// of 32 input channels the workgroup stages the input patch the tile's taps
+// reach ((TH - 1) s + span rows, pixels 80 bytes apart: the 16 lanes of a
+// fragment read then fall into 16 different 16-byte bank groups) and, per group
+// of <= G taps, the weights [tap][co][32 ci] (rows 80 bytes apart) in LDS;
+// every tap is then RW + BN / 16 fragment reads for RW * BN / 16 MFMAs.  Two or
+// three workgroups share a CU (<= 80 KB of LDS each): one stages while another
+// multiplies.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "../../include/lsi_hip.h"
+#include "lsi_splat_internal.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int IG_MAXTAPS = 49;
+constexpr int IG_PIX = 80;  // bytes per staged pixel / weight row (64 + 16 of padding)
+
+// One tap list = one class of output pixels: all of them (forward, stride-1
+// data gradient) or one parity class of a stride-2 data gradient.
+struct IgClass {
+  int ntaps, dy0, dx0;   // taps; smallest dy, dx
+  int ooy, oox;          // output pixel of (i, j): (i * os + ooy, j * os + oox)
+  int OHt, OWt;          // output grid (i, j) of the class
+  int wofs;              // first tap of the class in wp
+  // patch byte offset of every tap, (dy - dy0) * PW + (dx - dx0) pixels; padded
+  // with zeros to whole stages of G taps (their weights are staged as zeros)
+  int toff[IG_MAXTAPS + 7];
+  signed char tdy[IG_MAXTAPS + 3], tdx[IG_MAXTAPS + 3];
+};
+struct IgArgs {
+  const __bf16* x;    // N x H x W x Cin
+  const __bf16* wp;   // [taps of all classes][Cout][Cin]
+  __bf16* out;        // N x OHF x OWF x Cout
+  int N, H, W, Cin, Cout;
+  int s;              // input pixels per output step
+  int os;             // output pixels per (i, j) step
+  int OHF, OWF;
+  int G;              // taps per weight stage
+  int PH, PW;         // staged patch: rows, pixels per row
+  int ncls;
+  IgClass cls[4];
+};
+
+// RW: pixel rows per wave; NCT: tiles of 16 output channels (BN = 16 NCT); G:
+// taps per weight stage -- a compile-time count, so that a stage is straight-
+// line code: the tap offsets come in one batch of scalar loads and the
+// scheduler overlaps a tap's fragment reads with the previous tap's MFMAs
+template <int RW, int NCT, int G>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(IgArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ig_smem[];
+  constexpr int TH = 4 * RW, BN = 16 * NCT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int pxl = lane & 15, kg = lane >> 4;
+  const int ncb = a.Cout / BN;
+  const int zc = blockIdx.z / ncb, co0 = (blockIdx.z - zc * ncb) * BN;
+  const int ci_ = zc / a.N, n = zc - ci_ * a.N;
+  const IgClass& k = a.cls[ci_];
+  const int i0 = blockIdx.y * TH, j0 = blockIdx.x * 16;
+  if (i0 >= k.OHt || j0 >= k.OWt) return;  // (the grid covers the largest class)
+  const int PW = a.PW, npix = a.PH * PW;
+  unsigned char* const patch = ig_smem;
+  unsigned char* const wts = ig_smem + (size_t)npix * IG_PIX;
+
+  // The patch pieces this thread stages (16 bytes each: pixel, quarter of its
+  // 32 channels): element offsets into x (without the chunk's channel offset),
+  // -1 outside the input.  The same for every chunk.
+  constexpr int MAXP = 12;  // (<= 768 staged pixels)
+  int goff[MAXP];
+  const int npiece = npix * 4;
+  {
+    const int iy0 = i0 * a.s + k.dy0, ix0 = j0 * a.s + k.dx0;
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) {
+      const int idx = tid + 256 * k;
+      const int pix = idx >> 2, q = idx & 3;
+      const int py = pix / PW, px = pix - py * PW;
+      const int iy = iy0 + py, ix = ix0 + px;
+      const bool ok = idx < npiece && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+      goff[k] = ok ? (((n * a.H + iy) * a.W + ix) * a.Cin + 8 * q) : -1;
+    }
+  }
+  f32x4 acc[RW][NCT];
+#pragma unroll
+  for (int r = 0; r < RW; ++r)
+#pragma unroll
+    for (int c = 0; c < NCT; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  // this lane's B fragments: pixel (row wave * RW + r, column pxl) of the tile
+  const unsigned b_lane =
+      (unsigned)((wave * RW * a.s) * PW + pxl * a.s) * IG_PIX + (unsigned)kg * 16u;
+  const unsigned b_row = (unsigned)(a.s * PW) * IG_PIX;
+  const int ntaps = k.ntaps;
+  const __bf16* const wp = a.wp + (size_t)k.wofs * a.Cout * a.Cin;
+  const unsigned a_lane = (unsigned)pxl * IG_PIX + (unsigned)kg * 16u;  // weight row pxl of a tile
+
+  for (int c0 = 0; c0 < a.Cin; c0 += 32) {
+    __syncthreads();  // (the previous chunk's fragments have been read)
+    // ---- the input patch of this chunk (all loads issued, then all LDS stores:
+    // one memory round trip per stage, not one per piece) ------------------------
+    {
+      u32x4 pv[MAXP];
+#pragma unroll
+      for (int kk = 0; kk < MAXP; ++kk) {
+        pv[kk] = zero4;
+        if (tid + 256 * kk < npiece && goff[kk] >= 0)
+          pv[kk] = *reinterpret_cast<const u32x4*>(a.x + (size_t)goff[kk] + c0);
+      }
+#pragma unroll
+      for (int kk = 0; kk < MAXP; ++kk) {
+        const int idx = tid + 256 * kk;
+        if (idx < npiece)
+          *reinterpret_cast<u32x4*>(patch + (size_t)(idx >> 2) * IG_PIX + (idx & 3) * 16) = pv[kk];
+      }
+    }
+    for (int t0 = 0; t0 < ntaps; t0 += G) {
+      if (t0 > 0) __syncthreads();  // (the previous group's weights have been read)
+      // ---- weights of taps t0 .. t0 + G - 1: [tap][co][32 channels]; taps past
+      // the class's last one are zeros (loads first, then the LDS stores) --------
+      {
+        constexpr int NWP = G * BN * 4, WB = (NWP + 255) / 256;
+        const __bf16* const wsrc = wp + ((size_t)t0 * a.Cout + co0) * a.Cin + c0;
+        const int nreal = (ntaps - t0) * BN * 4;
+        u32x4 wv[WB];
+#pragma unroll
+        for (int kk = 0; kk < WB; ++kk) {
+          const int idx = tid + 256 * kk;
+          wv[kk] = zero4;
+          if (idx < NWP && idx < nreal) {
+            const int q = idx & 3, co = (idx >> 2) & (BN - 1), t = idx / (4 * BN);
+            wv[kk] = *reinterpret_cast<const u32x4*>(
+                wsrc + ((size_t)t * a.Cout + co) * a.Cin + 8 * q);
+          }
+        }
+#pragma unroll
+        for (int kk = 0; kk < WB; ++kk) {
+          const int idx = tid + 256 * kk;
+          if (idx < NWP) {
+            const int q = idx & 3, co = (idx >> 2) & (BN - 1), t = idx / (4 * BN);
+            *reinterpret_cast<u32x4*>(wts + (size_t)(t * BN + co) * IG_PIX + q * 16) = wv[kk];
+          }
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int t = 0; t < G; ++t) {
+        const unsigned toff = (unsigned)k.toff[t0 + t];
+        bf16x8 af[NCT];
+#pragma unroll
+        for (int c = 0; c < NCT; ++c)
+          af[c] = *reinterpret_cast<const bf16x8*>(wts + (size_t)(t * BN + 16 * c) * IG_PIX + a_lane);
+        const unsigned char* const bp = patch + b_lane + toff;
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+          const bf16x8 bf = *reinterpret_cast<const bf16x8*>(bp + r * b_row);
+#pragma unroll
+          for (int c = 0; c < NCT; ++c)
+            acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[c], bf, acc[r][c], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // ---- channels-last stores: lane = 4 output channels of one pixel -----------
+  const int j = j0 + pxl;
+  if (j < k.OWt) {
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+      const int i = i0 + wave * RW + r;
+      if (i < k.OHt) {
+        __bf16* const o = a.out +
+            (((size_t)n * a.OHF + (size_t)(i * a.os + k.ooy)) * a.OWF + (j * a.os + k.oox)) * a.Cout +
+            co0 + 4 * kg;
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) {
+          bf16x4 v;
+          v[0] = (__bf16)acc[r][c][0]; v[1] = (__bf16)acc[r][c][1];
+          v[2] = (__bf16)acc[r][c][2]; v[3] = (__bf16)acc[r][c][3];
+          *reinterpret_cast<bf16x4*>(o + 16 * c) = v;
+        }
+      }
+    }
+  }
+}
+
+// Weights into the kernel's operand order: dst[t][o][i] = W[o][i][ky_t][kx_t]
+// (tr = 0) or W[i][o][ky_t][kx_t] (tr = 1: the data gradients), rounded to bf16
+// as torch.autocast rounds them.  W is the layer's fp32 parameter
+// D0 x D1 x KH x KW (both multiples of 32).  A workgroup moves a 32 x 32 tile of
+// (d0, d1) per tap through LDS, so that reads and (transposed) writes are both
+// contiguous runs.
+struct PackArgs {
+  const float* w;
+  __bf16* dst;
+  int D0, D1, khw, tr, ntaps;
+  signed char tap[IG_MAXTAPS + 3];  // ky * KW + kx of every tap
+};
+__global__ __launch_bounds__(256) void conv_pack_kernel(PackArgs a) {
+  __shared__ float tile[32][33];
+  const int a0 = blockIdx.y * 32, b0 = blockIdx.x * 32;
+  const int c = threadIdx.x & 31, r0 = threadIdx.x >> 5;
+  const size_t per = (size_t)a.D0 * a.D1;
+  for (int t = 0; t < a.ntaps; ++t) {
+    const int tap = a.tap[t];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = r0 + 8 * j;
+      tile[r][c] = a.w[((size_t)(a0 + r) * a.D1 + b0 + c) * a.khw + tap];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = r0 + 8 * j;
+      if (a.tr)   // dst[t][d1][d0]
+        a.dst[(size_t)t * per + (size_t)(b0 + r) * a.D0 + a0 + c] = (__bf16)tile[c][r];
+      else        // dst[t][d0][d1]
+        a.dst[(size_t)t * per + (size_t)(a0 + r) * a.D1 + b0 + c] = (__bf16)tile[r][c];
+    }
+    __syncthreads();
+  }
+}
+
+constexpr size_t IG_LDS_CAP = 80 * 1024;  // two workgroups per CU
+
+// Tile shape for the tap lists: the tallest row block whose patch + one weight
+// stage fit the LDS share; G = as many taps per stage as fit next to the patch.
+bool ig_shape(IgArgs& k, int* rw_out, int* nct_out, size_t* lds_out) {
+  const int nct = (k.Cout % 64 == 0) ? 4 : 2;
+  const int bn = 16 * nct;
+  int spany = 1, spanx = 1, maxtaps = 0, maxoh = 1;
+  for (int c = 0; c < k.ncls; ++c) {
+    IgClass& q = k.cls[c];
+    int dy1 = -128, dx1 = -128, dy0 = 127, dx0 = 127;
+    for (int t = 0; t < q.ntaps; ++t) {
+      dy0 = q.tdy[t] < dy0 ? q.tdy[t] : dy0; dy1 = q.tdy[t] > dy1 ? q.tdy[t] : dy1;
+      dx0 = q.tdx[t] < dx0 ? q.tdx[t] : dx0; dx1 = q.tdx[t] > dx1 ? q.tdx[t] : dx1;
+    }
+    if (q.ntaps == 0) { dy0 = dy1 = dx0 = dx1 = 0; }
+    q.dy0 = dy0; q.dx0 = dx0;
+    spany = dy1 - dy0 + 1 > spany ? dy1 - dy0 + 1 : spany;
+    spanx = dx1 - dx0 + 1 > spanx ? dx1 - dx0 + 1 : spanx;
+    maxtaps = q.ntaps > maxtaps ? q.ntaps : maxtaps;
+    maxoh = q.OHt > maxoh ? q.OHt : maxoh;
+  }
+  k.PW = 15 * k.s + spanx;
+  for (int rw = 4; rw >= 1; rw >>= 1) {
+    if (rw > 1 && 4 * (rw / 2) >= maxoh) continue;  // (a shorter block covers the rows)
+    const int th = 4 * rw;
+    k.PH = (th - 1) * k.s + spany;
+    const size_t patch = (size_t)k.PH * k.PW * IG_PIX;
+    if (k.PH * k.PW > 768) continue;
+    if (patch + (size_t)bn * IG_PIX > IG_LDS_CAP) continue;
+    // taps per weight stage: one of the instantiated counts -- the one that
+    // wastes the fewest padded taps, then the fewest stages -- that fits
+    static const int GS[4] = {9, 7, 5, 4};
+    int g = 0, best_pad = 1 << 30, best_st = 1 << 30;
+    for (int gi = 0; gi < 4; ++gi) {
+      const int gc = GS[gi];
+      if (patch + (size_t)gc * bn * IG_PIX > IG_LDS_CAP) continue;
+      int pad = 0, st = 0;
+      for (int c = 0; c < k.ncls; ++c) {
+        const int n = k.cls[c].ntaps, stages = (n + gc - 1) / gc;
+        pad += stages * gc - n; st += stages;
+      }
+      if (pad < best_pad || (pad == best_pad && st < best_st)) {
+        best_pad = pad; best_st = st; g = gc;
+      }
+    }
+    if (!g) continue;
+    k.G = g;
+    for (int c = 0; c < k.ncls; ++c) {
+      IgClass& q = k.cls[c];
+      for (int t = 0; t < IG_MAXTAPS + 7; ++t)
+        q.toff[t] = t < q.ntaps
+            ? ((q.tdy[t] - q.dy0) * k.PW + (q.tdx[t] - q.dx0)) * IG_PIX : 0;
+    }
+    *rw_out = rw; *nct_out = nct;
+    *lds_out = patch + (size_t)g * bn * IG_PIX;
+    return true;
+  }
+  return false;
+}
+
+int ig_launch(IgArgs& k, hipStream_t stream) {
+  int rw, nct;
+  size_t lds;
+  if (!ig_shape(k, &rw, &nct, &lds)) return LSI_EUNSUPPORTED;
+  const int th = 4 * rw, bn = 16 * nct;
+  int oh = 0, ow = 0;
+  for (int c = 0; c < k.ncls; ++c) {
+    oh = k.cls[c].OHt > oh ? k.cls[c].OHt : oh;
+    ow = k.cls[c].OWt > ow ? k.cls[c].OWt : ow;
+  }
+  if (oh <= 0 || ow <= 0) return LSI_OK;
+  const dim3 grid((ow + 15) / 16, (oh + th - 1) / th, k.ncls * k.N * (k.Cout / bn));
+  if (grid.z > 65535 || grid.y > 65535) return LSI_EINVAL;
+  const void* fn = nullptr;
+#define IG_CASE(R, C, GG) \
+  if (rw == R && nct == C && k.G == GG) fn = (const void*)conv_igemm_kernel<R, C, GG>
+#define IG_CASES(GG) \
+  IG_CASE(4, 4, GG); IG_CASE(2, 4, GG); IG_CASE(1, 4, GG); \
+  IG_CASE(4, 2, GG); IG_CASE(2, 2, GG); IG_CASE(1, 2, GG)
+  IG_CASES(9); IG_CASES(7); IG_CASES(5); IG_CASES(4);
+#undef IG_CASES
+#undef IG_CASE
+  if (!fn) return LSI_EINVAL;
+  if (lsi_ensure_dynamic_lds(fn, lds) != LSI_OK) return LSI_ELAUNCH;
+  void* kargs[1] = {&k};
+  if (hipLaunchKernel(fn, grid, dim3(256), kargs, lds, stream) != hipSuccess) return LSI_ELAUNCH;
+  return hipGetLastError() == hipSuccess ? LSI_OK : LSI_ELAUNCH;
+}
+
+bool desc_ok(const LsiConvDesc* d) {
+  if (!d) return false;
+  if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->OH <= 0 || d->OW <= 0) return false;
+  if (d->Cin <= 0 || d->Cout <= 0 || d->Cin % 32 || d->Cout % 32) return false;
+  if (d->KH < 1 || d->KW < 1 || d->KH > 7 || d->KW > 7) return false;
+  if (d->stride != 1 && d->stride != 2) return false;
+  if (d->pad_t < 0 || d->pad_l < 0 || d->pad_t >= d->KH || d->pad_l >= d->KW) return false;
+  // int32 element offsets inside the kernels
+  if ((int64_t)d->N * d->H * d->W * d->Cin >= (1ll << 31)) return false;
+  if ((int64_t)d->N * d->OH * d->OW * d->Cout >= (1ll << 31)) return false;
+  return true;
+}
+
+// The tap lists of a call.  mode 0: forward (one class); mode 1: data gradient
+// (stride^2 parity classes of input pixels).  `tap` receives ky * KW + kx of
+// every tap in class order (the order of the packed weights).
+void ig_classes(const LsiConvDesc* d, int mode, IgArgs& k, signed char* tap) {
+  memset(&k, 0, sizeof(k));
+  int nt = 0;
+  if (mode == 0) {
+    IgClass& q = k.cls[0];
+    for (int y = 0; y < d->KH; ++y)
+      for (int xk = 0; xk < d->KW; ++xk) {
+        tap[nt] = (signed char)(y * d->KW + xk);
+        q.tdy[q.ntaps] = (signed char)(y - d->pad_t);
+        q.tdx[q.ntaps] = (signed char)(xk - d->pad_l);
+        ++q.ntaps; ++nt;
+      }
+    q.OHt = d->OH; q.OWt = d->OW; q.wofs = 0;
+    k.ncls = 1;
+    k.N = d->N; k.H = d->H; k.W = d->W; k.Cin = d->Cin; k.Cout = d->Cout;
+    k.s = d->stride; k.os = 1; k.OHF = d->OH; k.OWF = d->OW;
+    return;
+  }
+  const int s = d->stride;
+  // input pixels (iy, ix) = (s i + p, s j + q): the taps with ky = p + pad_t (mod s)
+  //   gx[s i + p] += gy[oy] W[ky],   s oy + ky - pad_t = s i + p
+  for (int p = 0; p < s; ++p)
+    for (int q_ = 0; q_ < s; ++q_) {
+      IgClass& q = k.cls[k.ncls++];
+      q.wofs = nt;
+      for (int y = 0; y < d->KH; ++y) {
+        if ((p + d->pad_t - y) % s != 0) continue;
+        for (int xk = 0; xk < d->KW; ++xk) {
+          if ((q_ + d->pad_l - xk) % s != 0) continue;
+          tap[nt] = (signed char)(y * d->KW + xk);
+          q.tdy[q.ntaps] = (signed char)((p + d->pad_t - y) / s);
+          q.tdx[q.ntaps] = (signed char)((q_ + d->pad_l - xk) / s);
+          ++q.ntaps; ++nt;
+        }
+      }
+      q.ooy = p; q.oox = q_;
+      q.OHt = (d->H - p + s - 1) / s; q.OWt = (d->W - q_ + s - 1) / s;
+    }
+  k.N = d->N; k.H = d->OH; k.W = d->OW; k.Cin = d->Cout; k.Cout = d->Cin;
+  k.s = 1; k.os = s; k.OHF = d->H; k.OWF = d->W;
+}
+
+}  // namespace
+
+extern "C" int lsi_conv2d_supported(const LsiConvDesc* d) { return desc_ok(d) ? 1 : 0; }
+
+extern "C" size_t lsi_conv2d_packed_bytes(const LsiConvDesc* d) {
+  if (!desc_ok(d)) return 0;
+  return (size_t)d->KH * d->KW * d->Cin * d->Cout * sizeof(__bf16);
+}
+
+extern "C" int lsi_conv2d_pack(const LsiConvDesc* d, int32_t mode, const float* weight,
+                               void* packed, size_t packed_bytes, lsi_stream_t stream_) {
+  if (!d || !weight || !packed) return LSI_ENULL;
+  if (!desc_ok(d)) return LSI_EUNSUPPORTED;
+  if (mode != 0 && mode != 1) return LSI_EINVAL;
+  if ((uintptr_t)packed & 15) return LSI_EINVAL;
+  if (packed_bytes < lsi_conv2d_packed_bytes(d)) return LSI_EWORKSPACE;
+  IgArgs k;
+  PackArgs p;
+  memset(&p, 0, sizeof(p));
+  ig_classes(d, mode, k, p.tap);
+  p.w = weight; p.dst = (__bf16*)packed;
+  p.D0 = d->Cout; p.D1 = d->Cin; p.khw = d->KH * d->KW; p.tr = mode;
+  p.ntaps = d->KH * d->KW;
+  hipLaunchKernelGGL(conv_pack_kernel, dim3(d->Cin / 32, d->Cout / 32), dim3(256), 0,
+                     (hipStream_t)stream_, p);
+  return hipGetLastError() == hipSuccess ? LSI_OK : LSI_ELAUNCH;
+}
+
+static int ig_run(const LsiConvDesc* d, int mode, const void* src, const void* packed,
+                  void* dst, lsi_stream_t stream_) {
+  if (!d || !src || !packed || !dst) return LSI_ENULL;
+  if (!desc_ok(d)) return LSI_EUNSUPPORTED;
+  if (((uintptr_t)src & 15) || ((uintptr_t)dst & 7) || ((uintptr_t)packed & 15)) return LSI_EINVAL;
+  IgArgs k;
+  signed char tap[IG_MAXTAPS + 3];
+  ig_classes(d, mode, k, tap);
+  k.x = (const __bf16*)src; k.wp = (const __bf16*)packed; k.out = (__bf16*)dst;
+  return ig_launch(k, (hipStream_t)stream_);
+}
+
+extern "C" int lsi_conv2d_fwd(const LsiConvDesc* d, const void* x, const void* packed,
+                              void* out, lsi_stream_t stream) {
+  return ig_run(d, 0, x, packed, out, stream);
+}
+
+extern "C" int lsi_conv2d_bwd_data(const LsiConvDesc* d, const void* gy, const void* packed,
+                                   void* gx, lsi_stream_t stream) {
+  return ig_run(d, 1, gy, packed, gx, stream);
+}

@@ -54,10 +54,16 @@ class LsiLossDesc(ctypes.Structure):
       [('reserved', ctypes.c_int32)])
 
 
+class LsiConvDesc(ctypes.Structure):
+  _fields_ = [(n, ctypes.c_int32) for n in (
+      'N', 'H', 'W', 'Cin', 'OH', 'OW', 'Cout', 'KH', 'KW', 'stride', 'pad_t', 'pad_l')]
+
+
 # name -> (restype, argtypes); every symbol include/lsi_hip.h declares.
 _I32, _I64, _VP, _SZ = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p, ctypes.c_size_t
 _DP = ctypes.POINTER(LsiSplatDesc)
 _LP = ctypes.POINTER(LsiLossDesc)
+_CP = ctypes.POINTER(LsiConvDesc)
 _F32 = ctypes.c_float
 SIGNATURES = {
     'lsi_version': (ctypes.c_int, []),
@@ -98,6 +104,11 @@ SIGNATURES = {
                         [_I32, _F32, _F32, _VP, _VP]),
     'lsi_compose_depth_fwd': (ctypes.c_int, [_I32, _I64] + [_VP] * 2 +
                               [_I32, _F32, _F32, _F32, _VP, _VP]),
+    'lsi_conv2d_supported': (ctypes.c_int, [_CP]),
+    'lsi_conv2d_packed_bytes': (_SZ, [_CP]),
+    'lsi_conv2d_pack': (ctypes.c_int, [_CP, _I32, _VP, _VP, _SZ, _VP]),
+    'lsi_conv2d_fwd': (ctypes.c_int, [_CP] + [_VP] * 4),
+    'lsi_conv2d_bwd_data': (ctypes.c_int, [_CP] + [_VP] * 4),
     'lsi_bn_workspace_floats': (_SZ, [_I64, _I32, _I32, _I32]),
     'lsi_bn_relu_fwd': (ctypes.c_int, [_VP] * 5 + [_I64, _I32, _I32, _I32, _F32, _I32, _VP]),
     'lsi_bn_relu_bwd': (ctypes.c_int, [_VP] * 7 + [_I64, _I32, _I32, _I32, _I32, _VP]),

@@ -237,3 +237,171 @@ def conv3x3_c32(x, weight):
 
 def conv3x3_c32_sigmoid(x, weight, bias):
   return _Conv3x3C32Sigmoid.apply(x, weight, bias)
+
+
+# ---- every other convolution: the implicit-GEMM kernel (csrc/lsi_conv_igemm.hip) ----
+import ctypes
+
+IGEMM_MIN_PIXELS = int(os.environ.get('LSI_IGEMM_MIN_PIXELS', '0'))
+
+
+def _conv_desc(n, h, w, cin, oh, ow, cout, kh, kw, stride, pad_t, pad_l):
+  d = _C.LsiConvDesc()
+  (d.N, d.H, d.W, d.Cin, d.OH, d.OW, d.Cout, d.KH, d.KW, d.stride, d.pad_t,
+   d.pad_l) = (n, h, w, cin, oh, ow, cout, kh, kw, stride, pad_t, pad_l)
+  return d
+
+
+def _cl_bf16(t):
+  return (t.is_cuda and t.dim() == 4 and t.dtype == torch.bfloat16 and
+          t.is_contiguous(memory_format=torch.channels_last) and t.data_ptr() % 16 == 0)
+
+
+def igemm_supported(x, cin, cout, k, stride):
+  """bf16 channels-last GPU activations, channel counts that are multiples of
+  32, kernels up to 7 x 7, stride 1 or 2 (lsi_conv2d_supported)."""
+  return (_cl_bf16(x) and x.shape[1] == cin and cin % 32 == 0 and cout % 32 == 0 and
+          1 <= k <= 7 and stride in (1, 2) and
+          x.shape[0] * x.shape[2] * x.shape[3] >= IGEMM_MIN_PIXELS)
+
+
+def _f32(weight):
+  weight = weight.detach()
+  if weight.dtype != torch.float32 or not weight.is_contiguous():
+    weight = weight.float().contiguous()
+  return weight
+
+
+_PACKED = {}   # (id(weight), mode) -> (weakref, version, shape key, packed bf16 weights)
+
+
+def _packed(desc, mode, weight):
+  """The layer's weights in the kernel's operand order (lsi_conv2d_pack), kept
+  until the parameter changes (its version counter: the optimiser's in-place
+  step moves it) -- an evaluation loop packs once, a training step once per
+  direction."""
+  import weakref
+  key = (id(weight), mode)
+  geo = (desc.Cin, desc.Cout, desc.KH, desc.KW, desc.stride, desc.pad_t, desc.pad_l)
+  hit = _PACKED.get(key)
+  if (hit is not None and hit[0]() is weight and hit[1] == weight._version and
+      hit[2] == geo and hit[3].device == weight.device):
+    return hit[3]
+  lib = _C.lib()
+  dev = weight.device
+  nbytes = lib.lsi_conv2d_packed_bytes(ctypes.byref(desc))
+  buf = torch.empty((nbytes // 2,), dtype=torch.bfloat16, device=dev)
+  rc = lib.lsi_conv2d_pack(ctypes.byref(desc), mode, _C.ptr(_f32(weight)), _C.ptr(buf),
+                           nbytes, _C.stream_ptr(dev))
+  _C.check(rc, 'lsi_conv2d_pack')
+  _PACKED[key] = (weakref.ref(weight, lambda _r, k=key: _PACKED.pop(k, None)),
+                  weight._version, geo, buf)
+  return buf
+
+
+def _igemm(entry, desc, src, weight, out):
+  mode = 1 if entry == 'lsi_conv2d_bwd_data' else 0
+  packed = _packed(desc, mode, weight)
+  rc = getattr(_C.lib(), entry)(ctypes.byref(desc), _C.ptr(src), _C.ptr(packed), _C.ptr(out),
+                                _C.stream_ptr(src.device))
+  _C.check(rc, entry)
+  return out
+
+
+def _empty_cl(n, c, h, w, dev):
+  return torch.empty((n, c, h, w), dtype=torch.bfloat16, device=dev,
+                     memory_format=torch.channels_last)
+
+
+class _Conv2dIgemm(torch.autograd.Function):
+  """slim.conv2d without bias (reference nets.py: the arg_scope's conv2d) --
+  forward and data gradient on lsi_conv2d_fwd / lsi_conv2d_bwd_data, the weight
+  gradient on lsi_conv3x3_wgrad where it applies (3 x 3 stride 1 at >= 200 k
+  pixels) and on aten (MIOpen) elsewhere."""
+
+  @staticmethod
+  def forward(ctx, x, weight, stride, pad_t, pad_l, oh, ow):
+    n, cin, h, w = x.shape
+    cout, _, kh, kw = weight.shape
+    desc = _conv_desc(n, h, w, cin, oh, ow, cout, kh, kw, stride, pad_t, pad_l)
+    ctx.desc = desc
+    ctx.save_for_backward(x, weight)
+    return _igemm('lsi_conv2d_fwd', desc, x, weight, _empty_cl(n, cout, oh, ow, x.device))
+
+  @staticmethod
+  def backward(ctx, g):
+    x, weight = ctx.saved_tensors
+    d = ctx.desc
+    if g.dtype != torch.bfloat16:
+      g = g.to(torch.bfloat16)
+    g = g.contiguous(memory_format=torch.channels_last)
+    gx = gw = None
+    if ctx.needs_input_grad[0]:
+      gx = _igemm('lsi_conv2d_bwd_data', d, g, weight,
+                  _empty_cl(d.N, d.Cin, d.H, d.W, x.device))
+    if ctx.needs_input_grad[1]:
+      if d.KH == 3 and d.KW == 3 and d.stride == 1 and d.pad_t == 1 and d.pad_l == 1:
+        gw = _weight_grad(x, g, weight)
+      else:
+        # explicit padding: TF SAME is asymmetric for stride 2 (one more after)
+        pb = max((d.OH - 1) * d.stride + d.KH - d.H - d.pad_t, 0)
+        pr = max((d.OW - 1) * d.stride + d.KW - d.W - d.pad_l, 0)
+        if pb == d.pad_t and pr == d.pad_l:
+          xp, pad = x, [d.pad_t, d.pad_l]
+        else:
+          xp, pad = torch.nn.functional.pad(x, (d.pad_l, pr, d.pad_t, pb)), [0, 0]
+        gw = torch.ops.aten.convolution_backward(
+            g, xp, weight.to(g.dtype), None, [d.stride, d.stride], pad, [1, 1], False,
+            [0, 0], 1, [False, True, False])[1].to(weight.dtype)
+    return gx, gw, None, None, None, None, None
+
+
+def conv2d(x, weight, stride, pad_t, pad_l, oh, ow):
+  return _Conv2dIgemm.apply(x, weight, stride, pad_t, pad_l, oh, ow)
+
+
+class _ConvTranspose2dIgemm(torch.autograd.Function):
+  """slim.conv2d_transpose 4 x 4 stride 2 (torch ConvTranspose2d(k, stride 2,
+  padding p); reference nets.py:100-103, 295-345): the data gradient of the
+  forward convolution {2h x 2w x Cout_T -> h x w x Cin_T} with the same weight
+  memory -- four parity classes, 2 x 2 taps each (lsi_conv2d_bwd_data); its own
+  data gradient is that forward convolution (lsi_conv2d_fwd)."""
+
+  @staticmethod
+  def forward(ctx, x, weight, stride, pad):
+    n, cin_t, h, w = x.shape
+    _, cout_t, kh, kw = weight.shape
+    desc = _conv_desc(n, stride * h, stride * w, cout_t, h, w, cin_t, kh, kw, stride, pad, pad)
+    ctx.desc = desc
+    ctx.save_for_backward(x, weight)
+    ctx.args = (stride, pad)
+    return _igemm('lsi_conv2d_bwd_data', desc, x, weight,
+                  _empty_cl(n, cout_t, stride * h, stride * w, x.device))
+
+  @staticmethod
+  def backward(ctx, g):
+    x, weight = ctx.saved_tensors
+    d = ctx.desc
+    stride, pad = ctx.args
+    if g.dtype != torch.bfloat16:
+      g = g.to(torch.bfloat16)
+    g = g.contiguous(memory_format=torch.channels_last)
+    gx = gw = None
+    if ctx.needs_input_grad[0]:
+      gx = _igemm('lsi_conv2d_fwd', d, g, weight,
+                  _empty_cl(d.N, d.Cout, d.OH, d.OW, x.device))
+    if ctx.needs_input_grad[1]:
+      gw = torch.ops.aten.convolution_backward(
+          g, x, weight.to(g.dtype), None, [stride, stride], [pad, pad], [1, 1], True,
+          [0, 0], 1, [False, True, False])[1].to(weight.dtype)
+    return gx, gw, None, None
+
+
+def conv_transpose2d(x, weight, stride=2, pad=1):
+  return _ConvTranspose2dIgemm.apply(x, weight, stride, pad)
+
+
+def convt_supported(x, cin, cout, k, stride):
+  return (_cl_bf16(x) and x.shape[1] == cin and cin % 32 == 0 and cout % 32 == 0 and
+          k <= 7 and stride == 2 and
+          x.shape[0] * x.shape[2] * x.shape[3] * 4 >= IGEMM_MIN_PIXELS)

@@ -164,3 +164,126 @@ def test_library_convolution_with_the_own_weight_gradient(dev, monkeypatch):
   # below the size threshold the layer stays on the library
   monkeypatch.setattr(_hip_conv, 'WGRAD_MIN_PIXELS', 10 ** 9)
   assert not _hip_conv.wgrad_supported(x, cin, cout, 3, 1)
+
+
+# ---- the implicit-GEMM kernel (csrc/lsi_conv_igemm.hip): every other layer ----------
+
+def _same_pads(size, k, s):
+  """TF `SAME`: (before, after, out)."""
+  out = -(-size // s)
+  total = max((out - 1) * s + k - size, 0)
+  return total // 2, total - total // 2, out
+
+
+def _cl(t):
+  return t.contiguous(memory_format=torch.channels_last)
+
+
+IGEMM_CASES = [
+    # n, cin, cout, h, w, k, stride
+    (2, 96, 64, 40, 48, 3, 1),      # upcnv2b
+    (1, 192, 128, 20, 36, 3, 1),    # upcnv3b
+    (2, 32, 32, 33, 50, 3, 1),      # ragged tile edges
+    (1, 32, 32, 30, 40, 7, 1),      # cnv1b
+    (1, 64, 64, 18, 24, 5, 1),      # cnv2b
+    (2, 64, 128, 32, 48, 3, 2),     # cnv3 (TF SAME: 0 before, 1 after)
+    (1, 32, 64, 24, 40, 5, 2),      # cnv2 (1 / 2)
+    (2, 512, 512, 4, 12, 3, 1),     # cnv6b: a map smaller than the tile
+    (1, 256, 96, 9, 7, 3, 2),       # odd sizes, 96 output channels (BN = 32)
+    (8, 1024, 512, 4, 12, 3, 1),    # icnv7
+]
+
+
+@pytest.mark.parametrize('case', IGEMM_CASES)
+def test_igemm_convolution_forward_and_gradients(case, dev):
+  """slim.conv2d with TF SAME padding (reference nets.py:244-348): forward,
+  data gradient and weight gradient against fp32 autograd of the same
+  bf16-rounded operands."""
+  from lsi.nnutils import _hip_conv
+  n, cin, cout, h, w, k, s = case
+  g = torch.Generator().manual_seed(11)
+  x = _cl(torch.randn((n, cin, h, w), generator=g).to(dev).to(torch.bfloat16)).requires_grad_(True)
+  wt = (torch.randn((cout, cin, k, k), generator=g) * (2.0 / (cin * k * k)) ** 0.5).to(dev).requires_grad_(True)
+  pt, pb, oh = _same_pads(h, k, s)
+  pl, pr, ow = _same_pads(w, k, s)
+  assert _hip_conv.igemm_supported(x, cin, cout, k, s)
+  got = _hip_conv.conv2d(x, wt, s, pt, pl, oh, ow)
+  assert got.dtype == torch.bfloat16 and got.shape == (n, cout, oh, ow)
+  assert got.is_contiguous(memory_format=torch.channels_last)
+  xr = x.detach().float().requires_grad_(True)
+  wr = wt.detach().to(torch.bfloat16).float().requires_grad_(True)
+  want = F.conv2d(F.pad(xr, (pl, pr, pt, pb)), wr, None, s)
+  err = (got.float() - want).abs()
+  assert float((err - want.abs() * 2.0 ** -8).max()) <= 2e-3, float(err.max())
+  c = torch.randn(want.shape, generator=g).to(dev).to(torch.bfloat16)
+  (got.float() * c.float()).sum().backward()
+  (want * c.float()).sum().backward()
+  gx, gxr = x.grad.float(), xr.grad
+  tol = float(gxr.abs().max()) * 2.0 ** -7 + 1e-6
+  assert float((gx - gxr).abs().max()) <= tol, (float((gx - gxr).abs().max()), tol)
+  gw, gwr = wt.grad, wr.grad
+  tolw = float(gwr.abs().max()) * 2e-2 + 1e-5
+  assert float((gw - gwr).abs().max()) <= tolw, (float((gw - gwr).abs().max()), tolw)
+
+
+@pytest.mark.parametrize('case', [(2, 128, 64, 16, 24), (1, 64, 32, 33, 20), (8, 512, 512, 2, 6),
+                                  (1, 128, 128, 64, 192)])
+def test_igemm_transposed_convolution(case, dev):
+  """slim.conv2d_transpose 4 x 4 stride 2 (reference nets.py:100-103) = torch
+  ConvTranspose2d(k = 4, stride 2, padding 1): four parity classes of 2 x 2 taps."""
+  from lsi.nnutils import _hip_conv
+  n, cin, cout, h, w = case
+  g = torch.Generator().manual_seed(12)
+  x = _cl(torch.randn((n, cin, h, w), generator=g).to(dev).to(torch.bfloat16)).requires_grad_(True)
+  wt = (torch.randn((cin, cout, 4, 4), generator=g) * (2.0 / (cin * 4)) ** 0.5).to(dev).requires_grad_(True)
+  assert _hip_conv.convt_supported(x, cin, cout, 4, 2)
+  got = _hip_conv.conv_transpose2d(x, wt)
+  assert got.shape == (n, cout, 2 * h, 2 * w) and got.dtype == torch.bfloat16
+  xr = x.detach().float().requires_grad_(True)
+  wr = wt.detach().to(torch.bfloat16).float().requires_grad_(True)
+  want = F.conv_transpose2d(xr, wr, None, 2, 1)
+  err = (got.float() - want).abs()
+  assert float((err - want.abs() * 2.0 ** -8).max()) <= 2e-3, float(err.max())
+  c = torch.randn(want.shape, generator=g).to(dev).to(torch.bfloat16)
+  (got.float() * c.float()).sum().backward()
+  (want * c.float()).sum().backward()
+  gx, gxr = x.grad.float(), xr.grad
+  tol = float(gxr.abs().max()) * 2.0 ** -7 + 1e-6
+  assert float((gx - gxr).abs().max()) <= tol, (float((gx - gxr).abs().max()), tol)
+  gw, gwr = wt.grad, wr.grad
+  tolw = float(gwr.abs().max()) * 2e-2 + 1e-5
+  assert float((gw - gwr).abs().max()) <= tolw, (float((gw - gwr).abs().max()), tolw)
+
+
+def test_igemm_refuses_what_it_does_not_take(dev):
+  import ctypes
+  from lsi import _C
+  d = _C.LsiConvDesc()
+  d.N, d.H, d.W, d.Cin, d.OH, d.OW, d.Cout = 1, 8, 8, 3, 8, 8, 32
+  d.KH = d.KW = 3; d.stride = 1; d.pad_t = d.pad_l = 1
+  assert _C.lib().lsi_conv2d_supported(ctypes.byref(d)) == 0
+  assert _C.lib().lsi_conv2d_packed_bytes(ctypes.byref(d)) == 0
+  buf = torch.zeros(4096, device=dev)
+  rc = _C.lib().lsi_conv2d_fwd(ctypes.byref(d), buf.data_ptr(), buf.data_ptr(), buf.data_ptr(),
+                               None)
+  assert rc == -5   # LSI_EUNSUPPORTED
+  rc = _C.lib().lsi_conv2d_pack(ctypes.byref(d), 0, buf.data_ptr(), buf.data_ptr(), 16384, None)
+  assert rc == -5
+
+
+def test_packed_weights_follow_the_parameter(dev):
+  """The packed form is remembered per parameter and version: an in-place
+  update (the optimiser's step) must be seen by the next call."""
+  from lsi.nnutils import _hip_conv
+  g = torch.Generator().manual_seed(13)
+  x = _cl(torch.randn((1, 32, 16, 16), generator=g).to(dev).to(torch.bfloat16))
+  wt = (torch.randn((32, 32, 3, 3), generator=g) * 0.1).to(dev)
+  a = _hip_conv.conv2d(x, wt, 1, 1, 1, 16, 16).float()
+  b = _hip_conv.conv2d(x, wt, 1, 1, 1, 16, 16).float()
+  assert torch.equal(a, b)
+  with torch.no_grad():
+    wt.mul_(2.0)
+  c = _hip_conv.conv2d(x, wt, 1, 1, 1, 16, 16).float()
+  want = F.conv2d(x.float(), wt.to(torch.bfloat16).float(), None, 1, 1)
+  assert float((c - want).abs().max()) <= 2e-3 + float(want.abs().max()) * 2.0 ** -8
+  assert float((c - 2 * a).abs().max()) <= float(c.abs().max()) * 2.0 ** -6
