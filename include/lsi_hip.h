@@ -539,6 +539,22 @@ int lsi_conv2d_supported(const LsiConvDesc* d);
 size_t lsi_conv2d_packed_bytes(const LsiConvDesc* d);
 int lsi_conv2d_pack(const LsiConvDesc* d, int32_t mode, const float* weight, void* packed,
                     size_t packed_bytes, lsi_stream_t stream);
+/* Many layers packed by ONE launch (a training step re-packs every layer after
+ * the optimiser's update: one launch instead of two per layer):
+ * lsi_conv2d_pack_job fills a host-side job record for (d, mode, weight, packed)
+ * and the number of workgroups it needs; the caller sets block0 of every record
+ * to the running sum, copies the table to the device and passes it to
+ * lsi_conv2d_pack_many with the total. */
+typedef struct LsiPackJob {
+  const float* w;     /* the layer's parameter Cout x Cin x KH x KW          */
+  void* dst;          /* packed bf16 weights                                  */
+  int32_t D0, D1, khw, tr, ntaps, block0;
+  int8_t tap[56];     /* ky * KW + kx of every tap, in the kernel's order     */
+} LsiPackJob;
+int lsi_conv2d_pack_job(const LsiConvDesc* d, int32_t mode, const float* weight, void* packed,
+                        size_t packed_bytes, LsiPackJob* job, int32_t* nblocks);
+int lsi_conv2d_pack_many(const LsiPackJob* jobs_device, int32_t njobs, int32_t total_blocks,
+                         lsi_stream_t stream);
 int lsi_conv2d_fwd(const LsiConvDesc* d, const void* x, const void* packed, void* out,
                    lsi_stream_t stream);
 int lsi_conv2d_bwd_data(const LsiConvDesc* d, const void* gy, const void* packed, void* gx,

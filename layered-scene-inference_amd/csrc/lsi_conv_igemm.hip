@@ -225,17 +225,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgArgs a) {
 // D0 x D1 x KH x KW (both multiples of 32).  A workgroup moves a 32 x 32 tile of
 // (d0, d1) per tap through LDS, so that reads and (transposed) writes are both
 // contiguous runs.
-struct PackArgs {
-  const float* w;
-  __bf16* dst;
-  int D0, D1, khw, tr, ntaps;
-  signed char tap[IG_MAXTAPS + 3];  // ky * KW + kx of every tap
-};
-__global__ __launch_bounds__(256) void conv_pack_kernel(PackArgs a) {
-  __shared__ float tile[32][33];
-  const int a0 = blockIdx.y * 32, b0 = blockIdx.x * 32;
+typedef LsiPackJob PackArgs;   // {w, dst, D0, D1, khw, tr, ntaps, block0, tap[]}
+__device__ __forceinline__ void pack_tile(const PackArgs& a, int bx, int by,
+                                          float (*tile)[33]) {
+  const int a0 = by * 32, b0 = bx * 32;
   const int c = threadIdx.x & 31, r0 = threadIdx.x >> 5;
   const size_t per = (size_t)a.D0 * a.D1;
+  __bf16* const dst = reinterpret_cast<__bf16*>(a.dst);
   for (int t = 0; t < a.ntaps; ++t) {
     const int tap = a.tap[t];
 #pragma unroll
@@ -248,12 +244,31 @@ __global__ __launch_bounds__(256) void conv_pack_kernel(PackArgs a) {
     for (int j = 0; j < 4; ++j) {
       const int r = r0 + 8 * j;
       if (a.tr)   // dst[t][d1][d0]
-        a.dst[(size_t)t * per + (size_t)(b0 + r) * a.D0 + a0 + c] = (__bf16)tile[c][r];
+        dst[(size_t)t * per + (size_t)(b0 + r) * a.D0 + a0 + c] = (__bf16)tile[c][r];
       else        // dst[t][d0][d1]
-        a.dst[(size_t)t * per + (size_t)(a0 + r) * a.D1 + b0 + c] = (__bf16)tile[r][c];
+        dst[(size_t)t * per + (size_t)(a0 + r) * a.D1 + b0 + c] = (__bf16)tile[r][c];
     }
     __syncthreads();
   }
+}
+__global__ __launch_bounds__(256) void conv_pack_kernel(PackArgs a) {
+  __shared__ float tile[32][33];
+  pack_tile(a, blockIdx.x, blockIdx.y, tile);
+}
+// Many layers in one launch: job j owns blocks [block0_j, block0_{j+1}) (the
+// table lives in device memory; the last entry's block0 + its blocks = grid).
+__global__ __launch_bounds__(256) void conv_pack_many_kernel(const PackArgs* jobs, int njobs) {
+  __shared__ float tile[32][33];
+  __shared__ int which;
+  if (threadIdx.x == 0) {
+    int j = 0;
+    while (j + 1 < njobs && (int)blockIdx.x >= jobs[j + 1].block0) ++j;
+    which = j;
+  }
+  __syncthreads();
+  const PackArgs a = jobs[which];
+  const int lb = (int)blockIdx.x - a.block0, nbx = a.D1 / 32;
+  pack_tile(a, lb % nbx, lb / nbx, tile);
 }
 
 constexpr size_t IG_LDS_CAP = 80 * 1024;  // two workgroups per CU
@@ -362,7 +377,7 @@ bool desc_ok(const LsiConvDesc* d) {
 // The tap lists of a call.  mode 0: forward (one class); mode 1: data gradient
 // (stride^2 parity classes of input pixels).  `tap` receives ky * KW + kx of
 // every tap in class order (the order of the packed weights).
-void ig_classes(const LsiConvDesc* d, int mode, IgArgs& k, signed char* tap) {
+void ig_classes(const LsiConvDesc* d, int mode, IgArgs& k, int8_t* tap) {
   memset(&k, 0, sizeof(k));
   int nt = 0;
   if (mode == 0) {
@@ -413,22 +428,42 @@ extern "C" size_t lsi_conv2d_packed_bytes(const LsiConvDesc* d) {
   return (size_t)d->KH * d->KW * d->Cin * d->Cout * sizeof(__bf16);
 }
 
-extern "C" int lsi_conv2d_pack(const LsiConvDesc* d, int32_t mode, const float* weight,
-                               void* packed, size_t packed_bytes, lsi_stream_t stream_) {
-  if (!d || !weight || !packed) return LSI_ENULL;
+extern "C" int lsi_conv2d_pack_job(const LsiConvDesc* d, int32_t mode, const float* weight,
+                                   void* packed, size_t packed_bytes, LsiPackJob* job,
+                                   int32_t* nblocks) {
+  if (!d || !weight || !packed || !job || !nblocks) return LSI_ENULL;
   if (!desc_ok(d)) return LSI_EUNSUPPORTED;
   if (mode != 0 && mode != 1) return LSI_EINVAL;
   if ((uintptr_t)packed & 15) return LSI_EINVAL;
   if (packed_bytes < lsi_conv2d_packed_bytes(d)) return LSI_EWORKSPACE;
   IgArgs k;
-  PackArgs p;
-  memset(&p, 0, sizeof(p));
-  ig_classes(d, mode, k, p.tap);
-  p.w = weight; p.dst = (__bf16*)packed;
-  p.D0 = d->Cout; p.D1 = d->Cin; p.khw = d->KH * d->KW; p.tr = mode;
-  p.ntaps = d->KH * d->KW;
+  memset(job, 0, sizeof(*job));
+  ig_classes(d, mode, k, job->tap);
+  job->w = weight; job->dst = packed;
+  job->D0 = d->Cout; job->D1 = d->Cin; job->khw = d->KH * d->KW; job->tr = mode;
+  job->ntaps = d->KH * d->KW;
+  job->block0 = 0;
+  *nblocks = (d->Cin / 32) * (d->Cout / 32);
+  return LSI_OK;
+}
+
+extern "C" int lsi_conv2d_pack(const LsiConvDesc* d, int32_t mode, const float* weight,
+                               void* packed, size_t packed_bytes, lsi_stream_t stream_) {
+  LsiPackJob p;
+  int32_t nb;
+  const int rc = lsi_conv2d_pack_job(d, mode, weight, packed, packed_bytes, &p, &nb);
+  if (rc != LSI_OK) return rc;
   hipLaunchKernelGGL(conv_pack_kernel, dim3(d->Cin / 32, d->Cout / 32), dim3(256), 0,
                      (hipStream_t)stream_, p);
+  return hipGetLastError() == hipSuccess ? LSI_OK : LSI_ELAUNCH;
+}
+
+extern "C" int lsi_conv2d_pack_many(const LsiPackJob* jobs_device, int32_t njobs,
+                                    int32_t total_blocks, lsi_stream_t stream_) {
+  if (!jobs_device) return LSI_ENULL;
+  if (njobs <= 0 || total_blocks <= 0) return LSI_EINVAL;
+  hipLaunchKernelGGL(conv_pack_many_kernel, dim3(total_blocks), dim3(256), 0,
+                     (hipStream_t)stream_, jobs_device, njobs);
   return hipGetLastError() == hipSuccess ? LSI_OK : LSI_ELAUNCH;
 }
 
@@ -438,7 +473,7 @@ static int ig_run(const LsiConvDesc* d, int mode, const void* src, const void* p
   if (!desc_ok(d)) return LSI_EUNSUPPORTED;
   if (((uintptr_t)src & 15) || ((uintptr_t)dst & 7) || ((uintptr_t)packed & 15)) return LSI_EINVAL;
   IgArgs k;
-  signed char tap[IG_MAXTAPS + 3];
+  int8_t tap[56];
   ig_classes(d, mode, k, tap);
   k.x = (const __bf16*)src; k.wp = (const __bf16*)packed; k.out = (__bf16*)dst;
   return ig_launch(k, (hipStream_t)stream_);

@@ -59,6 +59,12 @@ class LsiConvDesc(ctypes.Structure):
       'N', 'H', 'W', 'Cin', 'OH', 'OW', 'Cout', 'KH', 'KW', 'stride', 'pad_t', 'pad_l')]
 
 
+class LsiPackJob(ctypes.Structure):
+  _fields_ = ([('w', ctypes.c_void_p), ('dst', ctypes.c_void_p)] +
+              [(n, ctypes.c_int32) for n in ('D0', 'D1', 'khw', 'tr', 'ntaps', 'block0')] +
+              [('tap', ctypes.c_int8 * 56)])
+
+
 # name -> (restype, argtypes); every symbol include/lsi_hip.h declares.
 _I32, _I64, _VP, _SZ = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p, ctypes.c_size_t
 _DP = ctypes.POINTER(LsiSplatDesc)
@@ -107,6 +113,9 @@ SIGNATURES = {
     'lsi_conv2d_supported': (ctypes.c_int, [_CP]),
     'lsi_conv2d_packed_bytes': (_SZ, [_CP]),
     'lsi_conv2d_pack': (ctypes.c_int, [_CP, _I32, _VP, _VP, _SZ, _VP]),
+    'lsi_conv2d_pack_job': (ctypes.c_int, [_CP, _I32, _VP, _VP, _SZ,
+                                           ctypes.POINTER(LsiPackJob), _c_i]),
+    'lsi_conv2d_pack_many': (ctypes.c_int, [_VP, _I32, _I32, _VP]),
     'lsi_conv2d_fwd': (ctypes.c_int, [_CP] + [_VP] * 4),
     'lsi_conv2d_bwd_data': (ctypes.c_int, [_CP] + [_VP] * 4),
     'lsi_bn_workspace_floats': (_SZ, [_I64, _I32, _I32, _I32]),

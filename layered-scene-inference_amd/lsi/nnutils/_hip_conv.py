@@ -272,21 +272,29 @@ def _f32(weight):
   return weight
 
 
-_PACKED = {}   # (id(weight), mode) -> (weakref, version, shape key, packed bf16 weights)
+import weakref
+
+
+class _Pack(object):
+  """One layer's weights in the kernel's operand order for one direction."""
+  __slots__ = ('wref', 'version', 'geo', 'buf', 'mode', 'desc')
+
+
+_PACKED = {}   # (id(weight), mode) -> _Pack
+_PACK_TABLE = {}  # device index -> (key, device table, njobs, blocks, entries)
 
 
 def _packed(desc, mode, weight):
   """The layer's weights in the kernel's operand order (lsi_conv2d_pack), kept
   until the parameter changes (its version counter: the optimiser's in-place
-  step moves it) -- an evaluation loop packs once, a training step once per
-  direction."""
-  import weakref
+  step moves it) -- an evaluation loop packs once; a training loop calls
+  repack_all() after the optimiser's step: one launch for all layers."""
   key = (id(weight), mode)
-  geo = (desc.Cin, desc.Cout, desc.KH, desc.KW, desc.stride, desc.pad_t, desc.pad_l)
   hit = _PACKED.get(key)
-  if (hit is not None and hit[0]() is weight and hit[1] == weight._version and
-      hit[2] == geo and hit[3].device == weight.device):
-    return hit[3]
+  if hit is not None and hit.wref() is weight and hit.buf.device == weight.device:
+    geo = (desc.Cin, desc.Cout, desc.KH, desc.KW, desc.stride, desc.pad_t, desc.pad_l)
+    if hit.version == weight._version and hit.geo == geo:
+      return hit.buf
   lib = _C.lib()
   dev = weight.device
   nbytes = lib.lsi_conv2d_packed_bytes(ctypes.byref(desc))
@@ -294,17 +302,71 @@ def _packed(desc, mode, weight):
   rc = lib.lsi_conv2d_pack(ctypes.byref(desc), mode, _C.ptr(_f32(weight)), _C.ptr(buf),
                            nbytes, _C.stream_ptr(dev))
   _C.check(rc, 'lsi_conv2d_pack')
-  _PACKED[key] = (weakref.ref(weight, lambda _r, k=key: _PACKED.pop(k, None)),
-                  weight._version, geo, buf)
+  e = _Pack()
+  e.wref = weakref.ref(weight, lambda _r, k=key: _PACKED.pop(k, None))
+  e.version = weight._version
+  e.geo = (desc.Cin, desc.Cout, desc.KH, desc.KW, desc.stride, desc.pad_t, desc.pad_l)
+  e.buf, e.mode, e.desc = buf, mode, desc
+  _PACKED[key] = e
   return buf
+
+
+def repack_all(device=None):
+  """Re-packs, with ONE launch (lsi_conv2d_pack_many), the weights of every
+  layer the implicit-GEMM kernels have run so far -- the trainer calls it right
+  after the optimiser's step, so that the step's forward and backward find their
+  operands ready (eagerly: two launches per layer less; captured in a HIP graph:
+  the packs belong to the graph, whatever the version counters said at capture
+  time).  Parameters that are not plain fp32 tensors are left to _packed()."""
+  if not _PACKED:
+    return 0
+  lib = _C.lib()
+  by_dev = {}
+  for e in list(_PACKED.values()):
+    w = e.wref()
+    if w is None or not w.is_cuda or w.dtype != torch.float32 or not w.is_contiguous():
+      continue
+    if device is not None and w.device != device:
+      continue
+    if not w.requires_grad and e.version == w._version:
+      continue   # (a frozen parameter that has not moved)
+    by_dev.setdefault(w.device.index, []).append((e, w))
+  n = 0
+  for idx, items in by_dev.items():
+    key = tuple((w.data_ptr(), e.buf.data_ptr(), e.mode) for e, w in items)
+    tab = _PACK_TABLE.get(idx)
+    if tab is None or tab[0] != key:
+      jobs = (_C.LsiPackJob * len(items))()
+      nb = ctypes.c_int32(0)
+      blocks = 0
+      for j, (e, w) in enumerate(items):
+        rc = lib.lsi_conv2d_pack_job(ctypes.byref(e.desc), e.mode, w.data_ptr(),
+                                     e.buf.data_ptr(), e.buf.numel() * 2,
+                                     ctypes.byref(jobs[j]), ctypes.byref(nb))
+        _C.check(rc, 'lsi_conv2d_pack_job')
+        jobs[j].block0 = blocks
+        blocks += nb.value
+      host = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8)
+      tab = (key, host.to(items[0][1].device), len(items), blocks)
+      _PACK_TABLE[idx] = tab
+    dev = items[0][1].device
+    rc = lib.lsi_conv2d_pack_many(tab[1].data_ptr(), tab[2], tab[3], _C.stream_ptr(dev))
+    _C.check(rc, 'lsi_conv2d_pack_many')
+    for e, w in items:
+      e.version = w._version
+    n += len(items)
+  return n
 
 
 def _igemm(entry, desc, src, weight, out):
   mode = 1 if entry == 'lsi_conv2d_bwd_data' else 0
   packed = _packed(desc, mode, weight)
-  rc = getattr(_C.lib(), entry)(ctypes.byref(desc), _C.ptr(src), _C.ptr(packed), _C.ptr(out),
-                                _C.stream_ptr(src.device))
-  _C.check(rc, entry)
+  lib = _C.lib()
+  fn = lib.lsi_conv2d_bwd_data if mode else lib.lsi_conv2d_fwd
+  rc = fn(ctypes.byref(desc), src.data_ptr(), packed.data_ptr(), out.data_ptr(),
+          _C.stream_ptr(src.device))
+  if rc:
+    _C.check(rc, entry)
   return out
 
 

@@ -47,6 +47,18 @@ IMPLICIT_PAD = os.environ.get('LSI_IMPLICIT_PAD', '1') != '0'
 MFMA_CONV = os.environ.get('LSI_MFMA_CONV', '1') != '0'
 # bf16 batch norm on large maps under autocast (LSI_BF16_BN=0 restores fp32)
 BF16_BATCH_NORM = os.environ.get('LSI_BF16_BN', '1') != '0'
+# Every other convolution with channel counts that are multiples of 32 on the
+# implicit-GEMM MFMA kernel (csrc/lsi_conv_igemm.hip); LSI_IGEMM_CONV=0: MIOpen.
+# Maps with fewer than IGEMM_MIN_PIXELS pixels (batch included; on the smaller
+# side of the layer) stay on the library: the bottleneck layers are small GEMMs
+# with too few tiles for this kernel (tools/conv_bench.py: profiles/r05/conv_bench.txt)
+IGEMM_CONV = os.environ.get('LSI_IGEMM_CONV', '1') != '0'
+IGEMM_MIN_PIXELS = int(os.environ.get('LSI_IGEMM_MIN_PIXELS', '1024'))
+
+
+def _igemm_pays(x, stride):
+  n, _, h, w = x.shape
+  return n * (-(-h // stride)) * (-(-w // stride)) >= IGEMM_MIN_PIXELS
 # batch norm + ReLU of the conv layers as the fused HIP kernels (csrc/lsi_bn.hip)
 # for channels-last activations on the GPU; LSI_FUSED_BN=0 keeps MIOpen's
 FUSED_BN = os.environ.get('LSI_FUSED_BN', '1') != '0'
@@ -169,6 +181,16 @@ class SlimConv2d(nn.Module):
           return _hip_conv.conv3x3_c32_sigmoid(x, self.conv.weight, self.conv.bias)
         x = _hip_conv.conv3x3_c32(x, self.conv.weight)
         return self._bn_act(x)
+      if (IGEMM_CONV and self.bn is not None and
+          _hip_conv.igemm_supported(x, cin, cout, self.k, self.stride) and
+          _igemm_pays(x, self.stride)):
+        # every other batch-normed layer: the implicit-GEMM kernel (forward and
+        # data gradient; weight gradient on lsi_conv3x3_wgrad or the library)
+        ph = _same_pad(x.shape[2], self.k, self.stride)
+        pw = _same_pad(x.shape[3], self.k, self.stride)
+        x = _hip_conv.conv2d(x, self.conv.weight, self.stride, ph[0], pw[0],
+                             -(-x.shape[2] // self.stride), -(-x.shape[3] // self.stride))
+        return self._bn_act(x)
       if (self.bn is not None and torch.is_grad_enabled() and
           self.conv.weight.requires_grad and
           _hip_conv.wgrad_supported(x, cin, cout, self.k, self.stride)):
@@ -217,6 +239,13 @@ class SlimConvTranspose2d(nn.Module):
     self.bn = SlimBatchNorm(cout)
 
   def forward(self, x):
+    if MFMA_CONV and IGEMM_CONV and x.is_cuda and x.dtype == torch.bfloat16:
+      from lsi.nnutils import _hip_conv  # pylint: disable=g-import-not-at-top
+      cin, cout = self.conv.weight.shape[:2]
+      # four parity classes of 2 x 2 taps on the implicit-GEMM kernel
+      if (_hip_conv.convt_supported(x, cin, cout, 4, 2) and
+          x.shape[0] * x.shape[2] * x.shape[3] >= IGEMM_MIN_PIXELS):
+        return _bn_relu(self.bn, _hip_conv.conv_transpose2d(x, self.conv.weight))
     return _bn_relu(self.bn, self.conv(x))
 
 

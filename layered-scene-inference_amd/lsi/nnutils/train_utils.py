@@ -254,7 +254,15 @@ class Trainer(object):
     if self.flat_grads:
       self._reduce_flat()
     self.optim.step()
+    self._after_update()
     return out
+
+  def _after_update(self):
+    """The convolution kernels' packed weights follow the parameters: one
+    launch for all layers (lsi_conv2d_pack_many) right after the update."""
+    if self.device.type == 'cuda':
+      from lsi.nnutils import _hip_conv  # pylint: disable=g-import-not-at-top
+      _hip_conv.repack_all(self.device)
 
   def train_step(self):
     batch = self.feed()
@@ -304,6 +312,7 @@ class Trainer(object):
                                 pool=graph.pool(),
                                 capture_error_mode='thread_local'):
             self.optim.step()
+            self._after_update()
         self._graph = graph
         out = None
     cur.wait_stream(self._stream)

@@ -175,7 +175,7 @@ def _same_pads(size, k, s):
   return total // 2, total - total // 2, out
 
 
-def _cl(t):
+def _clast(t):
   return t.contiguous(memory_format=torch.channels_last)
 
 
@@ -202,7 +202,7 @@ def test_igemm_convolution_forward_and_gradients(case, dev):
   from lsi.nnutils import _hip_conv
   n, cin, cout, h, w, k, s = case
   g = torch.Generator().manual_seed(11)
-  x = _cl(torch.randn((n, cin, h, w), generator=g).to(dev).to(torch.bfloat16)).requires_grad_(True)
+  x = _clast(torch.randn((n, cin, h, w), generator=g).to(dev).to(torch.bfloat16)).requires_grad_(True)
   wt = (torch.randn((cout, cin, k, k), generator=g) * (2.0 / (cin * k * k)) ** 0.5).to(dev).requires_grad_(True)
   pt, pb, oh = _same_pads(h, k, s)
   pl, pr, ow = _same_pads(w, k, s)
@@ -234,7 +234,7 @@ def test_igemm_transposed_convolution(case, dev):
   from lsi.nnutils import _hip_conv
   n, cin, cout, h, w = case
   g = torch.Generator().manual_seed(12)
-  x = _cl(torch.randn((n, cin, h, w), generator=g).to(dev).to(torch.bfloat16)).requires_grad_(True)
+  x = _clast(torch.randn((n, cin, h, w), generator=g).to(dev).to(torch.bfloat16)).requires_grad_(True)
   wt = (torch.randn((cin, cout, 4, 4), generator=g) * (2.0 / (cin * 4)) ** 0.5).to(dev).requires_grad_(True)
   assert _hip_conv.convt_supported(x, cin, cout, 4, 2)
   got = _hip_conv.conv_transpose2d(x, wt)
@@ -276,7 +276,7 @@ def test_packed_weights_follow_the_parameter(dev):
   update (the optimiser's step) must be seen by the next call."""
   from lsi.nnutils import _hip_conv
   g = torch.Generator().manual_seed(13)
-  x = _cl(torch.randn((1, 32, 16, 16), generator=g).to(dev).to(torch.bfloat16))
+  x = _clast(torch.randn((1, 32, 16, 16), generator=g).to(dev).to(torch.bfloat16))
   wt = (torch.randn((32, 32, 3, 3), generator=g) * 0.1).to(dev)
   a = _hip_conv.conv2d(x, wt, 1, 1, 1, 16, 16).float()
   b = _hip_conv.conv2d(x, wt, 1, 1, 1, 16, 16).float()
@@ -287,3 +287,29 @@ def test_packed_weights_follow_the_parameter(dev):
   want = F.conv2d(x.float(), wt.to(torch.bfloat16).float(), None, 1, 1)
   assert float((c - want).abs().max()) <= 2e-3 + float(want.abs().max()) * 2.0 ** -8
   assert float((c - 2 * a).abs().max()) <= float(c.abs().max()) * 2.0 ** -6
+
+
+def test_repack_all_refreshes_every_layer_with_one_launch(dev):
+  """lsi_conv2d_pack_many: after an in-place update of the parameters (the
+  optimiser's step) one call brings every packed form up to date."""
+  from lsi.nnutils import _hip_conv
+  g = torch.Generator().manual_seed(14)
+  x = _clast(torch.randn((1, 64, 12, 16), generator=g).to(dev).to(torch.bfloat16)).requires_grad_(True)
+  w1 = (torch.randn((32, 64, 3, 3), generator=g) * 0.1).to(dev).requires_grad_(True)
+  w2 = (torch.randn((64, 32, 4, 4), generator=g) * 0.1).to(dev).requires_grad_(True)
+  def run():
+    y = _hip_conv.conv2d(x, w1, 1, 1, 1, 12, 16)
+    z = _hip_conv.conv_transpose2d(x, w2)
+    return y.float(), z.float()
+  y0, z0 = run()
+  y0.sum().backward()     # (packs the data-gradient form of w1 as well)
+  y0, z0 = y0.detach(), z0.detach()
+  with torch.no_grad():
+    w1.mul_(-2.0); w2.mul_(3.0)
+  assert _hip_conv.repack_all(dev) >= 3
+  # (the version counters now match: the calls below must not pack again)
+  packs = dict((k, e.buf.data_ptr()) for k, e in _hip_conv._PACKED.items())
+  y1, z1 = run()
+  assert packs == dict((k, e.buf.data_ptr()) for k, e in _hip_conv._PACKED.items())
+  assert float((y1 + 2 * y0).abs().max()) <= float(y1.abs().max()) * 2.0 ** -6
+  assert float((z1 - 3 * z0).abs().max()) <= float(z1.abs().max()) * 2.0 ** -6
