@@ -499,6 +499,22 @@ int lsi_conv3x3_wgrad(int32_t N, int32_t H, int32_t W, int32_t cin, int32_t cout
                       size_t workspace_bytes, lsi_stream_t stream);
 
 /*
+ * The compact STREAM kernel has two builds (12 waves x two items in flight, 16 x
+ * one); which is faster depends on the disparity field, which the planner does
+ * not see.  The kernel counts the items that took its folded routes on a few
+ * probe launches (the first calls of a geometry, then two of every 64); a later
+ * call reads the count -- asynchronously copied, never waited for -- and picks
+ * the build.  This is the library's only state besides memoised plans: per call
+ * geometry 8 bytes of device memory, 8 of pinned host memory, one event.
+ * tune_threads != 0, LSI_S2_WIDE and LSI_S2_ADAPT=0 switch it off; launches
+ * under stream capture use the standing decision.
+ * lsi_stream_adapt_state: that decision for a descriptor prepared as for
+ * lsi_splat_fwd (tune_window from lsi_stream_ok) on the current device:
+ * 0 undecided, 1 twelve waves, 2 sixteen waves, -1 unknown geometry / off.
+ */
+int lsi_stream_adapt_state(const LsiSplatDesc* d);
+
+/*
  * Convolutions of the encoder-decoder and the LDI heads on the matrix cores
  * (reference nets.py:29-70 encoder, 73-114 decoder_simple, 244-348 U-Net:
  * slim.conv2d k x k stride 1 | 2 with TF `SAME` padding, slim.conv2d_transpose

@@ -80,6 +80,9 @@ struct S2Args {
   int nsplit, lsub;                // units handed out lsub layers per ticket
   float inv_gx, inv_nseg;
   long long* stamps;  // S2X_STAMPS build: [workgroup][wave][8] wall-clock ticks
+  // probe launches (s2_adapt): {items on the folded routes B' / C, all items} of
+  // the launch are added here, one atomic pair per workgroup; NULL otherwise
+  unsigned* route_ctr;
 };
 
 #define S2_FENCE() asm volatile("" ::: "memory")
@@ -791,11 +794,14 @@ __global__ __launch_bounds__(MAXT) void splat_stream2_kernel(S2Args a) {
   float qb[4] = {0.f, 0.f, 0.f, 0.f};
   bool lane_dead = false;   // this lane's pixels of the current unit are past the row end
   int qn = 0;
+  // items of this wave: all in the low half, those on routes B' / C in the high
+  // half (s2_adapt; a scalar register)
+  unsigned n_items = 0u;
 #ifdef S2X_STAMPS
   unsigned route_n[4] = {0u, 0u, 0u, 0u};  // items by route: A, B, B' (folded), C (general)
-#define S2_ROUTE(k) (route_n[k] += 1u)
+#define S2_ROUTE(k) do { route_n[k] += 1u; n_items = S2_RFL(n_items + (((k) >= 2) ? 0x10001u : 1u)); } while (0)
 #else
-#define S2_ROUTE(k)
+#define S2_ROUTE(k) (n_items = S2_RFL(n_items + (((k) >= 2) ? 0x10001u : 1u)))
 #endif
   // merge: the lane's window slots (cells lane, lane + 64, ...)
   const int mslot = (lane >> 1) + (lane & 1) * WHS;
@@ -1253,7 +1259,17 @@ __global__ __launch_bounds__(MAXT) void splat_stream2_kernel(S2Args a) {
     __syncthreads();
   }
   S2_STAMP(4);
+  if (a.route_ctr) {  // (probe launches only: ctl[2], ctl[3] are free)
+    if (lane == 0) {
+      atomicAdd(reinterpret_cast<unsigned*>(&ctl[2]), n_items >> 16);
+      atomicAdd(reinterpret_cast<unsigned*>(&ctl[3]), n_items & 0xffffu);
+    }
+  }
   __syncthreads();  // every window is merged: the tile is complete
+  if (a.route_ctr && tid == 0) {
+    atomicAdd(a.route_ctr, (unsigned)ctl[2]);
+    atomicAdd(a.route_ctr + 1, (unsigned)ctl[3]);
+  }
   S2_STAMP(5);
   // ---- epilogue: (tile + background) normalised, each output written once --
   // (a.ep: 0 scalar stores; 1 / 2 / 3 four cells per lane, plain / write-through
@@ -1697,7 +1713,112 @@ bool s2_choose(const LsiSplatDesc* d, int wmax, bool both, S2Plan* plan, bool* w
   return true;
 }
 
+// ---- which build for a field the planner cannot see -----------------------------
+// Smooth disparity fields (a trained network's, the benchmark's) run best on 12
+// waves x two register sets; folded / noisy fields (an untrained network's) 12 -
+// 15 % faster on 16 x one.  The kernel knows which it is: it counts the items
+// that took the folded routes B' / C.  Per call geometry the library keeps a
+// small state: on PROBE launches (the first calls, then two of every 64) the
+// kernel adds its counts to a device counter, a 8-byte asynchronous copy brings
+// them to pinned host memory, and the NEXT call that finds the copy complete
+// (hipEventQuery: never a wait) takes the decision -- 16 x 1 when more than
+// FOLD_SHARE of the items were folded.  The decision of a call never depends on
+// that call's own data, no host synchronisation is added, and a launch that is
+// being captured into a HIP graph takes the decision standing at that moment
+// and probes nothing (the graph has it baked in).  tune_threads, LSI_S2_WIDE
+// and LSI_S2_ADAPT=0 switch the mechanism off.  (The library owns, per
+// geometry, 8 bytes of device memory, 8 of pinned host memory and one event.)
+struct S2Adapt {
+  int key[10];
+  int device;
+  int state;        // 0 undecided (narrow), 1 narrow, 2 wide
+  long calls;
+  bool pending;
+  unsigned* ctr_dev;
+  unsigned* ctr_host;
+  hipEvent_t ev;
+};
+constexpr double S2_FOLD_SHARE = 0.5;
+std::mutex s2_adapt_mu;
+std::vector<S2Adapt*> s2_adapt_tab;
+
+// Returns the entry of this geometry (NULL: mechanism off or not creatable
+// now); *want_wide the standing decision, *probe whether this launch counts.
+S2Adapt* s2_adapt_begin(const LsiSplatDesc* d, int wmax, hipStream_t stream, bool* want_wide,
+                        bool* probe) {
+  *want_wide = false; *probe = false;
+  static const char* off = getenv("LSI_S2_ADAPT");
+  static const char* forced = getenv("LSI_S2_WIDE");
+  if ((off && off[0] == '0') || forced || d->tune_threads != 0 || d->tune_rows != 0) return nullptr;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &cap) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  const bool capturing = cap != hipStreamCaptureStatusNone;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  int key[10] = {d->L, d->B, d->H, d->W, d->Ht, d->Wt, wmax, (int)(d->flags & LSI_PACKED_RGBD),
+                 0, 0};
+  memcpy(&key[8], &d->trg_downsampling, sizeof(float));
+  memcpy(&key[9], &d->max_disp, sizeof(float));
+  std::lock_guard<std::mutex> g(s2_adapt_mu);
+  S2Adapt* e = nullptr;
+  for (S2Adapt* c : s2_adapt_tab)
+    if (c->device == dev && memcmp(c->key, key, sizeof(key)) == 0) { e = c; break; }
+  if (!e) {
+    if (capturing || s2_adapt_tab.size() >= 256) return nullptr;  // (no allocation inside a capture)
+    e = new S2Adapt();
+    memcpy(e->key, key, sizeof(key));
+    e->device = dev; e->state = 0; e->calls = 0; e->pending = false;
+    e->ctr_dev = nullptr; e->ctr_host = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&e->ctr_dev), 8) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&e->ctr_host), 8, hipHostMallocDefault) != hipSuccess ||
+        hipEventCreateWithFlags(&e->ev, hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError();
+      delete e;
+      return nullptr;
+    }
+    s2_adapt_tab.push_back(e);
+  }
+  if (e->pending && hipEventQuery(e->ev) == hipSuccess) {
+    const unsigned fold = e->ctr_host[0], all = e->ctr_host[1];
+    if (all > 0u) e->state = ((double)fold > S2_FOLD_SHARE * (double)all) ? 2 : 1;
+    e->pending = false;
+  } else {
+    (void)hipGetLastError();  // (hipErrorNotReady is not an error)
+  }
+  *want_wide = e->state == 2;
+  if (!capturing && !e->pending && (e->state == 0 || (e->calls & 63) < 2)) *probe = true;
+  e->calls += 1;
+  return e;
+}
+
 }  // namespace
+
+// Diagnostic: the standing decision for this call geometry on the current
+// device -- 0 none yet, 1 twelve waves x two register sets, 2 sixteen x one;
+// -1 when the mechanism does not apply or has not seen the geometry.
+extern "C" int lsi_stream_adapt_state(const LsiSplatDesc* d) {
+  if (!d) return -1;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return -1;
+  const int wmax = d->tune_window & ~LSI_STREAM_FLAG_BITS;
+  int key[10] = {d->L, d->B, d->H, d->W, d->Ht, d->Wt, wmax, (int)(d->flags & LSI_PACKED_RGBD),
+                 0, 0};
+  memcpy(&key[8], &d->trg_downsampling, sizeof(float));
+  memcpy(&key[9], &d->max_disp, sizeof(float));
+  std::lock_guard<std::mutex> g(s2_adapt_mu);
+  for (S2Adapt* c : s2_adapt_tab)
+    if (c->device == dev && memcmp(c->key, key, sizeof(key)) == 0) {
+      if (c->pending && hipEventQuery(c->ev) == hipSuccess) {
+        const unsigned fold = c->ctr_host[0], all = c->ctr_host[1];
+        if (all > 0u) c->state = ((double)fold > S2_FOLD_SHARE * (double)all) ? 2 : 1;
+        c->pending = false;
+      } else {
+        (void)hipGetLastError();
+      }
+      return c->state;
+    }
+  return -1;
+}
 
 // Whether the compact instance renders this call (else: splat_stream_kernel).
 bool lsi_stream2_applies(const SplatArgs& a, bool simple, int layout) {
@@ -1731,6 +1852,22 @@ int lsi_stream2_launch(const SplatArgs& a, int wmax, hipStream_t stream,
   // flight per wave), or 16 waves with one (<= 128 VGPRs); see s2_choose().
   bool wide = false;
   if (!s2_choose(d, wmax, both, &plan, &wide)) return LSI_EINVAL;
+  // the field decides between the two builds where the planner alone would
+  // take 12 x 2 (s2_adapt_begin)
+  S2Adapt* adapt = nullptr;
+  bool probe = false;
+#ifndef S2X_STAMPS
+  if (!both && !wide) {
+    bool want_wide = false;
+    adapt = s2_adapt_begin(d, wmax, stream, &want_wide, &probe);
+    if (adapt && want_wide) {
+      S2Plan wp;
+      if (s2_plan(d, wmax, 1024 / 64, both, &wp) == LSI_OK && wp.nw > LSI_S2_MAXT / 64) {
+        plan = wp; wide = true;
+      }
+    }
+  }
+#endif
   S2Args k;
   k.tex = a.tex; k.disp = a.disp; k.M = a.M;
   k.out_img = a.out_img; k.out_wts = a.out_wts;
@@ -1771,6 +1908,11 @@ int lsi_stream2_launch(const SplatArgs& a, int wmax, hipStream_t stream,
   k.inv_gx = 1.0f / (float)nbands;
   k.inv_nseg = 1.0f / (float)k.nseg;
   k.stamps = nullptr;
+  k.route_ctr = nullptr;
+  if (adapt && probe) {
+    if (hipMemsetAsync(adapt->ctr_dev, 0, 8, stream) == hipSuccess) k.route_ctr = adapt->ctr_dev;
+    else (void)hipGetLastError();
+  }
 #ifdef S2X_STAMPS
   // (the last bytes of the workspace)
   if ((d->reserved & 4) && a.canvas &&
@@ -1796,5 +1938,13 @@ int lsi_stream2_launch(const SplatArgs& a, int wmax, hipStream_t stream,
   if (hipLaunchKernel(fn, dim3(nbands, d->B), dim3(plan.nw * 64), kargs, plan.lds,
                       stream) != hipSuccess)
     return LSI_ELAUNCH;
+  if (k.route_ctr) {   // the counts travel to the host behind the launch; read by a later call
+    std::lock_guard<std::mutex> g(s2_adapt_mu);
+    if (hipMemcpyAsync(adapt->ctr_host, adapt->ctr_dev, 8, hipMemcpyDeviceToHost, stream) == hipSuccess &&
+        hipEventRecord(adapt->ev, stream) == hipSuccess)
+      adapt->pending = true;
+    else
+      (void)hipGetLastError();
+  }
   return hipGetLastError() == hipSuccess ? LSI_OK : LSI_ELAUNCH;
 }

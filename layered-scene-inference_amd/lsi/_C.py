@@ -78,6 +78,7 @@ SIGNATURES = {
     'lsi_rowband_ok': (ctypes.c_int, [_DP, _VP]),
     'lsi_stream_ok': (ctypes.c_int, [_DP, _VP]),
     'lsi_splat_workspace_bytes': (_SZ, [_DP]),
+    'lsi_stream_adapt_state': (ctypes.c_int, [_DP]),
     'lsi_splat_fwd': (ctypes.c_int, [_DP] + [_VP] * 8 + [_SZ, _VP]),
     'lsi_splat_bwd_workspace_bytes': (_SZ, [_DP]),
     'lsi_splat_bwd': (ctypes.c_int, [_DP] + [_VP] * 12 + [_SZ, _VP]),

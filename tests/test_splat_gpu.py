@@ -1428,3 +1428,34 @@ def test_streamed_backward_with_a_mask(w, both, dev, monkeypatch):
     scale = np.abs(want).max() + 1e-30
     bad = np.abs(a - want) > 2e-4 * scale + 1e-3 * np.abs(want)
     assert bad.mean() < 0.005, (name, bad.mean(), np.abs(a - want).max() / scale)
+
+
+def test_the_library_picks_the_kernel_build_from_the_field(dev, ref_cpu):
+  """lsi_stream_adapt_state (include/lsi_hip.h): on a geometry where the planner
+  alone takes 12 waves x two register sets, a folded (i.i.d.) disparity field
+  moves the library to the 16-wave build after a few calls, a smooth field
+  leaves it on 12 -- read from the kernel's own route counts, no argument
+  given; the rendering is the same either way."""
+  import ctypes
+  from lsi import _C
+  from lsi.geometry import ldi
+  nl, b, h, w = 2, 8, 256, 768
+  states = {}
+  for kind, md in (('smooth', 0.4), ('iid', 0.41)):    # (max_disp is part of the geometry key)
+    rs = np.random.RandomState(5)
+    tex, disp, mat = _stream_case(rs, nl, b, h, w, kind)
+    t_tex, t_disp = torch.tensor(tex, device=dev), torch.tensor(disp, device=dev)
+    mat_t = torch.tensor(mat)
+    for _ in range(6):
+      img, wts = ldi.forward_splat_matrix([t_tex, None, t_disp], mat_t, trg_downsampling=0.5,
+                                          bg_layer_disp=1e-3, max_disp=md, zbuf_scale=50)
+      torch.cuda.synchronize()
+    desc = ldi._desc(t_tex, None, t_disp, h // 2, w // 2, 0.5, md, 50.0,
+                     _C.bg_weight(1e-3, md, 50.0), _C.LSI_COMPOSE, 0)
+    ldi.select_path(desc, mat_t, 'auto')
+    assert desc.path == _C.LSI_PATH_STREAM
+    states[kind] = _C.lib().lsi_stream_adapt_state(ctypes.byref(desc))
+    want = ref_cpu.forward_splat(tex, None, disp, mat, 0.5, 1e-3, md, 50, True)
+    assert float(np.abs(img.cpu().numpy() - want['img']).max()) <= 2e-5
+    np.testing.assert_allclose(wts.cpu().numpy(), want['wts'], rtol=1e-4)
+  assert states == {'smooth': 1, 'iid': 2}, states
