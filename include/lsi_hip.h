@@ -575,6 +575,26 @@ int lsi_conv2d_fwd(const LsiConvDesc* d, const void* x, const void* packed, void
                    lsi_stream_t stream);
 int lsi_conv2d_bwd_data(const LsiConvDesc* d, const void* gy, const void* packed, void* gx,
                         lsi_stream_t stream);
+/*
+ * Weight gradient of the convolution LsiConvDesc describes (TF autodiff of
+ * slim.conv2d, reference nets.py:29-114, 244-348):
+ *   g_weight[co][ci][ky][kx] = sum over n, oy, ox of
+ *       gy[n][oy][ox][co] * x[n][oy*stride + ky - pad_t][ox*stride + kx - pad_l][ci]
+ *   x: bf16 N x H x W x Cin, gy: bf16 N x OH x OW x Cout (16-byte aligned);
+ *   g_weight: fp32 Cout x Cin x KH x KW, written (not added to).  MFMA with K =
+ *   output pixels, both operands transposed by the LDS transpose read; partial
+ *   sums of the pixel blocks in the workspace, folded by a second kernel
+ *   (deterministic).  lsi_conv2d_wgrad_workspace_bytes returns 0 for shapes it
+ *   does not take (LSI_EUNSUPPORTED from the call: channel counts that are not
+ *   multiples of 32, or small maps with so many channels that the partial sums
+ *   would exceed 96 MB -- the bottleneck layers, which stay on the library).
+ *   For a transposed convolution described as above (its forward = the data
+ *   gradient of the descriptor's convolution), x is the transposed
+ *   convolution's OUTPUT gradient and gy its INPUT.
+ */
+size_t lsi_conv2d_wgrad_workspace_bytes(const LsiConvDesc* d);
+int lsi_conv2d_wgrad(const LsiConvDesc* d, const void* x, const void* gy, float* g_weight,
+                     void* workspace, size_t workspace_bytes, lsi_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -91,6 +91,9 @@ def build_parser():
   a('--batched_pairs', type=_bool, default=True,
     help='source and target images go through the network in one pass, every '
     'batch norm with separate statistics per view (same arithmetic as two passes)')
+  a('--paired_splat', type=_bool, default=True,
+    help='with --batched_pairs: the src -> trg and trg -> src renderings of a step '
+    'are one forward_splat_both call on the 2 B LDIs the network pass produced')
   a('--fused_adam', type=_bool, default=True,
     help='torch.optim.Adam(fused=True) on the GPU')
   a('--miopen_tune', type=_bool, default=False,
@@ -162,6 +165,7 @@ class LdiNet(torch.nn.Module):
     return self.ldi_tex_disp(feat_dec, skip_feat, disp_scale=self.max_disp)
 
   def forward(self, imgs_src, imgs_trg):
+    self.pair_ldi = None
     if not self.batched_pairs or imgs_src.shape != imgs_trg.shape:
       return self.predict(imgs_src), self.predict(imgs_trg)
     # One pass over [src; trg]: every batch norm keeps separate statistics for
@@ -172,6 +176,8 @@ class LdiNet(torch.nn.Module):
     with nets.bn_groups(2):
       tex, masks, disps = self.predict(torch.cat([imgs_src, imgs_trg], dim=0))
     half = lambda t, k: None if t is None else t[:, k * b:(k + 1) * b]
+    # (the un-halved LDI: the trainer renders both directions with one launch)
+    self.pair_ldi = [tex, masks, disps]
     return ([half(tex, 0), half(masks, 0), half(disps, 0)],
             [half(tex, 1), half(masks, 1), half(disps, 1)])
 
@@ -310,6 +316,8 @@ class Trainer(train_utils.Trainer):
     mats = {'trg': mat_trg, 'src': mat_src}
     amp = (torch.autocast('cuda', dtype=torch.bfloat16) if opts.bf16
            else _NullCtx())
+    if hasattr(self, 'model'):
+      self.model.pair_ldi = None
     with amp:
       ldi_src, ldi_trg = self.train_model(imgs_src, imgs_trg)
     if opts.debug_synth_texture and len(staged) >= 6:
@@ -341,7 +349,32 @@ class Trainer(train_utils.Trainer):
     # One sweep per direction renders the per-layer AND the composed view
     # (the reference makes four forward_splat calls whose per-layer splats
     # are identical pairwise).
-    if opts.indep_splat_wt > 0 or opts.compose_splat_wt > 0:
+    pair = getattr(getattr(self, 'model', None), 'pair_ldi', None)
+    if (pair is not None and getattr(opts, 'paired_splat', True) and
+        not (opts.debug_synth_texture and len(staged) >= 6) and
+        (opts.indep_splat_wt > 0 or opts.compose_splat_wt > 0)):
+      # Both directions of the pair from ONE launch (and one in the backward):
+      # the network's output is one buffer of 2 B LDIs -- the B source views'
+      # then the B target views' -- so the src -> trg and the trg -> src
+      # renderings (reference ldi_enc_dec.py:302-334) are a batch of 2 B
+      # elements with their own matrices, compared with [imgs_trg; imgs_src].
+      # A rank with 4 samples then issues 8-view launches instead of twice 4.
+      # Each loss term is a mean over the batch: the mean over 2 B samples is
+      # half the sum of the two directions' means.
+      mat2 = torch.cat([mats['trg'], mats['src']], dim=0)
+      host2 = torch.cat([self.host_mats['trg'], self.host_mats['src']], dim=0)
+      target2 = torch.cat([imgs_trg, imgs_src], dim=0)
+      img_i, _, img_c, _ = ldi_utils.forward_splat_both(
+          pair, mat2, trg_downsampling=opts.trg_splat_downsampling,
+          zbuf_scale=opts.zbuf_scale, bg_layer_disp=opts.bg_layer_disp,
+          max_disp=opts.max_disp, mat_host=host2)
+      if opts.indep_splat_wt > 0:
+        indep_splat_loss = 2.0 * loss.view_synthesis_loss(
+            img_i, target2, opts.splat_bdry_ignore)
+      if opts.compose_splat_wt > 0:
+        compose_splat_loss = 2.0 * loss.view_synthesis_loss(
+            img_c, target2, opts.splat_bdry_ignore)
+    elif opts.indep_splat_wt > 0 or opts.compose_splat_wt > 0:
       for which in ('trg', 'src'):
         if which == 'trg':
           target, l = imgs_trg, ldi_src

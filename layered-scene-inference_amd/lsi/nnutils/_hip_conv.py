@@ -375,6 +375,38 @@ def _empty_cl(n, c, h, w, dev):
                      memory_format=torch.channels_last)
 
 
+OWN_WGRAD = os.environ.get('LSI_IGEMM_WGRAD', '1') != '0'
+IGEMM_WGRAD_MIN_PIXELS = int(os.environ.get('LSI_IGEMM_WGRAD_MIN_PIXELS', '4096'))
+_WGRAD_BYTES = {}
+
+
+def _igemm_wgrad_bytes(d):
+  """lsi_conv2d_wgrad_workspace_bytes per geometry (0: the library takes it)."""
+  key = (d.N, d.H, d.W, d.Cin, d.OH, d.OW, d.Cout, d.KH, d.KW, d.stride, d.pad_t, d.pad_l)
+  n = _WGRAD_BYTES.get(key)
+  if n is None:
+    n = int(_C.lib().lsi_conv2d_wgrad_workspace_bytes(ctypes.byref(d)))
+    # (below ~4 k output pixels the K = pixels GEMM has too few pixel blocks to
+    # fill the chip and the library's kernels are ahead: tools/conv_bench.py)
+    if d.N * d.OH * d.OW < IGEMM_WGRAD_MIN_PIXELS:
+      n = 0
+    _WGRAD_BYTES[key] = n
+  return n
+
+
+def _igemm_wgrad(d, x, gy, weight):
+  """lsi_conv2d_wgrad: x = the descriptor's input tensor, gy its output gradient."""
+  dev = x.device
+  nbytes = _igemm_wgrad_bytes(d)
+  ws = _wgrad_workspace(dev, nbytes)
+  gw = torch.empty(tuple(weight.shape), dtype=torch.float32, device=dev)
+  rc = _C.lib().lsi_conv2d_wgrad(ctypes.byref(d), x.data_ptr(), gy.data_ptr(), gw.data_ptr(),
+                                 ws.data_ptr(), ws.numel() * 4, _C.stream_ptr(dev))
+  if rc:
+    _C.check(rc, 'lsi_conv2d_wgrad')
+  return gw if weight.dtype == torch.float32 else gw.to(weight.dtype)
+
+
 class _Conv2dIgemm(torch.autograd.Function):
   """slim.conv2d without bias (reference nets.py: the arg_scope's conv2d) --
   forward and data gradient on lsi_conv2d_fwd / lsi_conv2d_bwd_data, the weight
@@ -402,8 +434,11 @@ class _Conv2dIgemm(torch.autograd.Function):
       gx = _igemm('lsi_conv2d_bwd_data', d, g, weight,
                   _empty_cl(d.N, d.Cin, d.H, d.W, x.device))
     if ctx.needs_input_grad[1]:
-      if d.KH == 3 and d.KW == 3 and d.stride == 1 and d.pad_t == 1 and d.pad_l == 1:
-        gw = _weight_grad(x, g, weight)
+      if (d.KH == 3 and d.KW == 3 and d.stride == 1 and d.pad_t == 1 and d.pad_l == 1 and
+          wgrad_supported(x, d.Cin, d.Cout, 3, 1)):
+        gw = _weight_grad(x, g, weight)    # (the row-ring kernel: full / half resolution)
+      elif OWN_WGRAD and _igemm_wgrad_bytes(d) > 0:
+        gw = _igemm_wgrad(d, x, g, weight)
       else:
         # explicit padding: TF SAME is asymmetric for stride 2 (one more after)
         pb = max((d.OH - 1) * d.stride + d.KH - d.H - d.pad_t, 0)
@@ -453,9 +488,14 @@ class _ConvTranspose2dIgemm(torch.autograd.Function):
       gx = _igemm('lsi_conv2d_fwd', d, g, weight,
                   _empty_cl(d.N, d.Cout, d.OH, d.OW, x.device))
     if ctx.needs_input_grad[1]:
-      gw = torch.ops.aten.convolution_backward(
-          g, x, weight.to(g.dtype), None, [stride, stride], [pad, pad], [1, 1], True,
-          [0, 0], 1, [False, True, False])[1].to(weight.dtype)
+      if OWN_WGRAD and _igemm_wgrad_bytes(d) > 0:
+        # the descriptor's convolution: "input" = this layer's output gradient,
+        # "output gradient" = this layer's input
+        gw = _igemm_wgrad(d, g, x, weight)
+      else:
+        gw = torch.ops.aten.convolution_backward(
+            g, x, weight.to(g.dtype), None, [stride, stride], [pad, pad], [1, 1], True,
+            [0, 0], 1, [False, True, False])[1].to(weight.dtype)
     return gx, gw, None, None
 
 

@@ -355,3 +355,31 @@ def test_batched_pair_pass_on_the_gpu_and_rgbd_output_layout(tmp_path, built_lib
   num = sum(float(((x - y) ** 2).sum()) for x, y in zip(grads[True], grads[False]))
   den = sum(float((y ** 2).sum()) for y in grads[False])
   assert num <= 1e-4 * den, num / den       # (MIOpen picks other kernels at batch 4 / 2)
+
+
+def test_paired_splat_equals_one_call_per_direction(tmp_path, built_lib):
+  """--paired_splat (default): both directions of a pair rendered by ONE
+  forward_splat_both call on the 2 B LDIs of the batched network pass
+  (reference ldi_enc_dec.py:302-334 makes one call per direction).  Same seed,
+  same batch: the six scalars and the gradients equal those of two calls."""
+  res = {}
+  for paired in ('true', 'false'):
+    torch.manual_seed(0)
+    tr = _trainer(tmp_path, paired_splat=paired)
+    torch.manual_seed(1)
+    batch = tr.feed()
+    staged, _ = tr.stage(batch)
+    tr.optim.zero_grad(set_to_none=True)
+    total, scalars = tr.compute_losses(staged)
+    assert tr.model.pair_ldi is not None      # (the batched pass offers it; the flag decides)
+    total.backward()
+    res[paired] = ({k: float(v) for k, v in scalars.items()},
+                   [p.grad.detach().clone() for p in tr.model.parameters() if p.grad is not None])
+  sa, ga = res['true']
+  sb, gb = res['false']
+  for k in sa:
+    assert abs(sa[k] - sb[k]) <= 1e-5 * abs(sb[k]) + 1e-9, (k, sa[k], sb[k])
+  assert len(ga) == len(gb)
+  for a, b in zip(ga, gb):
+    scale = float(b.abs().max()) + 1e-12
+    assert float((a - b).abs().max()) <= 2e-4 * scale + 1e-9

@@ -100,6 +100,17 @@ for name, kind, cin, cout, k, s, h, w in L:
         gy, xp, wb, None, [s, s], [pt, pl] if sym else [0, 0], [1, 1], False, [0, 0], 1,
         [True, False, False])
     ref = lib_f().float()
+    if k == 3 and s == 1 and _hip_conv.wgrad_supported(x, cin, cout, 3, 1):
+      own_w = lambda: _hip_conv._weight_grad(x, gy, wt)
+    elif _hip_conv._igemm_wgrad_bytes(d) > 0:
+      own_w = lambda: _hip_conv._igemm_wgrad(d, x, gy, wt)
+    else:
+      own_w = None
+    lib_w = lambda: torch.ops.aten.convolution_backward(
+        gy, xp, wb, None, [s, s], [pt, pl] if sym else [0, 0], [1, 1], False, [0, 0], 1,
+        [False, True, False])
+    if own_w is not None:
+      werr = float((own_w().float() - lib_w()[1].float()).abs().max() / (lib_w()[1].float().abs().max() + 1e-20))
   else:
     wt = (torch.randn((cin, cout, 4, 4), generator=g) * 0.05).to(dev)
     flop = 2.0 * N * (2 * h) * (2 * w) * cin * cout * 4
@@ -113,23 +124,34 @@ for name, kind, cin, cout, k, s, h, w in L:
     lib_d = lambda: torch.ops.aten.convolution_backward(
         gy, x, wb, None, [2, 2], [1, 1], [1, 1], True, [0, 0], 1, [True, False, False])
     ref = lib_f().float()
+    own_w = (lambda: _hip_conv._igemm_wgrad(d, gy, x, wt)) if _hip_conv._igemm_wgrad_bytes(d) > 0 else None
+    lib_w = lambda: torch.ops.aten.convolution_backward(
+        gy, x, wb, None, [2, 2], [1, 1], [1, 1], True, [0, 0], 1, [False, True, False])
+    if own_w is not None:
+      werr = float((own_w().float() - lib_w()[1].float()).abs().max() / (lib_w()[1].float().abs().max() + 1e-20))
   err = float((y.float() - ref).abs().max())
   r = dict(name=name, kind=kind, cin=cin, cout=cout, k=k, stride=s, h=h, w=w, gflop=flop / 1e9,
            own_fwd_us=timeit(own_f), lib_fwd_us=timeit(lib_f), own_dgrad_us=timeit(own_d),
            lib_dgrad_us=timeit(lib_d), max_diff_vs_lib=err)
+  mult = 2 if name.startswith('head.') else 1
+  r['lib_wgrad_us'] = timeit(lib_w)
+  r['own_wgrad_us'] = timeit(own_w) if own_w is not None else float('nan')
+  r['wgrad_rel_diff_vs_lib'] = werr if own_w is not None else float('nan')
   r['own_fwd_util'] = flop / (r['own_fwd_us'] * 1e-6) / 2.5e15
   r['own_dgrad_util'] = flop / (r['own_dgrad_us'] * 1e-6) / 2.5e15
   rows.append(r)
-  mult = 2 if name.startswith('head.') else 1
   tot['own_f'] += mult * r['own_fwd_us']; tot['lib_f'] += mult * r['lib_fwd_us']
   tot['own_d'] += mult * r['own_dgrad_us']; tot['lib_d'] += mult * r['lib_dgrad_us']
   tot['flop'] += mult * flop
-  print('%-14s %-5s %4d->%-4d k%d s%d %3dx%-3d %7.1f GF | fwd own %7.1f us (%4.1f%%) lib %7.1f | dgrad own %7.1f (%4.1f%%) lib %7.1f | diff %.3g'
+  tot['own_w'] = tot.get('own_w', 0.) + mult * (r['own_wgrad_us'] if own_w is not None else r['lib_wgrad_us'])
+  tot['lib_w'] = tot.get('lib_w', 0.) + mult * r['lib_wgrad_us']
+  print('%-14s %-5s %4d->%-4d k%d s%d %3dx%-3d %7.1f GF | fwd own %7.1f us (%4.1f%%) lib %7.1f | dgrad own %7.1f (%4.1f%%) lib %7.1f | wgrad own %7.1f lib %7.1f (rel diff %.1e) | diff %.3g'
         % (name, kind, cin, cout, k, s, h, w, flop / 1e9, r['own_fwd_us'], 100 * r['own_fwd_util'],
-           r['lib_fwd_us'], r['own_dgrad_us'], 100 * r['own_dgrad_util'], r['lib_dgrad_us'], err),
+           r['lib_fwd_us'], r['own_dgrad_us'], 100 * r['own_dgrad_util'], r['lib_dgrad_us'],
+           r['own_wgrad_us'], r['lib_wgrad_us'], r['wgrad_rel_diff_vs_lib'], err),
         flush=True)
-print('total (2 heads): fwd own %.0f us lib %.0f us | dgrad own %.0f lib %.0f | %.1f GFLOP; fwd util own %.1f%% lib %.1f%%'
-      % (tot['own_f'], tot['lib_f'], tot['own_d'], tot['lib_d'], tot['flop'] / 1e9,
+print('total (2 heads): fwd own %.0f us lib %.0f us | dgrad own %.0f lib %.0f | wgrad own(+lib where not taken) %.0f lib %.0f | %.1f GFLOP; fwd util own %.1f%% lib %.1f%%'
+      % (tot['own_f'], tot['lib_f'], tot['own_d'], tot['lib_d'], tot['own_w'], tot['lib_w'], tot['flop'] / 1e9,
          100 * tot['flop'] / (tot['own_f'] * 1e-6) / 2.5e15,
          100 * tot['flop'] / (tot['lib_f'] * 1e-6) / 2.5e15))
 if args.out:

@@ -116,6 +116,21 @@ for it in range(n):
     loss.backward()
     ref = p64.grad.numpy()
     ref[bad[:, :1]] = 0.0
+    # the same op graph in fp32 (what the reference's own autodiff runs): the bar
+    # for the kernels fed their own fp32 forward outputs
+    p32 = p64.detach().float().requires_grad_(True)
+    t32, d32 = p32[..., 0:3], p32[..., 3:4]
+    q_l = TR.forward_splat(t32, torch.ones_like(d32), d32, mat[:1].float(), s, bg, dmax, zb, False)
+    q_c = TR.forward_splat(t32, torch.ones_like(d32), d32, mat[:1].float(), s, bg, dmax, zb, True)
+    outs32 = [q_l[0], q_l[1], q_c[0], q_c[1]] if mode == 'both' else [q_c[0], q_c[1]]
+    g = torch.Generator().manual_seed(it)
+    loss = 0
+    for o in outs32:
+      c = torch.rand(tuple(o.shape[:1]) + (b,) + tuple(o.shape[2:]), generator=g)[:, :1]
+      loss = loss + ((o if o.shape[-1] == 3 else torch.log(o) * 1e-3) * c).sum()
+    loss.backward()
+    ref32 = p32.grad.double().numpy()
+    ref32[bad[:, :1]] = 0.0
   # The backward kernels read the forward's outputs (img = A / W, W).  `own`:
   # the ones the fp32 forward produced (what training does); `exact`: the first
   # element's replaced by the oracle's, rounded once to fp32 -- the backward
@@ -155,6 +170,8 @@ for it in range(n):
     firm = np.stack([O.decisions_are_robust(mat[:1].numpy(), np.nan_to_num(
         pred[l, :1, :, :, 3], nan=0.0, posinf=0.0), s, int(h * s), int(w * s), dmax)
                      for l in range(nl)])[..., None]
+    e32 = float((np.abs(ref32 - ref) * firm).max() / sc)
+    worst['fp32_op_graph_vs_fp64'] = max(worst.get('fp32_op_graph_vs_fp64', 0.0), e32)
     for feed in ('own', 'exact'):
       for key, name in (('1', 'stream'), ('0', 'gather')):
         dlt = np.abs(grads[feed, key][:, :1] - ref) * firm
@@ -175,4 +192,9 @@ for it in range(n):
         # A sanity bar, 500 x the kernel-vs-kernel one: what is sharp is that the
         # two independent kernels agree, and the full-size test on smooth fields.
         assert feed == 'own' or e64 <= 500 * gtol, (tag, wname, e64, gtol)
+        # Fed their own fp32 forward outputs (what training does) the kernels
+        # carry the forward's rounding through the same cancellation; the bar is
+        # what fp32 autodiff of the reference's op graph -- TF1's own arithmetic
+        # -- is from fp64 on the same case (x 3, plus the exact-feed bar)
+        assert feed != 'own' or e64 <= 3.0 * e32 + 500 * gtol, (tag, wname, e64, e32)
 print('fuzz_compact: %d cases (%d on STREAM) ok; worst' % (n, stream_hits), worst)
