@@ -503,9 +503,9 @@ int lsi_conv3x3_wgrad(int32_t N, int32_t H, int32_t W, int32_t cin, int32_t cout
  * one); which is faster depends on the disparity field, which the planner does
  * not see.  The kernel counts the items that took its folded routes on a few
  * probe launches (the first calls of a geometry, then two of every 64); a later
- * call reads the count -- asynchronously copied, never waited for -- and picks
- * the build.  This is the library's only state besides memoised plans: per call
- * geometry 8 bytes of device memory, 8 of pinned host memory, one event.
+ * call reads the count -- asynchronously copied to pinned host memory, never
+ * waited for -- and picks the build.  This is the library's only state besides
+ * memoised plans: per call geometry 16 bytes of device and of pinned host memory.
  * tune_threads != 0, LSI_S2_WIDE and LSI_S2_ADAPT=0 switch it off; launches
  * under stream capture use the standing decision.
  * lsi_stream_adapt_state: that decision for a descriptor prepared as for

@@ -1719,26 +1719,38 @@ bool s2_choose(const LsiSplatDesc* d, int wmax, bool both, S2Plan* plan, bool* w
 // 15 % faster on 16 x one.  The kernel knows which it is: it counts the items
 // that took the folded routes B' / C.  Per call geometry the library keeps a
 // small state: on PROBE launches (the first calls, then two of every 64) the
-// kernel adds its counts to a device counter, a 8-byte asynchronous copy brings
-// them to pinned host memory, and the NEXT call that finds the copy complete
-// (hipEventQuery: never a wait) takes the decision -- 16 x 1 when more than
+// kernel adds its counts to a device counter, a 12-byte asynchronous copy brings
+// them and the probe's sequence number to pinned host memory, and the NEXT call
+// that sees the number there (a plain read of host memory: no runtime call, legal
+// also while a stream is being captured) takes the decision -- 16 x 1 when more than
 // FOLD_SHARE of the items were folded.  The decision of a call never depends on
 // that call's own data, no host synchronisation is added, and a launch that is
 // being captured into a HIP graph takes the decision standing at that moment
 // and probes nothing (the graph has it baked in).  tune_threads, LSI_S2_WIDE
 // and LSI_S2_ADAPT=0 switch the mechanism off.  (The library owns, per
-// geometry, 8 bytes of device memory, 8 of pinned host memory and one event.)
+// geometry, 16 bytes of device memory and 16 of pinned host memory.)
+constexpr double S2_FOLD_SHARE = 0.5;
 struct S2Adapt {
   int key[10];
   int device;
   int state;        // 0 undecided (narrow), 1 narrow, 2 wide
   long calls;
   bool pending;
-  unsigned* ctr_dev;
+  unsigned seq;       // the pending probe's number (word 2 of the counters)
+  unsigned* ctr_dev;  // {folded items, all items, sequence number}
   unsigned* ctr_host;
-  hipEvent_t ev;
 };
-constexpr double S2_FOLD_SHARE = 0.5;
+// the pending probe's counts if they have arrived
+bool s2_adapt_poll(S2Adapt* e) {
+  if (!e->pending) return false;
+  volatile unsigned* h = e->ctr_host;
+  if (h[2] != e->seq) return false;
+  __sync_synchronize();
+  const unsigned fold = h[0], all = h[1];
+  if (all > 0u) e->state = ((double)fold > S2_FOLD_SHARE * (double)all) ? 2 : 1;
+  e->pending = false;
+  return true;
+}
 std::mutex s2_adapt_mu;
 std::vector<S2Adapt*> s2_adapt_tab;
 
@@ -1767,24 +1779,18 @@ S2Adapt* s2_adapt_begin(const LsiSplatDesc* d, int wmax, hipStream_t stream, boo
     if (capturing || s2_adapt_tab.size() >= 256) return nullptr;  // (no allocation inside a capture)
     e = new S2Adapt();
     memcpy(e->key, key, sizeof(key));
-    e->device = dev; e->state = 0; e->calls = 0; e->pending = false;
+    e->device = dev; e->state = 0; e->calls = 0; e->pending = false; e->seq = 0u;
     e->ctr_dev = nullptr; e->ctr_host = nullptr;
-    if (hipMalloc(reinterpret_cast<void**>(&e->ctr_dev), 8) != hipSuccess ||
-        hipHostMalloc(reinterpret_cast<void**>(&e->ctr_host), 8, hipHostMallocDefault) != hipSuccess ||
-        hipEventCreateWithFlags(&e->ev, hipEventDisableTiming) != hipSuccess) {
+    if (hipMalloc(reinterpret_cast<void**>(&e->ctr_dev), 16) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&e->ctr_host), 16, hipHostMallocDefault) != hipSuccess) {
       (void)hipGetLastError();
       delete e;
       return nullptr;
     }
+    memset(e->ctr_host, 0, 16);
     s2_adapt_tab.push_back(e);
   }
-  if (e->pending && hipEventQuery(e->ev) == hipSuccess) {
-    const unsigned fold = e->ctr_host[0], all = e->ctr_host[1];
-    if (all > 0u) e->state = ((double)fold > S2_FOLD_SHARE * (double)all) ? 2 : 1;
-    e->pending = false;
-  } else {
-    (void)hipGetLastError();  // (hipErrorNotReady is not an error)
-  }
+  s2_adapt_poll(e);
   *want_wide = e->state == 2;
   if (!capturing && !e->pending && (e->state == 0 || (e->calls & 63) < 2)) *probe = true;
   e->calls += 1;
@@ -1808,13 +1814,7 @@ extern "C" int lsi_stream_adapt_state(const LsiSplatDesc* d) {
   std::lock_guard<std::mutex> g(s2_adapt_mu);
   for (S2Adapt* c : s2_adapt_tab)
     if (c->device == dev && memcmp(c->key, key, sizeof(key)) == 0) {
-      if (c->pending && hipEventQuery(c->ev) == hipSuccess) {
-        const unsigned fold = c->ctr_host[0], all = c->ctr_host[1];
-        if (all > 0u) c->state = ((double)fold > S2_FOLD_SHARE * (double)all) ? 2 : 1;
-        c->pending = false;
-      } else {
-        (void)hipGetLastError();
-      }
+      s2_adapt_poll(c);
       return c->state;
     }
   return -1;
@@ -1910,8 +1910,15 @@ int lsi_stream2_launch(const SplatArgs& a, int wmax, hipStream_t stream,
   k.stamps = nullptr;
   k.route_ctr = nullptr;
   if (adapt && probe) {
-    if (hipMemsetAsync(adapt->ctr_dev, 0, 8, stream) == hipSuccess) k.route_ctr = adapt->ctr_dev;
-    else (void)hipGetLastError();
+    std::lock_guard<std::mutex> g(s2_adapt_mu);
+    adapt->seq += 1u;
+    if (adapt->seq == 0u) adapt->seq = 1u;
+    if (hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(adapt->ctr_dev), 0, 2, stream) == hipSuccess &&
+        hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(adapt->ctr_dev + 2), (int)adapt->seq, 1,
+                          stream) == hipSuccess)
+      k.route_ctr = adapt->ctr_dev;
+    else
+      (void)hipGetLastError();
   }
 #ifdef S2X_STAMPS
   // (the last bytes of the workspace)
@@ -1940,8 +1947,7 @@ int lsi_stream2_launch(const SplatArgs& a, int wmax, hipStream_t stream,
     return LSI_ELAUNCH;
   if (k.route_ctr) {   // the counts travel to the host behind the launch; read by a later call
     std::lock_guard<std::mutex> g(s2_adapt_mu);
-    if (hipMemcpyAsync(adapt->ctr_host, adapt->ctr_dev, 8, hipMemcpyDeviceToHost, stream) == hipSuccess &&
-        hipEventRecord(adapt->ev, stream) == hipSuccess)
+    if (hipMemcpyAsync(adapt->ctr_host, adapt->ctr_dev, 12, hipMemcpyDeviceToHost, stream) == hipSuccess)
       adapt->pending = true;
     else
       (void)hipGetLastError();

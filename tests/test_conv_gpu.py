@@ -194,8 +194,17 @@ IGEMM_CASES = [
 ]
 
 
+@pytest.fixture
+def own_wgrad_everywhere(monkeypatch):
+  """lsi_conv2d_wgrad also below the size from which the network uses it."""
+  from lsi.nnutils import _hip_conv
+  monkeypatch.setattr(_hip_conv, 'IGEMM_WGRAD_MIN_PIXELS', 0)
+  monkeypatch.setattr(_hip_conv, 'WGRAD_MIN_PIXELS', 1 << 30)   # (not the row-ring kernel)
+  monkeypatch.setattr(_hip_conv, '_WGRAD_BYTES', {})
+
+
 @pytest.mark.parametrize('case', IGEMM_CASES)
-def test_igemm_convolution_forward_and_gradients(case, dev):
+def test_igemm_convolution_forward_and_gradients(case, dev, own_wgrad_everywhere):
   """slim.conv2d with TF SAME padding (reference nets.py:244-348): forward,
   data gradient and weight gradient against fp32 autograd of the same
   bf16-rounded operands."""
@@ -222,13 +231,16 @@ def test_igemm_convolution_forward_and_gradients(case, dev):
   tol = float(gxr.abs().max()) * 2.0 ** -7 + 1e-6
   assert float((gx - gxr).abs().max()) <= tol, (float((gx - gxr).abs().max()), tol)
   gw, gwr = wt.grad, wr.grad
-  tolw = float(gwr.abs().max()) * 2e-2 + 1e-5
+  # (c is bf16: the products are exact, the sums fp32 in another order -- where
+  # lsi_conv2d_wgrad takes the shape; the library returns a bf16-rounded result)
+  own = _hip_conv._igemm_wgrad_bytes(_hip_conv._conv_desc(n, h, w, cin, oh, ow, cout, k, k, s, pt, pl)) > 0
+  tolw = float(gwr.abs().max()) * (1e-4 if own else 2e-2) + 1e-6
   assert float((gw - gwr).abs().max()) <= tolw, (float((gw - gwr).abs().max()), tolw)
 
 
 @pytest.mark.parametrize('case', [(2, 128, 64, 16, 24), (1, 64, 32, 33, 20), (8, 512, 512, 2, 6),
                                   (1, 128, 128, 64, 192)])
-def test_igemm_transposed_convolution(case, dev):
+def test_igemm_transposed_convolution(case, dev, own_wgrad_everywhere):
   """slim.conv2d_transpose 4 x 4 stride 2 (reference nets.py:100-103) = torch
   ConvTranspose2d(k = 4, stride 2, padding 1): four parity classes of 2 x 2 taps."""
   from lsi.nnutils import _hip_conv

@@ -360,26 +360,35 @@ def test_batched_pair_pass_on_the_gpu_and_rgbd_output_layout(tmp_path, built_lib
 def test_paired_splat_equals_one_call_per_direction(tmp_path, built_lib):
   """--paired_splat (default): both directions of a pair rendered by ONE
   forward_splat_both call on the 2 B LDIs of the batched network pass
-  (reference ldi_enc_dec.py:302-334 makes one call per direction).  Same seed,
-  same batch: the six scalars and the gradients equal those of two calls."""
+  (reference ldi_enc_dec.py:302-334 makes one call per direction).  On a FIXED
+  buffer of 2 B RGBD LDIs (the network is bypassed, as in the six-scalar test):
+  the scalars and the gradient with respect to every LDI value equal those of
+  one call per direction."""
+  tr = _trainer(tmp_path)
+  o = tr.opts
+  nl, b, h, w = o.n_layers, o.batch_size, o.img_height, o.img_width
+  batch = tr.feed()
+  staged, _ = tr.stage(batch)
+  g = torch.Generator().manual_seed(21)
+  base = torch.rand((nl, 2 * b, h, w, 4), generator=g)
+  base[..., 3] *= o.max_disp
   res = {}
-  for paired in ('true', 'false'):
-    torch.manual_seed(0)
-    tr = _trainer(tmp_path, paired_splat=paired)
-    torch.manual_seed(1)
-    batch = tr.feed()
-    staged, _ = tr.stage(batch)
-    tr.optim.zero_grad(set_to_none=True)
+  for paired in (True, False):
+    pred = base.clone().to(tr.device).requires_grad_(True)
+    tex, disp = pred[..., 0:3], pred[..., 3:4]
+    half = lambda t, k: t[:, k * b:(k + 1) * b]
+    src, trg = [half(tex, 0), None, half(disp, 0)], [half(tex, 1), None, half(disp, 1)]
+
+    def fake(_a, _b, src=src, trg=trg, full=[tex, None, disp], paired=paired):
+      tr.model.pair_ldi = full if paired else None
+      return src, trg
+    tr.train_model = fake
     total, scalars = tr.compute_losses(staged)
-    assert tr.model.pair_ldi is not None      # (the batched pass offers it; the flag decides)
     total.backward()
-    res[paired] = ({k: float(v) for k, v in scalars.items()},
-                   [p.grad.detach().clone() for p in tr.model.parameters() if p.grad is not None])
-  sa, ga = res['true']
-  sb, gb = res['false']
+    res[paired] = ({k: float(v) for k, v in scalars.items()}, pred.grad.clone())
+  (sa, ga), (sb, gb) = res[True], res[False]
   for k in sa:
     assert abs(sa[k] - sb[k]) <= 1e-5 * abs(sb[k]) + 1e-9, (k, sa[k], sb[k])
-  assert len(ga) == len(gb)
-  for a, b in zip(ga, gb):
-    scale = float(b.abs().max()) + 1e-12
-    assert float((a - b).abs().max()) <= 2e-4 * scale + 1e-9
+  scale = float(gb.abs().max())
+  assert scale > 0
+  assert float((ga - gb).abs().max()) <= 2e-5 * scale, float((ga - gb).abs().max()) / scale
