@@ -37,6 +37,7 @@
 // multiplies.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/lsi_hip.h"
@@ -131,18 +132,41 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgArgs a) {
   const __bf16* const wp = a.wp + (size_t)k.wofs * a.Cout * a.Cin;
   const unsigned a_lane = (unsigned)pxl * IG_PIX + (unsigned)kg * 16u;  // weight row pxl of a tile
 
-  for (int c0 = 0; c0 < a.Cin; c0 += 32) {
-    __syncthreads();  // (the previous chunk's fragments have been read)
-    // ---- the input patch of this chunk (all loads issued, then all LDS stores:
-    // one memory round trip per stage, not one per piece) ------------------------
-    {
-      u32x4 pv[MAXP];
+  // Software pipeline over the units (chunk of 32 channels, group of G taps):
+  // the loads of unit u + 1 -- its weights, and the chunk's patch when the unit
+  // opens a chunk -- are issued into registers before unit u is multiplied and
+  // written to LDS after it, so a stage's memory latency hides behind the
+  // previous stage's MFMAs (one wave per SIMD and workgroup: nobody else would).
+  constexpr int NWP = G * BN * 4, WB = (NWP + 255) / 256;
+  const int ngrp = (ntaps + G - 1) / G;
+  const int nunit = (a.Cin / 32) * ngrp;
+  u32x4 pv[MAXP], wv[WB];
+  auto fetch = [&](int u) {
+    const int ch = u / ngrp, gi = u - ch * ngrp;
+    const int c0 = ch * 32, t0 = gi * G;
+    if (gi == 0) {
 #pragma unroll
       for (int kk = 0; kk < MAXP; ++kk) {
         pv[kk] = zero4;
         if (tid + 256 * kk < npiece && goff[kk] >= 0)
           pv[kk] = *reinterpret_cast<const u32x4*>(a.x + (size_t)goff[kk] + c0);
       }
+    }
+    const __bf16* const wsrc = wp + ((size_t)t0 * a.Cout + co0) * a.Cin + c0;
+    const int nreal = (ntaps - t0) * BN * 4;   // (taps past the class's last one: zeros)
+#pragma unroll
+    for (int kk = 0; kk < WB; ++kk) {
+      const int idx = tid + 256 * kk;
+      wv[kk] = zero4;
+      if (idx < NWP && idx < nreal) {
+        const int q = idx & 3, co = (idx >> 2) & (BN - 1), t = idx / (4 * BN);
+        wv[kk] = *reinterpret_cast<const u32x4*>(wsrc + ((size_t)t * a.Cout + co) * a.Cin + 8 * q);
+      }
+    }
+  };
+  auto stash = [&](int u) {   // registers -> LDS
+    const int gi = u % ngrp;
+    if (gi == 0) {
 #pragma unroll
       for (int kk = 0; kk < MAXP; ++kk) {
         const int idx = tid + 256 * kk;
@@ -150,50 +174,36 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgArgs a) {
           *reinterpret_cast<u32x4*>(patch + (size_t)(idx >> 2) * IG_PIX + (idx & 3) * 16) = pv[kk];
       }
     }
-    for (int t0 = 0; t0 < ntaps; t0 += G) {
-      if (t0 > 0) __syncthreads();  // (the previous group's weights have been read)
-      // ---- weights of taps t0 .. t0 + G - 1: [tap][co][32 channels]; taps past
-      // the class's last one are zeros (loads first, then the LDS stores) --------
-      {
-        constexpr int NWP = G * BN * 4, WB = (NWP + 255) / 256;
-        const __bf16* const wsrc = wp + ((size_t)t0 * a.Cout + co0) * a.Cin + c0;
-        const int nreal = (ntaps - t0) * BN * 4;
-        u32x4 wv[WB];
 #pragma unroll
-        for (int kk = 0; kk < WB; ++kk) {
-          const int idx = tid + 256 * kk;
-          wv[kk] = zero4;
-          if (idx < NWP && idx < nreal) {
-            const int q = idx & 3, co = (idx >> 2) & (BN - 1), t = idx / (4 * BN);
-            wv[kk] = *reinterpret_cast<const u32x4*>(
-                wsrc + ((size_t)t * a.Cout + co) * a.Cin + 8 * q);
-          }
-        }
-#pragma unroll
-        for (int kk = 0; kk < WB; ++kk) {
-          const int idx = tid + 256 * kk;
-          if (idx < NWP) {
-            const int q = idx & 3, co = (idx >> 2) & (BN - 1), t = idx / (4 * BN);
-            *reinterpret_cast<u32x4*>(wts + (size_t)(t * BN + co) * IG_PIX + q * 16) = wv[kk];
-          }
-        }
+    for (int kk = 0; kk < WB; ++kk) {
+      const int idx = tid + 256 * kk;
+      if (idx < NWP) {
+        const int q = idx & 3, co = (idx >> 2) & (BN - 1), t = idx / (4 * BN);
+        *reinterpret_cast<u32x4*>(wts + (size_t)(t * BN + co) * IG_PIX + q * 16) = wv[kk];
       }
-      __syncthreads();
+    }
+  };
+  if (nunit > 0) fetch(0);
+  for (int u = 0; u < nunit; ++u) {
+    __syncthreads();  // (the previous unit's fragments have been read)
+    stash(u);
+    __syncthreads();
+    if (u + 1 < nunit) fetch(u + 1);   // in flight while this unit is multiplied
+    const int t0 = (u % ngrp) * G;
 #pragma unroll
-      for (int t = 0; t < G; ++t) {
-        const unsigned toff = (unsigned)k.toff[t0 + t];
-        bf16x8 af[NCT];
+    for (int t = 0; t < G; ++t) {
+      const unsigned toff = (unsigned)k.toff[t0 + t];
+      bf16x8 af[NCT];
+#pragma unroll
+      for (int c = 0; c < NCT; ++c)
+        af[c] = *reinterpret_cast<const bf16x8*>(wts + (size_t)(t * BN + 16 * c) * IG_PIX + a_lane);
+      const unsigned char* const bp = patch + b_lane + toff;
+#pragma unroll
+      for (int r = 0; r < RW; ++r) {
+        const bf16x8 bf = *reinterpret_cast<const bf16x8*>(bp + r * b_row);
 #pragma unroll
         for (int c = 0; c < NCT; ++c)
-          af[c] = *reinterpret_cast<const bf16x8*>(wts + (size_t)(t * BN + 16 * c) * IG_PIX + a_lane);
-        const unsigned char* const bp = patch + b_lane + toff;
-#pragma unroll
-        for (int r = 0; r < RW; ++r) {
-          const bf16x8 bf = *reinterpret_cast<const bf16x8*>(bp + r * b_row);
-#pragma unroll
-          for (int c = 0; c < NCT; ++c)
-            acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[c], bf, acc[r][c], 0, 0, 0);
-        }
+          acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[c], bf, acc[r][c], 0, 0, 0);
       }
     }
   }
@@ -294,8 +304,16 @@ bool ig_shape(IgArgs& k, int* rw_out, int* nct_out, size_t* lds_out) {
     maxoh = q.OHt > maxoh ? q.OHt : maxoh;
   }
   k.PW = 15 * k.s + spanx;
-  for (int rw = 4; rw >= 1; rw >>= 1) {
+  static const char* rw_env = getenv("LSI_IGEMM_MAXRW");   // experiments
+  const int rw_max = rw_env ? atoi(rw_env) : 8;
+  for (int rw = rw_max; rw >= 1; rw >>= 1) {
     if (rw > 1 && 4 * (rw / 2) >= maxoh) continue;  // (a shorter block covers the rows)
+    // (rows 8 per wave: 12 fragment reads for 32 MFMAs instead of 8 for 16 -- the
+    // LDS read rate is what bounds the wide layers -- where the tile count still
+    // fills the chip twice)
+    if (rw == 8 && (long)((maxoh + 31) / 32) * ((k.cls[0].OWt + 15) / 16) * k.N * k.ncls *
+                           (k.Cout / bn) < 1024)
+      continue;
     const int th = 4 * rw;
     k.PH = (th - 1) * k.s + spany;
     const size_t patch = (size_t)k.PH * k.PW * IG_PIX;
@@ -349,6 +367,7 @@ int ig_launch(IgArgs& k, hipStream_t stream) {
 #define IG_CASE(R, C, GG) \
   if (rw == R && nct == C && k.G == GG) fn = (const void*)conv_igemm_kernel<R, C, GG>
 #define IG_CASES(GG) \
+  IG_CASE(8, 4, GG); IG_CASE(8, 2, GG); \
   IG_CASE(4, 4, GG); IG_CASE(2, 4, GG); IG_CASE(1, 4, GG); \
   IG_CASE(4, 2, GG); IG_CASE(2, 2, GG); IG_CASE(1, 2, GG)
   IG_CASES(9); IG_CASES(7); IG_CASES(5); IG_CASES(4);
