@@ -58,6 +58,7 @@ struct GwArgs {
   int khw, ntaps, ntg;        // kernel taps; tap groups of GW_GT
   int dy0, dx0, PH, PW, TH;   // patch origin (smallest dy, dx), size; tile rows per stage
   int nstrip, nrowblk, RB;
+  int NI;             // images per pixel block (small maps: all of them -- no partial sums to fold)
   signed char tdy[GW_MAXTAPS + 3], tdx[GW_MAXTAPS + 3];
 };
 
@@ -90,7 +91,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_igemm_kernel(GwArgs a) {
   int pb = blockIdx.x;
   const int rb = pb % a.nrowblk;
   pb /= a.nrowblk;
-  const int st = pb % a.nstrip, n = pb / a.nstrip;
+  const int st = pb % a.nstrip, n = (pb / a.nstrip) * a.NI;
+  const int n_end = min(a.N, n + a.NI);
   const int tg = blockIdx.y % a.ntg, c0 = (blockIdx.y / a.ntg) * 32;
   const int o0 = blockIdx.z * BN;
   const int t0 = tg * GW_GT, nt = min(GW_GT, a.ntaps - t0);
@@ -131,12 +133,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_igemm_kernel(GwArgs a) {
       poff[j] = ((a.tdy[t0 + tl] - a.dy0) * PW + (a.tdx[t0 + tl] - a.dx0)) * XS + 16 * c;
   }
 
+  for (int ni = n; ni < n_end; ++ni)
   for (int i0 = i_beg; i0 < i_end; i0 += TH) {
     __syncthreads();  // (the previous stage's fragments have been read)
     // ---- input patch: rows i0 * S + dy0 + py ---------------------------------
     {
       const int iy0 = i0 * S + a.dy0;
-      const int shift = iy0 * a.W * a.Cin;
+      const int shift = (iy0 + (ni - n) * a.H) * a.W * a.Cin;
       u32x4 pv[MAXP];
 #pragma unroll
       for (int k = 0; k < MAXP; ++k) {
@@ -167,7 +170,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_igemm_kernel(GwArgs a) {
           gv[k] = zero4;
           if (piece < ngp && oy < i_end && ox < a.OW)
             gv[k] = *reinterpret_cast<const u32x4*>(
-                a.gy + (((size_t)n * a.OH + oy) * a.OW + ox) * a.Cout + o0 + 8 * part);
+                a.gy + (((size_t)ni * a.OH + oy) * a.OW + ox) * a.Cout + o0 + 8 * part);
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -291,19 +294,28 @@ bool gw_plan(const LsiConvDesc* d, GwArgs& k, int* nct_out, size_t* lds_out, int
   const long chan_wgs = (long)(d->Cin / 32) * k.ntg * (d->Cout / bn);
   const size_t wbytes = (size_t)d->Cout * d->Cin * k.khw * sizeof(float);
   int rb = d->OH;
+  // images per pixel block: all of them while the channel blocks alone fill the
+  // chip (the bottleneck layers: 512 - 1024 channels on 2 x 6 ... 8 x 24 maps --
+  // one block, nothing to fold), fewer until there are enough workgroups
+  int ni = d->N;
+  while (ni > 1 && (long)((d->N + ni - 1) / ni) * k.nstrip * chan_wgs < 192) ni = (ni + 1) / 2;
+  while (ni < d->N && (size_t)((d->N + ni - 1) / ni) * k.nstrip * wbytes > GW_PART_CAP) ni *= 2;
+  if (ni > d->N) ni = d->N;
+  k.NI = ni;
+  const long nimg = (d->N + ni - 1) / ni;
   for (;;) {
     const long nrb = (d->OH + rb - 1) / rb;
-    const long nblk = (long)d->N * k.nstrip * nrb;
+    const long nblk = nimg * k.nstrip * nrb;
     if (nblk * chan_wgs >= 512 || rb <= th) break;
     const int half = ((rb / 2 + th - 1) / th) * th;
     if (half >= rb) break;
-    const long nblk2 = (long)d->N * k.nstrip * ((d->OH + half - 1) / half);
+    const long nblk2 = nimg * k.nstrip * ((d->OH + half - 1) / half);
     if ((size_t)nblk2 * wbytes > GW_PART_CAP) break;
     rb = half;
   }
   k.RB = rb;
   k.nrowblk = (d->OH + rb - 1) / rb;
-  const long nblk = (long)d->N * k.nstrip * k.nrowblk;
+  const long nblk = nimg * k.nstrip * k.nrowblk;
   if ((size_t)nblk * wbytes > GW_PART_CAP || nblk > 65535 * 32L) return false;
   *nblk_out = (int)nblk;
   *nct_out = nct;

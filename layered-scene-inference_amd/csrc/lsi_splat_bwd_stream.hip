@@ -79,6 +79,7 @@ struct BSArgs {
   int tex_sb, tex_sl, tex_sy, disp_sb, disp_sl, disp_sy;
   float s, max_disp, zscale, zA, zB;
   int compose;  // 1: one canvas for all layers (grid.z = 1), 0: grid.z = layer
+  int remap;    // see the kernel: the layers of a band as neighbours on one XCD
   int RS;       // source rows per band
   int GR;       // canvas rows the LDS tile holds (0: always gather from global)
 };
@@ -326,9 +327,25 @@ __global__ __launch_bounds__(BS_T, LSI_BS_WPE) void splat_bwd_stream_kernel(BSAr
   float4* const gt = reinterpret_cast<float4*>(smem);  // [GR][Wt]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int b = blockIdx.y;
-  const int ys = blockIdx.x * a.RS, ye = min(a.H, ys + a.RS);
-  const int l_lo = a.compose ? 0 : (int)blockIdx.z;
+  // Which (band, batch element, layer).  One workgroup per layer (both outputs:
+  // the composed canvas' rows are read by every layer's workgroup of a band):
+  // the L workgroups of a band are made neighbours in the dispatch order of ONE
+  // XCD (workgroup i runs on XCD i % 8), so that they are resident together and
+  // the composed rows they share come from that XCD's L2 once, not L times from
+  // memory (a.remap; LSI_BWD_REMAP=0: the natural order).
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (a.remap) {
+    const unsigned nbx = gridDim.x, L = gridDim.z;
+    const unsigned lin = blockIdx.x + nbx * (blockIdx.y + gridDim.y * blockIdx.z);
+    const unsigned xcd = lin & 7u, slot = lin >> 3;
+    const unsigned l = slot % L, pair = (slot / L) * 8u + xcd;
+    bz = (int)l;
+    by = (int)(pair / nbx);
+    bx = (int)(pair - (unsigned)by * nbx);
+  }
+  const int b = by;
+  const int ys = bx * a.RS, ye = min(a.H, ys + a.RS);
+  const int l_lo = a.compose ? 0 : bz;
   const int NL = a.compose ? a.L : 1;
   const int Wt = a.Wt;
   const int nseg = a.nseg;
@@ -525,6 +542,12 @@ int lsi_bwd_stream_launch(const LsiSplatDesc* d, const float* tex,
       return LSI_ELAUNCH;
   }
   const dim3 grid((d->H + rs - 1) / rs, d->B, a.compose ? 1 : d->L);
+  {
+    static const char* rm = getenv("LSI_BWD_REMAP");
+    const long nwg = (long)grid.x * grid.y * grid.z;
+    a.remap = (!a.compose && grid.z > 1 && nwg % (8L * grid.z) == 0 &&
+               !(rm && rm[0] == '0')) ? 1 : 0;
+  }
   void* kargs[1] = {&a};
   if (hipLaunchKernel(fn, grid, dim3(BS_T), kargs, lds, stream) != hipSuccess)
     return LSI_ELAUNCH;

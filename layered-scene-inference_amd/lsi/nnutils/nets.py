@@ -49,11 +49,14 @@ MFMA_CONV = os.environ.get('LSI_MFMA_CONV', '1') != '0'
 BF16_BATCH_NORM = os.environ.get('LSI_BF16_BN', '1') != '0'
 # Every other convolution with channel counts that are multiples of 32 on the
 # implicit-GEMM MFMA kernel (csrc/lsi_conv_igemm.hip); LSI_IGEMM_CONV=0: MIOpen.
-# Maps with fewer than IGEMM_MIN_PIXELS pixels (batch included; on the smaller
-# side of the layer) stay on the library: the bottleneck layers are small GEMMs
-# with too few tiles for this kernel (tools/conv_bench.py: profiles/r05/conv_bench.txt)
+# LSI_IGEMM_MIN_PIXELS=1024 sends maps with fewer pixels (batch included; on the
+# smaller side of the layer) to the library: the bottleneck layers `cnv6b`,
+# `cnv7b`, `icnv7`, `upcnv6/7` are small GEMMs with few tiles for this kernel,
+# where MIOpen is 1.1 - 1.4 x ahead -- 77 us of a 10 ms step in all
+# (tools/conv_bench.py: profiles/r05/conv_bench.txt); by default they too run on
+# the own kernel.
 IGEMM_CONV = os.environ.get('LSI_IGEMM_CONV', '1') != '0'
-IGEMM_MIN_PIXELS = int(os.environ.get('LSI_IGEMM_MIN_PIXELS', '1024'))
+IGEMM_MIN_PIXELS = int(os.environ.get('LSI_IGEMM_MIN_PIXELS', '0'))
 
 
 def _igemm_pays(x, stride):
