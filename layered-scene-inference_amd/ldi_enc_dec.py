@@ -300,8 +300,16 @@ class Trainer(train_utils.Trainer):
                              o.max_disp, self.host_mats[w])
           for w in ('trg', 'src'))
     dev = self.device
-    staged = [imgs_src.to(dev), imgs_trg.to(dev), mat_trg.to(dev),
-              mat_src.to(dev)]
+
+    def up(t):
+      # A pageable host-to-device copy blocks the host until the GPU has drained
+      # the kernels queued before it -- once per step that serialises the step's
+      # launches with the previous step's kernels (eager training: 12 ms per step
+      # instead of 10).  Through pinned memory the copy is asynchronous.
+      if dev.type == 'cuda' and not t.is_cuda:
+        return t.pin_memory().to(dev, non_blocking=True)
+      return t.to(dev)
+    staged = [up(imgs_src), up(imgs_trg), up(mat_trg), up(mat_src)]
     if getattr(self, 'gt_disps', None) is not None:
       # (part of the staged batch: a captured HIP graph replays on static copies)
       staged += [self.gt_disps[0].to(dev), self.gt_disps[1].to(dev)]
