@@ -24,15 +24,18 @@
 //   most recent tickets are in 16 bands of source rows several rows apart, so
 //   concurrent waves rarely meet in the tile.
 // * Every pixel is projected with the exact index arithmetic of the other
-//   paths and each corner is added to its tile cell by a plain LDS
-//   read-modify-write under a per-cell spin lock.  The two left corners
-//   (x0, y0) and (x0, y0+1) are locked by ONE `ds_wrxchg2_rtn_b32` and released
-//   by one `ds_write2_b32`, then the two right ones: lanes of a wave are >= 1
-//   cell apart in x, so lanes do not collide with themselves.  Integer LDS
-//   exchanges retire ~20x faster than `ds_add_f32` (tools/microbench2.hip).
-//   A lane never waits while it holds a lock (try both, add where acquired,
-//   release, retry what failed): no deadlock for any input, any collision
-//   pattern is merely slower.
+//   paths (the two exact quotients share one refined reciprocal: div2_rn) and
+//   each corner is added to its tile cell by a plain LDS read-modify-write of a
+//   cell the lane has TAKEN: the cell is its own lock (take2 below: an 8-byte
+//   exchange that swaps the cell's (b, w) half with a mark and returns what was
+//   there, one LDS round trip for lock + read; the 16-byte store of the sums
+//   gives the cell back).  The two left corners (x0, y0) and (x0, y0+1) are
+//   taken by ONE `ds_wrxchg2st64_rtn_b64`, then the two right ones: lanes of a
+//   wave are >= 1 cell apart in x, so lanes do not collide with themselves.
+//   Integer LDS exchanges retire ~20x faster than `ds_add_f32`
+//   (tools/microbench2.hip).  A lane never waits while it holds a cell (take
+//   both, add where taken, give back, retry what failed): no deadlock for any
+//   input, any collision pattern is merely slower.
 // * Tile cells are stored even/odd interleaved within a row: lanes two cells
 //   apart (trg_downsampling 0.5 x 4 pixels) hit consecutive 16-byte slots.
 // * Epilogue per cell: background, normalisation (ldi.py:122-125, 157-182).
@@ -68,6 +71,10 @@ constexpr int SWEEP_T = LSI_SWEEP_T;   // threads per workgroup
 constexpr int SWEEP_NW = SWEEP_T / 64;  // waves
 constexpr int SWEEP_BPW = (SWEEP_CAP / 64 + SWEEP_NW - 1) / SWEEP_NW;  // blocks per wave
 constexpr int SEGW = 64;        // source pixels per item (16 lanes x 4)
+// Tile rows in LDS: one dummy row above the tile's first row, one below its
+// last (row -1 takes the upper corners of pixels whose lower corners are the
+// tile's first row).
+constexpr int ROW0 = 1;
 
 struct SweepCfg {
   int th;          // nominal tile height (cells): equal-height tiles
@@ -90,40 +97,129 @@ __device__ __forceinline__ int div_small(int n, int d, float rcp) {
   return q;
 }
 
-// Try-lock of the lock words at LDS byte address `addr` and `addr + 4 * OFF1`:
-// writes 1 to both, returns what was there (0 = acquired).
-template <int OFF1>
-__device__ __forceinline__ void try_lock2(unsigned addr, int& o0, int& o1) {
-  unsigned long long r;
-  const int one = 1;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// A tile cell is its own lock.  A cell is 16 bytes (r, g | b, w); the w word of a
+// cell that a lane has taken holds the mark 0xffffffff (never a stored sum: see
+// keep_w).  TAKE = one 8-byte exchange of the (b, w) half with the mark -- the
+// returned w tells whether the lane got the cell, and the old b, w come with it
+// -- followed by a read of the (r, g) half (the LDS executes a wave's
+// instructions in order, so the read sees what the exchange saw).  GIVE BACK =
+// the 16-byte store of the updated cell.  One LDS round trip and two
+// instructions per cell pair less than lock words next to the cells (round 2-4:
+// exchange on a lock word, wait, read, wait, write, unlock), and no lock array.
+constexpr unsigned CELL_TAKEN = 0xffffffffu;
+// (the wave's lane mask of a condition without materialising it in a VGPR)
+__device__ __forceinline__ unsigned long long any_lane(bool x) {
+  return __builtin_amdgcn_ballot_w64(x);
+}
+
+// Takes the cells at LDS byte addresses `a` and `a + 512 * OFF` (the cell one
+// tile row below).  bw = {b0, w0, b1, w1}, rg = {r0, g0, r1, g1}.
+template <int OFF>
+__device__ __forceinline__ void take2(unsigned a, f32x4& bw, f32x4& rg) {
+  const unsigned long long mark = ~0ull;
+  const unsigned a8 = a + 8u;
   asm volatile(
-      "ds_wrxchg2_rtn_b32 %0, %1, %2, %2 offset1:%3\n\ts_waitcnt lgkmcnt(0)"
-      : "=&v"(r)
-      : "v"(addr), "v"(one), "n"(OFF1)
+      "ds_wrxchg2st64_rtn_b64 %0, %2, %4, %4 offset1:%5\n\t"
+      "ds_read2st64_b64 %1, %3 offset1:%5\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(bw), "=&v"(rg)
+      : "v"(a8), "v"(a), "v"(mark), "n"(OFF)
       : "memory");
-  o0 = (int)(unsigned)r;
-  o1 = (int)(r >> 32);
 }
-__device__ __forceinline__ int try_lock1(unsigned addr) {
-  int r;
-  const int one = 1;
-  asm volatile("ds_wrxchg_rtn_b32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)"
-               : "=&v"(r)
-               : "v"(addr), "v"(one)
-               : "memory");
-  return r;
+__device__ __forceinline__ void take1(unsigned a, f32x2& bw, f32x2& rg) {
+  const unsigned long long mark = ~0ull;
+  asm volatile(
+      "ds_wrxchg_rtn_b64 %0, %2, %3 offset:8\n\t"
+      "ds_read_b64 %1, %2\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(bw), "=&v"(rg)
+      : "v"(a), "v"(mark)
+      : "memory");
 }
-template <int OFF1>
-__device__ __forceinline__ void unlock2(unsigned addr) {
-  const int zero = 0;
-  asm volatile("ds_write2_b32 %0, %1, %1 offset1:%2"
-               :
-               : "v"(addr), "v"(zero), "n"(OFF1)
-               : "memory");
+// The common case of a cell pair as ONE straight-line block (no branch, no
+// compiler-made exec juggling: a wave issues in order, four waves per SIMD, so
+// every instruction of the loop is on some wave's critical path): the lanes of
+// `need` take the cell at `a` and the one `ROWB` bytes below it, add V * wa /
+// V * wb where they got the cell, and give it back -- (r, g) first, then (b, w),
+// whose store is what releases the cell.  Returns the lane masks of the cells
+// NOT got (left to the caller's retry loop: rare).  A taken cell reads back as
+// the all-ones mark in b and w: one 64-bit compare.
+template <int ROWB>
+__device__ __forceinline__ void pair_add(unsigned long long need, unsigned a, f32x2 vxy,
+                                         f32x2 vzw, f32x2 wa, f32x2 wb,
+                                         unsigned long long& fa, unsigned long long& fb) {
+  const unsigned long long mark = ~0ull;
+  const unsigned a8 = a + 8u;
+  f32x2 bwa, bwb, rga, rgb;
+  unsigned long long sv, nx;
+  asm volatile(
+      "s_and_saveexec_b64 %[sv], %[need]\n\t"
+      "ds_wrxchg_rtn_b64 %[bwa], %[a8], %[mk]\n\t"
+      "ds_wrxchg_rtn_b64 %[bwb], %[a8], %[mk] offset:%[rowb]\n\t"
+      "ds_read_b64 %[rga], %[a]\n\t"
+      "ds_read_b64 %[rgb], %[a] offset:%[rowb]\n\t"
+      "s_mov_b64 %[nx], exec\n\t"
+      "s_waitcnt lgkmcnt(2)\n\t"
+      "v_cmp_eq_u64_e64 %[fa], -1, %[bwa]\n\t"
+      "v_cmp_eq_u64_e64 %[fb], -1, %[bwb]\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "s_andn2_b64 exec, %[nx], %[fa]\n\t"
+      "v_pk_fma_f32 %[rga], %[vxy], %[wa], %[rga] op_sel_hi:[1,0,1]\n\t"
+      "v_pk_fma_f32 %[bwa], %[vzw], %[wa], %[bwa] op_sel_hi:[1,0,1]\n\t"
+      "ds_write_b64 %[a], %[rga]\n\t"
+      "ds_write_b64 %[a8], %[bwa]\n\t"
+      "s_andn2_b64 exec, %[nx], %[fb]\n\t"
+      "v_pk_fma_f32 %[rgb], %[vxy], %[wb], %[rgb] op_sel_hi:[1,0,1]\n\t"
+      "v_pk_fma_f32 %[bwb], %[vzw], %[wb], %[bwb] op_sel_hi:[1,0,1]\n\t"
+      "ds_write_b64 %[a], %[rgb] offset:%[rowb]\n\t"
+      "ds_write_b64 %[a8], %[bwb] offset:%[rowb]\n\t"
+      "s_mov_b64 exec, %[sv]"
+      : [bwa] "=&v"(bwa), [bwb] "=&v"(bwb), [rga] "=&v"(rga), [rgb] "=&v"(rgb),
+        [sv] "=&s"(sv), [nx] "=&s"(nx), [fa] "=&s"(fa), [fb] "=&s"(fb)
+      : [need] "s"(need), [a] "v"(a), [a8] "v"(a8), [mk] "v"(mark), [vxy] "v"(vxy),
+        [vzw] "v"(vzw), [wa] "v"(wa), [wb] "v"(wb), [rowb] "n"(ROWB)
+      : "memory", "vcc");
 }
-__device__ __forceinline__ void unlock1(unsigned addr) {
-  const int zero = 0;
-  asm volatile("ds_write_b32 %0, %1" : : "v"(addr), "v"(zero) : "memory");
+
+__device__ __forceinline__ bool got_cell(float w) { return __float_as_uint(w) != CELL_TAKEN; }
+// A stored w never carries the mark: only a NaN with that payload could, and
+// only from a NaN mask value with it (every other input that is not finite is
+// dropped or lands in r, g, b) -- the pixel weight is passed through this (it
+// stays a NaN, with the next payload), and so are the sums of the C++ path.
+template <bool HAS_MASK>
+__device__ __forceinline__ float keep_w(float w) {
+  return HAS_MASK ? __uint_as_float(min(__float_as_uint(w), CELL_TAKEN - 1u)) : w;
+}
+
+// The two exact quotients q0 / n and q1 / n (IEEE, round to nearest: they feed
+// floorf) and the refined reciprocal of n.  When |n|, |q0|, |q1| all lie in
+// [2^-60, 2^60] -- every lane of the wave: one branch -- v_div_scale_f32 scales
+// nothing and v_div_fixup_f32 passes the quotient through, so the compiler's
+// division is this sequence with one reciprocal per quotient; sharing the
+// reciprocal gives the same bits with 13 instead of 22 instructions and one
+// v_rcp_f32 instead of three (the weight's reciprocal was a third).
+__device__ __forceinline__ void div2_rn(float q0, float q1, float n, bool active,
+                                        float& o0, float& o1, float& rcp_n) {
+  const float hi = fmaxf(fmaxf(fabsf(n), fabsf(q0)), fabsf(q1));
+  const float lo = fminf(fminf(fabsf(n), fabsf(q0)), fabsf(q1));
+  const bool plain = hi < 0x1p60f && lo > 0x1p-60f;  // (false for NaN)
+  float r = __builtin_amdgcn_rcpf(n);
+  r = __fmaf_rn(__fmaf_rn(-n, r, 1.0f), r, r);
+  rcp_n = r;
+  if (any_lane(active && !plain) == 0ull) {
+    float a = q0 * r;
+    a = __fmaf_rn(__fmaf_rn(-n, a, q0), r, a);
+    o0 = __fmaf_rn(__fmaf_rn(-n, a, q0), r, a);
+    float b = q1 * r;
+    b = __fmaf_rn(__fmaf_rn(-n, b, q1), r, b);
+    o1 = __fmaf_rn(__fmaf_rn(-n, b, q1), r, b);
+  } else {
+    o0 = div_rn(q0, n);
+    o1 = div_rn(q1, n);
+  }
 }
 
 template <int TWL, bool VEC4, bool HAS_MASK, bool WANT_DISP>
@@ -137,21 +233,21 @@ __global__ __launch_bounds__(SWEEP_T, LSI_SWEEP_WGS) void splat_sweep_kernel(
   const int l_begin = c.all_layers ? 0 : (int)blockIdx.z;
   const int NLW = c.all_layers ? d.L : 1;  // layers this workgroup sums
   // c.thmax rows of cells are allocated; the tile's own height is decided below
-  const int NCP = (c.thmax + 2) << TWL;
+  const int NCP = (c.thmax + ROW0 + 1) << TWL;
   const int tile_y = blockIdx.x / c.tiles_x, tile_x = blockIdx.x - tile_y * c.tiles_x;
   const int tx0 = tile_x * TW;
   const int Ht = d.Ht, Wt = d.Wt, H = d.H, W = d.W;
 
-  // r g b w sums and one lock per cell, rows -1 .. thmax (slot row r + 1)
-  float4* tile = reinterpret_cast<float4*>(smem);   // [thmax + 2][TW]
-  int* locks = reinterpret_cast<int*>(tile + NCP);  // [thmax + 2][TW]
-  int* list = locks + NCP;                          // [SWEEP_CAP] accepted items
+  // r g b w sums per cell, rows -1 .. thmax (slot row r + 1); a cell is its own
+  // lock (take2 above)
+  float4* tile = reinterpret_cast<float4*>(smem);   // [thmax + ROW0 + 1][TW]
+  int* list = reinterpret_cast<int*>(tile + NCP);   // [SWEEP_CAP] accepted items
   int* cnt = list + SWEEP_CAP;                      // [64] per-block counts
   int* ctl = cnt + 64;                              // [1] list fill
   float2* lrange = reinterpret_cast<float2*>(ctl + 4);  // [LSI_SWEEP_MAXL]
   // WANT_DISP: sum of (target disparity * weight) per cell, next to the tile
-  float* dsum = reinterpret_cast<float*>(lrange + LSI_SWEEP_MAXL);  // [thmax + 2][TW]
-  const unsigned locks_addr = (unsigned)(uintptr_t)locks;
+  float* dsum = reinterpret_cast<float*>(lrange + LSI_SWEEP_MAXL);  // [thmax + ROW0 + 1][TW]
+  const unsigned tile_addr = (unsigned)(uintptr_t)tile;
 
   float m[16];
 #pragma unroll
@@ -166,7 +262,6 @@ __global__ __launch_bounds__(SWEEP_T, LSI_SWEEP_WGS) void splat_sweep_kernel(
 
   for (int i = tid; i < NCP; i += SWEEP_T) {
     tile[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    locks[i] = 0;
     if (WANT_DISP) dsum[i] = 0.0f;
   }
   if (tid < NLW) {  // the layer's disparity range: fold the row slices
@@ -440,84 +535,68 @@ __global__ __launch_bounds__(SWEEP_T, LSI_SWEEP_WGS) void splat_sweep_kernel(
       }
     };
 
-    // Adds V * wa to the cell at slot `cell` (= (row + 1) * TW + slot, row in
+    // Adds V * wa to the cell at slot `cell` (= (row + ROW0) * TW + slot, row in
     // -1 .. TH-1) and V * wb to the cell below it, for the lanes with need ==
-    // true.  Both cells are locked and updated together whatever their
+    // true.  Both cells are taken and updated together whatever their
     // weights (the reference, too, adds all four corners, zero weights
     // included); rows -1 and TH exist so that no lane needs a special case --
-    // what lands there is never read.
+    // what lands there is never read.  A lane never waits while it holds a
+    // cell: it updates and gives back what it got, then retries what it did not
+    // get, one cell at a time.
     auto locked_pair = [&](bool need, int cell, float wa, float wb,
                            const float4& V, float vd) {
 #if LSI_STREAM_HOOKS
       if (d.reserved & 512) return;  // timing experiment: no accumulation
 #endif
-      const unsigned la = locks_addr + (unsigned)cell * 4u;
-      bool pend = false;
-      if (need) {
-        int oa, ob;
-#if LSI_STREAM_HOOKS
-        if (d.reserved & 1024) { oa = 0; ob = 0; } else  // experiment: no locks
-#endif
-        try_lock2<TW>(la, oa, ob);
-        if ((oa | ob) == 0) {
-          float4 ta = tile[cell], tb = tile[cell + TW];
-          // (explicit FMAs: a sum, not an index or a threshold)
-          ta.x = __fmaf_rn(V.x, wa, ta.x); ta.y = __fmaf_rn(V.y, wa, ta.y);
-          ta.z = __fmaf_rn(V.z, wa, ta.z); ta.w = __fmaf_rn(V.w, wa, ta.w);
-          tb.x = __fmaf_rn(V.x, wb, tb.x); tb.y = __fmaf_rn(V.y, wb, tb.y);
-          tb.z = __fmaf_rn(V.z, wb, tb.z); tb.w = __fmaf_rn(V.w, wb, tb.w);
-          tile[cell] = ta;
-          tile[cell + TW] = tb;
-          if (WANT_DISP) {
-            dsum[cell] = __fmaf_rn(vd, wa, dsum[cell]);
-            dsum[cell + TW] = __fmaf_rn(vd, wb, dsum[cell + TW]);
-          }
-          asm volatile("" ::: "memory");
-#if LSI_STREAM_HOOKS
-          if (!(d.reserved & 1024))
-#endif
-          unlock2<TW>(la);
-        } else {  // give back the half that was acquired
-          if (oa == 0) unlock1(la);
-          if (ob == 0) unlock1(la + TW * 4u);
-          pend = true;
+      const unsigned ca = tile_addr + (unsigned)cell * 16u;
+      auto put = [&](int c1, float w1, float r, float g, float bb, float ww) {
+        if (WANT_DISP) {
+          dsum[c1] = __fmaf_rn(vd, w1, dsum[c1]);
+          asm volatile("" ::: "memory");  // before the cell is given back
         }
+        // (explicit FMAs: a sum, not an index or a threshold)
+        tile[c1] = make_float4(__fmaf_rn(V.x, w1, r), __fmaf_rn(V.y, w1, g),
+                               __fmaf_rn(V.z, w1, bb),
+                               keep_w<HAS_MASK>(__fmaf_rn(V.w, w1, ww)));
+      };
+      bool na, nb;
+      if (!WANT_DISP) {
+        unsigned long long fa, fb;
+        pair_add<TW * 16>(any_lane(need), ca, f32x2{V.x, V.y}, f32x2{V.z, V.w},
+                          f32x2{wa, wa}, f32x2{wb, wb}, fa, fb);
+        if ((fa | fb) == 0ull) return;  // (nearly always)
+        na = (fa >> lane) & 1ull;
+        nb = (fb >> lane) & 1ull;
+      } else {
+        f32x4 bw, rg;
+        bool ga = false, gb = false;
+        if (need) {
+          take2<TW / 32>(ca, bw, rg);
+          ga = got_cell(bw.y);
+          gb = got_cell(bw.w);
+        }
+        if (ga) put(cell, wa, rg.x, rg.y, bw.x, bw.y);
+        if (gb) put(cell + TW, wb, rg.z, rg.w, bw.z, bw.w);
+        na = need && !ga;
+        nb = need && !gb;
       }
-      // Lost a lock to another lane: one cell at a time, only cells still
-      // needed (two lanes after the same pair cannot keep each other's other
-      // half busy), never waiting while holding a lock.
-      if (__ballot(pend) != 0ull) {
-        bool na = pend, nb = pend;
-        while (__ballot(na || nb) != 0ull) {
-          if (na) {
-            if (try_lock1(la) == 0) {
-              float4 t = tile[cell];
-              t.x = __fmaf_rn(V.x, wa, t.x); t.y = __fmaf_rn(V.y, wa, t.y);
-              t.z = __fmaf_rn(V.z, wa, t.z); t.w = __fmaf_rn(V.w, wa, t.w);
-              tile[cell] = t;
-              if (WANT_DISP) dsum[cell] = __fmaf_rn(vd, wa, dsum[cell]);
-              asm volatile("" ::: "memory");
-              unlock1(la);
-              na = false;
-            }
-          } else if (nb) {
-            if (try_lock1(la + TW * 4u) == 0) {
-              float4 t = tile[cell + TW];
-              t.x = __fmaf_rn(V.x, wb, t.x); t.y = __fmaf_rn(V.y, wb, t.y);
-              t.z = __fmaf_rn(V.z, wb, t.z); t.w = __fmaf_rn(V.w, wb, t.w);
-              tile[cell + TW] = t;
-              if (WANT_DISP) dsum[cell + TW] = __fmaf_rn(vd, wb, dsum[cell + TW]);
-              asm volatile("" ::: "memory");
-              unlock1(la + TW * 4u);
-              nb = false;
-            }
+      // Lost a cell to another lane: one cell at a time, only cells still needed
+      while (any_lane(na || nb) != 0ull) {
+        if (na || nb) {
+          const int c1 = na ? cell : cell + TW;
+          const float w1 = na ? wa : wb;
+          f32x2 bw1, rg1;
+          take1(tile_addr + (unsigned)c1 * 16u, bw1, rg1);
+          if (got_cell(bw1.y)) {
+            put(c1, w1, rg1.x, rg1.y, bw1.x, bw1.y);
+            if (na) na = false; else nb = false;
           }
         }
       }
     };
 
     auto process = [&](const Px& p) {
-      if (__ballot(p.x >= 0) == 0ull) return;
+      if (any_lane(p.x >= 0) == 0ull) return;
 #if LSI_STREAM_HOOKS
       if (d.reserved & 2048) return;  // timing experiment: loads only
 #endif
@@ -536,36 +615,31 @@ __global__ __launch_bounds__(SWEEP_T, LSI_SWEEP_WGS) void splat_sweep_kernel(
         const float dv = dvs[j];
         const float q1 = ((px * m[4] + pm1) + m[6]) + dv * m[7];
         const float nden = safe_den(((px * m[8] + pm2) + m[10]) + dv * m[11]);
-        const float Y = div_rn(q1, nden) * s - 0.5f;
-        const float y0 = floorf(Y);
         const float q0 = ((px * m[0] + pm0) + m[2]) + dv * m[3];
-        const float X = div_rn(q0, nden) * s - 0.5f;
+        float qx, qy, rn;
+        div2_rn(q0, q1, nden, p.x >= 0, qx, qy, rn);
+        const float Y = qy * s - 0.5f;
+        const float y0 = floorf(Y);
+        const float X = qx * s - 0.5f;
         const float x0 = floorf(X);
         // (non-finite X / Y fail the comparisons: dropped, like every path)
         bool ok = p.x >= 0 && y0 >= ay_lo && y0 <= ay_hi && x0 >= ax_lo && x0 <= ax_hi;
-        if (__ballot(ok) == 0ull) continue;
+        if (any_lane(ok) == 0ull) continue;
 #if LSI_STREAM_HOOKS
         if (prof) tacc[5] += 1 + ((long long)__popcll(__ballot(ok)) << 32);  // px-iters, ok lanes
 #endif
         const float q3 = ((px * m[12] + pm3) + m[14]) + dv * m[15];
         // The target disparity feeds the weight and the disparity output
-        // (1e-4 relative), no index or threshold: reciprocal + one Newton step
-        // instead of the IEEE division (the disparity output keeps the exact
-        // quotient)
-        float dd;
-        if (WANT_DISP) {
-          dd = div_rn(q3, nden);
-        } else {
-          float r = __builtin_amdgcn_rcpf(nden);
-          r = __fmaf_rn(__fmaf_rn(-nden, r, 1.0f), r, r);
-          dd = q3 * r;
-        }
+        // (1e-4 relative), no index or threshold: the refined reciprocal of the
+        // normaliser instead of the IEEE division (the disparity output keeps
+        // the exact quotient)
+        const float dd = WANT_DISP ? div_rn(q3, nden) : q3 * rn;
         // exp((clip(D/max,0,1) - 0.5) * scale) [D > 0] as exp2 of one fma
         const float xn = dd * inv_md;
         const float ez = __builtin_amdgcn_exp2f(
             __fmaf_rn(__builtin_amdgcn_fmed3f(xn, 0.0f, 1.0f), zA, zB));
         const float zw = xn > 0.0f ? ez : 0.0f;
-        const float pw = (VEC4 && !HAS_MASK) ? zw : zw * mks[j];
+        const float pw = (VEC4 && !HAS_MASK) ? zw : keep_w<true>(zw * mks[j]);
         ok = ok && pw != 0.0f;  // contributes exactly +0 everywhere
         // Corner weights (sampling.py:193-222).  The border masks are implied:
         // a corner outside the image is outside every tile and never read.
@@ -581,7 +655,7 @@ __global__ __launch_bounds__(SWEEP_T, LSI_SWEEP_WGS) void splat_sweep_kernel(
         const int ixr = ix + 1;
         const int sl = (ix >> 1) + ((ix & 1) << (TWL - 1));
         const int sr = (ixr >> 1) + ((ixr & 1) << (TWL - 1));
-        const int rowb = (iy + 1) << TWL;
+        const int rowb = (iy + ROW0) << TWL;
         SWEEP_STAMP(1);
         locked_pair(ok && ix >= 0, rowb + sl, w00, w10, V, dd * pw);
         SWEEP_STAMP(2);
@@ -628,7 +702,7 @@ __global__ __launch_bounds__(SWEEP_T, LSI_SWEEP_WGS) void splat_sweep_kernel(
       const int cell = tid + k * SWEEP_T;
       if (cell >= (th_eff << TWL)) continue;
       const int cy = cell >> TWL, cx = cell & (TW - 1);
-      const int slot = ((cy + 1) << TWL) + (cx >> 1) + ((cx & 1) << (TWL - 1));
+      const int slot = ((cy + ROW0) << TWL) + (cx >> 1) + ((cx & 1) << (TWL - 1));
       const float4 t = tile[slot];
       const float bg = d.bg_wt;
       const float l0 = bg + t.x, l1 = bg + t.y, l2 = bg + t.z, lw = bg + t.w;
@@ -691,7 +765,7 @@ __global__ __launch_bounds__(SWEEP_T, LSI_SWEEP_WGS) void splat_sweep_kernel(
     // of the row's 3 * TW colour floats -- they belong to cells 4q/3 and 4q/3+1.
     constexpr int QR = 3 * TW / 4;  // 16-byte stores per tile row (colours)
     auto cell_at = [&](int cy, int cx) {
-      return tile[((cy + 1) << TWL) + (cx >> 1) + ((cx & 1) << (TWL - 1))];
+      return tile[((cy + ROW0) << TWL) + (cx >> 1) + ((cx & 1) << (TWL - 1))];
     };
     for (int q = tid; q < th_eff * QR; q += SWEEP_T) {
       const int cy = q / QR, j = q - cy * QR;
@@ -724,7 +798,7 @@ __global__ __launch_bounds__(SWEEP_T, LSI_SWEEP_WGS) void splat_sweep_kernel(
     const int cy = cell >> TWL, cx = cell & (TW - 1);
     const int gy = ty0 + cy, gx = tx0 + cx;
     if (gx >= Wt) continue;
-    const int slot = ((cy + 1) << TWL) + (cx >> 1) + ((cx & 1) << (TWL - 1));
+    const int slot = ((cy + ROW0) << TWL) + (cx >> 1) + ((cx & 1) << (TWL - 1));
     const float4 t = tile[slot];
     const size_t o = obase + (size_t)gy * Wt + gx;
     const float w = t.w + bgs;
@@ -774,7 +848,7 @@ int lsi_sweep_launch(const SplatArgs& a, const float2* range, hipStream_t stream
   const LsiSplatDesc* d = &a.d;
   if (d->H > 65535 || d->W > 65535) return LSI_EINVAL;  // item packing
   SweepCfg c;
-  // a tile of (up to) 4096 cells: 64 KB of sums + 17 KB of locks
+  // a tile of (up to) 4096 cells: 64 KB of sums (+ two dummy rows)
   const int twl = d->Wt <= 32 ? 5 : (d->Wt <= 64 ? 6 : 7);
   const int TW = 1 << twl;
   const bool compose = (d->flags & LSI_COMPOSE) != 0;
@@ -802,7 +876,7 @@ int lsi_sweep_launch(const SplatArgs& a, const float2* range, hipStream_t stream
   const int tiles_y = (d->Ht + c.th - 1) / c.th;
   c.nty = tiles_y;
   // adaptive tile rows: up to 1.5x the nominal height (48 rows of 128 cells:
-  // 128 KB of sums and locks)
+  // 100 KB of sums)
   const bool want_disp = (d->flags & LSI_WANT_DISP) != 0;
   if (want_disp && !a.out_disp) return LSI_ENULL;
   // (with the disparity output: 4 more bytes per cell, and the composed
@@ -810,7 +884,7 @@ int lsi_sweep_launch(const SplatArgs& a, const float2* range, hipStream_t stream
   c.adaptive = (tiles_y >= 2 && tiles_y <= 63 && d->Ht <= SWEEP_CAP &&
                 !want_disp && !(d->reserved & 4096)) ? 1 : 0;
   c.thmax = c.adaptive ? c.th + c.th / 2 : c.th;
-  const size_t lds = (size_t)(c.thmax + 2) * TW * (want_disp ? 24 : 20) + (size_t)SWEEP_CAP * 4 + 64 * 4 + 16 +
+  const size_t lds = (size_t)(c.thmax + ROW0 + 1) * TW * (want_disp ? 20 : 16) + (size_t)SWEEP_CAP * 4 + 64 * 4 + 16 +
                      LSI_SWEEP_MAXL * 8;
   const bool vec4 = sweep_vec4(a), has_mask = (d->flags & LSI_HAS_MASK) != 0;
   const void* fn = twl == 5 ? sweep_fn<5>(vec4, has_mask, want_disp)
