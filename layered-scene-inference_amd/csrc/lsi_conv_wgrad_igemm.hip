@@ -249,6 +249,42 @@ __global__ __launch_bounds__(1024) void conv_wgrad_fold_kernel(const float* part
   }
 }
 
+// The same fold for layers with many channels (Cout * Cin / 64 workgroups fill
+// the chip): workgroup = (co, 64 input channels), all taps.  The partials
+// [blk][tap][co][ci] are read in 256-byte runs per (block, tap); the sums go
+// through LDS and leave as ONE contiguous run of 64 * khw floats of the
+// parameter's layout [co][ci][tap] (the fold above writes 4-byte pieces khw
+// floats apart: 9 - 16 visits per cache line, ~70 us for a 512 x 512 x 3 x 3
+// layer whatever its map size; this one: a plain stream).
+__global__ __launch_bounds__(256) void conv_wgrad_fold_t_kernel(const float* part, int nblk,
+                                                                int Cout, int Cin, int khw,
+                                                                float* out) {
+  extern __shared__ float ft_tile[];  // [64][khw + 1]
+  const int ncc = Cin / 64;
+  const int co = blockIdx.x / ncc, ci0 = (blockIdx.x - co * ncc) * 64;
+  const int l = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const size_t nout = (size_t)khw * Cout * Cin;
+  for (int tap = grp; tap < khw; tap += 4) {
+    const float* p = part + ((size_t)tap * Cout + co) * Cin + ci0 + l;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int w = 0;
+    for (; w + 3 < nblk; w += 4) {
+      s0 += p[(size_t)w * nout];
+      s1 += p[(size_t)(w + 1) * nout];
+      s2 += p[(size_t)(w + 2) * nout];
+      s3 += p[(size_t)(w + 3) * nout];
+    }
+    for (; w < nblk; ++w) s0 += p[(size_t)w * nout];
+    ft_tile[l * (khw + 1) + tap] = (s0 + s1) + (s2 + s3);
+  }
+  __syncthreads();
+  float* o = out + ((size_t)co * Cin + ci0) * khw;
+  for (int i = threadIdx.x; i < 64 * khw; i += 256) {
+    const int c = i / khw, tap = i - c * khw;
+    o[i] = ft_tile[c * (khw + 1) + tap];
+  }
+}
+
 bool gw_desc_ok(const LsiConvDesc* d) {
   if (!d) return false;
   if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->OH <= 0 || d->OW <= 0) return false;
@@ -362,7 +398,13 @@ extern "C" int lsi_conv2d_wgrad(const LsiConvDesc* d, const void* x, const void*
   void* kargs[1] = {&k};
   if (hipLaunchKernel(fn, grid, dim3(256), kargs, lds, stream) != hipSuccess) return LSI_ELAUNCH;
   if (hipGetLastError() != hipSuccess) return LSI_ELAUNCH;
-  hipLaunchKernelGGL(conv_wgrad_fold_kernel, dim3((unsigned)((nout + 63) / 64)), dim3(1024), 0,
-                     stream, k.part, nblk, (int)nout, g_weight, d->KH * d->KW);
+  const int khw = d->KH * d->KW;
+  if (d->Cin % 64 == 0 && (long)d->Cout * (d->Cin / 64) >= 1024)
+    hipLaunchKernelGGL(conv_wgrad_fold_t_kernel, dim3((unsigned)(d->Cout * (d->Cin / 64))), dim3(256),
+                       (size_t)64 * (khw + 1) * sizeof(float), stream, k.part, nblk, d->Cout,
+                       d->Cin, khw, g_weight);
+  else
+    hipLaunchKernelGGL(conv_wgrad_fold_kernel, dim3((unsigned)((nout + 63) / 64)), dim3(1024), 0,
+                       stream, k.part, nblk, (int)nout, g_weight, khw);
   return hipGetLastError() == hipSuccess ? LSI_OK : LSI_ELAUNCH;
 }

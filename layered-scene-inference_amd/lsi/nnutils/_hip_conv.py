@@ -376,7 +376,7 @@ def _empty_cl(n, c, h, w, dev):
 
 
 OWN_WGRAD = os.environ.get('LSI_IGEMM_WGRAD', '1') != '0'
-IGEMM_WGRAD_MIN_PIXELS = int(os.environ.get('LSI_IGEMM_WGRAD_MIN_PIXELS', '4096'))
+IGEMM_WGRAD_MIN_PIXELS = int(os.environ.get('LSI_IGEMM_WGRAD_MIN_PIXELS', '0'))
 _WGRAD_BYTES = {}
 
 
@@ -386,8 +386,9 @@ def _igemm_wgrad_bytes(d):
   n = _WGRAD_BYTES.get(key)
   if n is None:
     n = int(_C.lib().lsi_conv2d_wgrad_workspace_bytes(ctypes.byref(d)))
-    # (below ~4 k output pixels the K = pixels GEMM has too few pixel blocks to
-    # fill the chip and the library's kernels are ahead: tools/conv_bench.py)
+    # (every map size since the transposing fold -- the bottleneck layers' 2 x 6
+    # ... 8 x 24 maps, too: 32 - 66 us against the library's 25 - 92,
+    # tools/conv_bench.py; LSI_IGEMM_WGRAD_MIN_PIXELS sends small maps back)
     if d.N * d.OH * d.OW < IGEMM_WGRAD_MIN_PIXELS:
       n = 0
     _WGRAD_BYTES[key] = n
