@@ -436,6 +436,13 @@ int lsi_bn_relu_bwd(const void* x, const void* dy, const float* mean_rstd,
                     const float* beta, void* dx, float* dbeta, float* workspace,
                     int64_t npix, int32_t C, int32_t bf16, int32_t relu,
                     int32_t groups, lsi_stream_t stream);
+/* lsi_bn_relu_fwd behind a producer that left the sums of x and x * x in
+ * `workspace` (lsi_conv2d_fwd_bnstats / lsi_conv2d_bwd_data_bnstats on the same
+ * stream): one pass -- y = relu((x - mean) * rstd + beta), mean_rstd out as from
+ * lsi_bn_relu_fwd --, accumulators cleared for the next producer. */
+int lsi_bn_relu_norm(const void* x, void* y, const float* beta, float* workspace,
+                     float* mean_rstd, int64_t npix, int32_t C, int32_t bf16, int32_t relu,
+                     float eps, int32_t groups, lsi_stream_t stream);
 
 /*
  * 3x3 stride-1 SAME convolution over 32 input channels on the matrix cores
@@ -575,6 +582,24 @@ int lsi_conv2d_fwd(const LsiConvDesc* d, const void* x, const void* packed, void
                    lsi_stream_t stream);
 int lsi_conv2d_bwd_data(const LsiConvDesc* d, const void* gy, const void* packed, void* gx,
                         lsi_stream_t stream);
+/*
+ * The same two calls for a layer that slim.batch_norm follows (every
+ * slim.conv2d / conv2d_transpose of nets.py:44-67, 95-111, 265-347): the
+ * kernel's epilogue also adds the sums of y and y * y of its (bf16-rounded)
+ * output -- per channel and sub-batch group, what lsi_bn_relu_fwd's first pass
+ * would read the tensor back for -- to the accumulators of `bn_workspace`
+ * (lsi_bn_workspace_floats; zero-filled once).  The caller completes the layer
+ * with lsi_bn_relu_norm(out, y, ...) as the NEXT call that uses this workspace
+ * on the stream: it folds the sums, forms mean / rstd and clears the
+ * accumulators.  groups must divide N.  (Plain sums, no shift: a layer whose
+ * |mean| is 10^3 times its standard deviation loses the variance -- not a
+ * convolution without bias behind a batch norm.)
+ */
+int lsi_conv2d_fwd_bnstats(const LsiConvDesc* d, const void* x, const void* packed, void* out,
+                           float* bn_workspace, int32_t groups, lsi_stream_t stream);
+int lsi_conv2d_bwd_data_bnstats(const LsiConvDesc* d, const void* gy, const void* packed,
+                                void* gx, float* bn_workspace, int32_t groups,
+                                lsi_stream_t stream);
 /*
  * Weight gradient of the convolution LsiConvDesc describes (TF autodiff of
  * slim.conv2d, reference nets.py:29-114, 244-348):

@@ -27,6 +27,7 @@
 #include <stdlib.h>
 
 #include "../../include/lsi_hip.h"
+#include "lsi_splat_internal.h"
 
 namespace {
 
@@ -74,7 +75,7 @@ template <> struct Vec<true> {
 // workspace layout per group (floats): [0] arrival counter (int), [16, 16 + 4096)
 // the accumulators -- both zero between launches --, then 2*C constants of the
 // second pass and (backward) the group's C sums of dz
-constexpr int WS_ACC = 16, WS_CONST = 16 + 4096, WS_STRIDE = 16 + 4096 + 3 * 2048;
+constexpr int WS_ACC = LSI_BN_WS_ACC, WS_CONST = LSI_BN_WS_CONST, WS_STRIDE = LSI_BN_WS_STRIDE;
 
 // Sums of the per-thread accumulators over the threads that hold the same
 // channels (tid % lpp), added to the 2*C global accumulators; returns true in
@@ -239,6 +240,83 @@ __global__ __launch_bounds__(BN_THREADS) void bn_norm_kernel(
     long npix, int C, int relu) {
   norm_pass<BF16>(grp_in<BF16>(x, npix, C), grp_out<BF16>(y, npix, C),
                          ws + (size_t)blockIdx.y * WS_STRIDE + WS_CONST, npix, C, relu);
+}
+
+// The second pass behind a producer that left plain sums of x and x * x in the
+// group's accumulator slots (the convolution kernels' epilogue,
+// lsi_conv_igemm.hip): every workgroup folds the slots and forms the constants
+// itself (2 C * slots floats out of L2: less than its first pixel step), the
+// group's first workgroup leaves mean / rstd for the backward, and the
+// workgroup that finishes last -- all of them have read the sums by then --
+// clears the accumulators for the next producer.
+template <bool BF16>
+__global__ __launch_bounds__(BN_THREADS) void bn_norm_sums_kernel(
+    const void* __restrict__ x, void* __restrict__ y, const float* __restrict__ beta,
+    float* __restrict__ ws_, float* __restrict__ mean_rstd_, long npix, int C, int relu,
+    float eps, int ns) {
+  __shared__ float ab[2 * 2048];
+  __shared__ float red[BN_THREADS];
+  float* ws = ws_ + (size_t)blockIdx.y * WS_STRIDE;
+  // (plain loads: the sums were added by the previous kernel on the stream; all
+  // of a thread's loads are in flight together)
+  const float* acc = ws + WS_ACC;
+  const int n2 = 2 * C;
+  if (n2 <= BN_THREADS) {   // several threads per entry, a few slots each
+    const int t = threadIdx.x % n2, s0 = threadIdx.x / n2, sstep = BN_THREADS / n2;
+    float v = 0.0f;
+    for (int sl = s0; sl < ns; sl += sstep) v += acc[sl * n2 + t];
+    red[threadIdx.x] = v;
+    __syncthreads();
+    if ((int)threadIdx.x < n2) {
+      v = 0.0f;
+      for (int k = 0; k < sstep; ++k) v += red[k * n2 + threadIdx.x];
+      ab[threadIdx.x] = v;
+    }
+  } else {
+    for (int t = threadIdx.x; t < n2; t += BN_THREADS) {
+      float v = 0.0f;
+      for (int sl = 0; sl < ns; ++sl) v += acc[sl * n2 + t];
+      ab[t] = v;
+    }
+  }
+  __syncthreads();
+  // This workgroup has read the sums: it is counted now, and looks at what the
+  // counter returned only when it is done (the round trip hides behind the pass).
+  int ticket = 0;
+  if (threadIdx.x == 0)
+    ticket = __hip_atomic_fetch_add(reinterpret_cast<int*>(ws_), 1, __ATOMIC_RELAXED,
+                                    __HIP_MEMORY_SCOPE_AGENT);
+  __shared__ float cst[2 * 2048];
+  const float inv_n = (float)(1.0 / (double)npix);
+  for (int c = threadIdx.x; c < C; c += BN_THREADS) {
+    const float mean = ab[c] * inv_n;
+    // biased variance (tf.nn.moments); fp32: the sums are fp32
+    const float var = fmaxf(__fmaf_rn(-mean, mean, ab[C + c] * inv_n), 0.0f);
+    const float rstd = 1.0f / sqrtf(var + eps);
+    if (blockIdx.x == 0) {
+      float* mr = mean_rstd_ + (size_t)blockIdx.y * 2 * C;
+      mr[c] = mean;
+      mr[C + c] = rstd;
+    }
+    cst[c] = rstd;
+    cst[C + c] = __fmaf_rn(-mean, rstd, beta[c]);
+  }
+  __syncthreads();
+  norm_pass<BF16>(grp_in<BF16>(x, npix, C), grp_out<BF16>(y, npix, C), cst, npix, C, relu);
+  // the workgroup that was counted last clears every group's accumulators (all
+  // the others had read them when they were counted)
+  __shared__ int last;
+  if (threadIdx.x == 0) last = ticket == (int)(gridDim.x * gridDim.y) - 1;
+  __syncthreads();
+  if (last) {
+    for (unsigned g = 0; g < gridDim.y; ++g) {
+      float* a = ws_ + (size_t)g * WS_STRIDE + WS_ACC;
+      for (int t = threadIdx.x; t < ns * 2 * C; t += BN_THREADS) a[t] = 0.0f;
+    }
+    if (threadIdx.x == 0)
+      __hip_atomic_store(reinterpret_cast<int*>(ws_), 0, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 // pass 2 of the backward: dx = rstd * (dz - mean(dz) - xhat * mean(dz * xhat))
@@ -423,6 +501,24 @@ extern "C" int lsi_bn_relu_fwd(const void* x, void* y, const float* beta,
     hipLaunchKernelGGL(bn_norm_kernel<false>, grid, blk, 0, st, x, y,
                        (const float*)workspace, (long)npix, C, relu);
   }
+  return hipGetLastError() == hipSuccess ? LSI_OK : LSI_ELAUNCH;
+}
+
+extern "C" int lsi_bn_relu_norm(const void* x, void* y, const float* beta, float* workspace,
+                                float* mean_rstd, int64_t npix, int32_t C, int32_t bf16,
+                                int32_t relu, float eps, int32_t groups, lsi_stream_t stream_) {
+  if (!x || !y || !beta || !workspace || !mean_rstd) return LSI_ENULL;
+  if (!bn_shape_ok(npix, C, bf16) || !al16(x) || !al16(y) || groups < 1 || groups > 65535)
+    return LSI_EINVAL;
+  hipStream_t st = (hipStream_t)stream_;
+  const dim3 grid(bn_grid(npix, C, bf16), groups), blk(BN_THREADS);
+  const int ns = lsi_bn_stat_slots(C);
+  if (bf16)
+    hipLaunchKernelGGL(bn_norm_sums_kernel<true>, grid, blk, 0, st, x, y, beta, workspace,
+                       mean_rstd, (long)npix, C, relu, eps, ns);
+  else
+    hipLaunchKernelGGL(bn_norm_sums_kernel<false>, grid, blk, 0, st, x, y, beta, workspace,
+                       mean_rstd, (long)npix, C, relu, eps, ns);
   return hipGetLastError() == hipSuccess ? LSI_OK : LSI_ELAUNCH;
 }
 

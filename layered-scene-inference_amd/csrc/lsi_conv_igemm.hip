@@ -76,8 +76,30 @@ struct IgArgs {
   int G;              // taps per weight stage
   int PH, PW;         // staged patch: rows, pixels per row
   int ncls;
+  // Batch-norm statistics of the output, accumulated in the epilogue (st_ws !=
+  // nullptr; csrc/lsi_bn.hip's workspace): sums of y and y * y per channel and
+  // sub-batch group of the bf16-ROUNDED outputs -- what lsi_bn_relu_fwd's first
+  // pass would read the tensor back for --, fp32 device atomics into slot
+  // (workgroup index mod st_ns) of the group's accumulators, fire and forget:
+  // lsi_bn_relu_norm, the next kernel on the stream, folds and clears them.  (A
+  // last-arriver protocol inside this kernel was built first: every workgroup
+  // then waits for its adds and a counter's return before it leaves, ~4 us each
+  // -- 91 -> 117 us for the 3072 workgroups of `upcnv1`, all that the
+  // statistics pass had cost.)
+  float* st_ws;
+  int st_groups;   // sub-batch groups along N
+  int st_ns;       // accumulator slots (lsi_bn_stat_slots)
   IgClass cls[4];
 };
+
+// sum over the 16 lanes of a DPP row (every lane gets it)
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xb1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4e, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));  // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));  // row_mirror
+  return v;
+}
 
 // RW: pixel rows per wave; NCT: tiles of 16 output channels (BN = 16 NCT); G:
 // taps per weight stage -- a compile-time count, so that a stage is straight-
@@ -209,6 +231,55 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgArgs a) {
   }
   // ---- channels-last stores: lane = 4 output channels of one pixel -----------
   const int j = j0 + pxl;
+  if (a.st_ws) {
+    // ---- batch-norm statistics of this tile (see IgArgs) -----------------------
+    float ss[NCT][4], qq[NCT][4];
+#pragma unroll
+    for (int c = 0; c < NCT; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { ss[c][e] = 0.f; qq[c][e] = 0.f; }
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+      const int i = i0 + wave * RW + r;
+      if (j < k.OWt && i < k.OHt) {
+#pragma unroll
+        for (int c = 0; c < NCT; ++c)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float v = (float)(__bf16)acc[r][c][e];
+            ss[c][e] += v;
+            qq[c][e] = __builtin_fmaf(v, v, qq[c][e]);
+          }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < NCT; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { ss[c][e] = row16_sum(ss[c][e]); qq[c][e] = row16_sum(qq[c][e]); }
+    __syncthreads();  // (the last unit's fragments have been read)
+    float* const red = reinterpret_cast<float*>(ig_smem);   // [4 waves][2][BN]
+    if (pxl == 0) {
+#pragma unroll
+      for (int c = 0; c < NCT; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          red[(wave * 2 + 0) * BN + 16 * c + 4 * kg + e] = ss[c][e];
+          red[(wave * 2 + 1) * BN + 16 * c + 4 * kg + e] = qq[c][e];
+        }
+    }
+    __syncthreads();
+    const int C = a.Cout;
+    if (tid < 2 * BN) {
+      const int q = tid / BN, ch = tid - q * BN;
+      const float v = (red[(0 * 2 + q) * BN + ch] + red[(1 * 2 + q) * BN + ch]) +
+                      (red[(2 * 2 + q) * BN + ch] + red[(3 * 2 + q) * BN + ch]);
+      const int grp = n / (a.N / a.st_groups);
+      const int f = (int)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+      __hip_atomic_fetch_add(a.st_ws + (size_t)grp * LSI_BN_WS_STRIDE + LSI_BN_WS_ACC +
+                                 (f % a.st_ns) * 2 * C + q * C + co0 + ch,
+                             v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
   if (j < k.OWt) {
 #pragma unroll
     for (int r = 0; r < RW; ++r) {
@@ -486,8 +557,12 @@ extern "C" int lsi_conv2d_pack_many(const LsiPackJob* jobs_device, int32_t njobs
   return hipGetLastError() == hipSuccess ? LSI_OK : LSI_ELAUNCH;
 }
 
+struct IgStats {
+  float* ws; int groups;
+};
+
 static int ig_run(const LsiConvDesc* d, int mode, const void* src, const void* packed,
-                  void* dst, lsi_stream_t stream_) {
+                  void* dst, lsi_stream_t stream_, const IgStats* st = nullptr) {
   if (!d || !src || !packed || !dst) return LSI_ENULL;
   if (!desc_ok(d)) return LSI_EUNSUPPORTED;
   if (((uintptr_t)src & 15) || ((uintptr_t)dst & 7) || ((uintptr_t)packed & 15)) return LSI_EINVAL;
@@ -495,6 +570,12 @@ static int ig_run(const LsiConvDesc* d, int mode, const void* src, const void* p
   int8_t tap[56];
   ig_classes(d, mode, k, tap);
   k.x = (const __bf16*)src; k.wp = (const __bf16*)packed; k.out = (__bf16*)dst;
+  if (st) {
+    if (!st->ws) return LSI_ENULL;
+    // (the accumulators of a group are 2 x 2048 floats; whole images per group)
+    if (st->groups < 1 || k.N % st->groups || k.Cout > 2048) return LSI_EINVAL;
+    k.st_ws = st->ws; k.st_groups = st->groups; k.st_ns = lsi_bn_stat_slots(k.Cout);
+  }
   return ig_launch(k, (hipStream_t)stream_);
 }
 
@@ -506,4 +587,18 @@ extern "C" int lsi_conv2d_fwd(const LsiConvDesc* d, const void* x, const void* p
 extern "C" int lsi_conv2d_bwd_data(const LsiConvDesc* d, const void* gy, const void* packed,
                                    void* gx, lsi_stream_t stream) {
   return ig_run(d, 1, gy, packed, gx, stream);
+}
+
+extern "C" int lsi_conv2d_fwd_bnstats(const LsiConvDesc* d, const void* x, const void* packed,
+                                      void* out, float* bn_workspace, int32_t groups,
+                                      lsi_stream_t stream) {
+  const IgStats st = {bn_workspace, groups};
+  return ig_run(d, 0, x, packed, out, stream, &st);
+}
+
+extern "C" int lsi_conv2d_bwd_data_bnstats(const LsiConvDesc* d, const void* gy,
+                                           const void* packed, void* gx, float* bn_workspace,
+                                           int32_t groups, lsi_stream_t stream) {
+  const IgStats st = {bn_workspace, groups};
+  return ig_run(d, 1, gy, packed, gx, stream, &st);
 }

@@ -80,3 +80,22 @@ int lsi_sweep_launch(const SplatArgs& a, const float2* range, hipStream_t stream
 // kernel) has not been granted `bytes` yet: an eager caller launches the same
 // kernel with the same plan thousands of times (lsi_splat.hip).
 int lsi_ensure_dynamic_lds(const void* fn, size_t bytes);
+
+// Batch-norm workspace layout per group, in floats (lsi_bn.hip; the convolution
+// kernels that accumulate the statistics in their epilogue write the same
+// places): [0] arrival counter (int), [ACC, ACC + 4096) the accumulators -- both
+// zero between launches --, from CONST the 2 C constants of the second pass and
+// (backward) the group's C sums of dz.
+#define LSI_BN_WS_ACC 16
+#define LSI_BN_WS_CONST (16 + 4096)
+#define LSI_BN_WS_STRIDE (16 + 4096 + 3 * 2048)
+// Statistics left by a convolution's epilogue (lsi_conv2d_*_bnstats): plain sums
+// of y and y * y in `lsi_bn_stat_slots(C)` copies of the accumulators (slot s of
+// a group: ACC + s * 2 C; thousands of workgroups adding to the same two cache
+// lines would take ~8 ns each, one after the other), folded, turned into the
+// constants and cleared by lsi_bn_relu_norm.
+static inline int lsi_bn_stat_slots(int C) {
+  int ns = 1;
+  while (ns < 32 && 2 * ns * 2 * C <= 4096) ns *= 2;
+  return ns;
+}

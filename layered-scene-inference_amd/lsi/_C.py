@@ -119,11 +119,14 @@ SIGNATURES = {
     'lsi_conv2d_pack_many': (ctypes.c_int, [_VP, _I32, _I32, _VP]),
     'lsi_conv2d_fwd': (ctypes.c_int, [_CP] + [_VP] * 4),
     'lsi_conv2d_bwd_data': (ctypes.c_int, [_CP] + [_VP] * 4),
+    'lsi_conv2d_fwd_bnstats': (ctypes.c_int, [_CP] + [_VP] * 4 + [_I32, _VP]),
+    'lsi_conv2d_bwd_data_bnstats': (ctypes.c_int, [_CP] + [_VP] * 4 + [_I32, _VP]),
     'lsi_conv2d_wgrad_workspace_bytes': (_SZ, [_CP]),
     'lsi_conv2d_wgrad': (ctypes.c_int, [_CP] + [_VP] * 4 + [_SZ, _VP]),
     'lsi_bn_workspace_floats': (_SZ, [_I64, _I32, _I32, _I32]),
     'lsi_bn_relu_fwd': (ctypes.c_int, [_VP] * 5 + [_I64, _I32, _I32, _I32, _F32, _I32, _VP]),
     'lsi_bn_relu_bwd': (ctypes.c_int, [_VP] * 7 + [_I64, _I32, _I32, _I32, _I32, _VP]),
+    'lsi_bn_relu_norm': (ctypes.c_int, [_VP] * 5 + [_I64, _I32, _I32, _I32, _F32, _I32, _VP]),
 }
 
 _lib = None

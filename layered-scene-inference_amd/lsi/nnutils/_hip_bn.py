@@ -72,7 +72,9 @@ def supported(x, groups=1):
 class _BnRelu(torch.autograd.Function):
 
   @staticmethod
-  def forward(ctx, x, beta, eps, relu, groups):
+  def forward(ctx, x, beta, eps, relu, groups, prestat=False):
+    """prestat: a producer has left the sums of x and x * x in the workspace
+    (lsi_conv2d_*_bnstats on this stream, just before this call): one pass."""
     if not x.is_cuda:
       raise RuntimeError('fused batch norm needs a tensor on a ROCm GPU')
     dev = x.device
@@ -83,16 +85,21 @@ class _BnRelu(torch.autograd.Function):
     stream = _C.stream_ptr(dev)
     ws = _workspace(dev, stream, npix, c, bf16, groups)
     y = torch.empty_like(x)               # (x is channels-last: supported())
+    beta_f = beta_f32(beta)
     mean_rstd = torch.empty((groups, 2, c), dtype=torch.float32, device=dev)
-    beta_f = beta.detach()
-    if beta_f.dtype != torch.float32 or not beta_f.is_contiguous():
-      beta_f = beta_f.float().contiguous()
-    # (N-major storage: the groups are consecutive blocks of npix * C values)
-    rc = lib.lsi_bn_relu_fwd(x.data_ptr(), y.data_ptr(), beta_f.data_ptr(), ws.data_ptr(),
-                             mean_rstd.data_ptr(), npix, c, bf16, int(relu),
-                             float(eps), groups, stream)
-    if rc:
-      _C.check(rc, 'lsi_bn_relu_fwd')
+    if prestat:
+      rc = lib.lsi_bn_relu_norm(x.data_ptr(), y.data_ptr(), beta_f.data_ptr(), ws.data_ptr(),
+                                mean_rstd.data_ptr(), npix, c, bf16, int(relu), float(eps),
+                                groups, stream)
+      if rc:
+        _C.check(rc, 'lsi_bn_relu_norm')
+    else:
+      # (N-major storage: the groups are consecutive blocks of npix * C values)
+      rc = lib.lsi_bn_relu_fwd(x.data_ptr(), y.data_ptr(), beta_f.data_ptr(), ws.data_ptr(),
+                               mean_rstd.data_ptr(), npix, c, bf16, int(relu),
+                               float(eps), groups, stream)
+      if rc:
+        _C.check(rc, 'lsi_bn_relu_fwd')
     ctx.save_for_backward(x, beta_f, mean_rstd)
     ctx.relu = int(relu)
     ctx.groups = groups
@@ -120,11 +127,32 @@ class _BnRelu(torch.autograd.Function):
                              npix, c, bf16, ctx.relu, groups, stream)
     if rc:
       _C.check(rc, 'lsi_bn_relu_bwd')
-    return dx, dbeta, None, None, None
+    return dx, dbeta, None, None, None, None
 
 
-def batch_norm_relu(x, beta, eps=1e-3, relu=True, groups=1):
+def beta_f32(beta):
+  b = beta.detach()
+  if b.dtype != torch.float32 or not b.is_contiguous():
+    b = b.float().contiguous()
+  return b
+
+
+def stats_workspace(x_like_shape, dev, bf16, groups):
+  """The workspace a producer of statistics (lsi_conv2d_*_bnstats) has to write
+  so that batch_norm_relu(..., prestat=) finds them: the one _BnRelu.forward
+  will pick for a tensor of this shape on the current stream."""
+  n, c, h, w = x_like_shape
+  return _workspace(dev, _C.stream_ptr(dev), (n // groups) * h * w, c, bf16, groups)
+
+
+def channels_ok(c, bf16=True):
+  nv = 8 if bf16 else 4
+  lpp = c // nv
+  return c % nv == 0 and c <= 2048 and lpp <= 256 and lpp & (lpp - 1) == 0
+
+
+def batch_norm_relu(x, beta, eps=1e-3, relu=True, groups=1, prestat=False):
   """relu(batch_norm(x) + beta) with batch statistics (slim.batch_norm,
   scale=False) for a channels-last N x C x H x W tensor; same dtype out.
   groups > 1: N is that many sub-batches, each normalised on its own."""
-  return _BnRelu.apply(x, beta, eps, relu, groups)
+  return _BnRelu.apply(x, beta, eps, relu, groups, prestat)

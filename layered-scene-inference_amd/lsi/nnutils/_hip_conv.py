@@ -358,10 +358,22 @@ def repack_all(device=None):
   return n
 
 
-def _igemm(entry, desc, src, weight, out):
+def _igemm(entry, desc, src, weight, out, bn_groups=0):
+  """bn_groups > 0: the kernel also adds the batch-norm sums of `out` to the
+  workspace (lsi_conv2d_*_bnstats) for the lsi_bn_relu_norm that has to follow."""
   mode = 1 if entry == 'lsi_conv2d_bwd_data' else 0
   packed = _packed(desc, mode, weight)
   lib = _C.lib()
+  if bn_groups:
+    from lsi.nnutils import _hip_bn  # pylint: disable=g-import-not-at-top
+    dev = src.device
+    ws = _hip_bn.stats_workspace(tuple(out.shape), dev, 1, bn_groups)
+    fn = lib.lsi_conv2d_bwd_data_bnstats if mode else lib.lsi_conv2d_fwd_bnstats
+    rc = fn(ctypes.byref(desc), src.data_ptr(), packed.data_ptr(), out.data_ptr(),
+            ws.data_ptr(), int(bn_groups), _C.stream_ptr(dev))
+    if rc:
+      _C.check(rc, entry + '_bnstats')
+    return out
   fn = lib.lsi_conv2d_bwd_data if mode else lib.lsi_conv2d_fwd
   rc = fn(ctypes.byref(desc), src.data_ptr(), packed.data_ptr(), out.data_ptr(),
           _C.stream_ptr(src.device))
@@ -415,13 +427,14 @@ class _Conv2dIgemm(torch.autograd.Function):
   pixels) and on aten (MIOpen) elsewhere."""
 
   @staticmethod
-  def forward(ctx, x, weight, stride, pad_t, pad_l, oh, ow):
+  def forward(ctx, x, weight, stride, pad_t, pad_l, oh, ow, bn_groups=0):
     n, cin, h, w = x.shape
     cout, _, kh, kw = weight.shape
     desc = _conv_desc(n, h, w, cin, oh, ow, cout, kh, kw, stride, pad_t, pad_l)
     ctx.desc = desc
     ctx.save_for_backward(x, weight)
-    return _igemm('lsi_conv2d_fwd', desc, x, weight, _empty_cl(n, cout, oh, ow, x.device))
+    return _igemm('lsi_conv2d_fwd', desc, x, weight, _empty_cl(n, cout, oh, ow, x.device),
+                  bn_groups)
 
   @staticmethod
   def backward(ctx, g):
@@ -451,11 +464,14 @@ class _Conv2dIgemm(torch.autograd.Function):
         gw = torch.ops.aten.convolution_backward(
             g, xp, weight.to(g.dtype), None, [d.stride, d.stride], pad, [1, 1], False,
             [0, 0], 1, [False, True, False])[1].to(weight.dtype)
-    return gx, gw, None, None, None, None, None
+    return gx, gw, None, None, None, None, None, None
 
 
-def conv2d(x, weight, stride, pad_t, pad_l, oh, ow):
-  return _Conv2dIgemm.apply(x, weight, stride, pad_t, pad_l, oh, ow)
+def conv2d(x, weight, stride, pad_t, pad_l, oh, ow, bn_groups=0):
+  """bn_groups > 0: the batch-norm sums of the output (that many sub-batch groups)
+  are left for _hip_bn.batch_norm_relu(out, ..., groups, prestat=True), which has
+  to be the next batch-norm call on this stream."""
+  return _Conv2dIgemm.apply(x, weight, stride, pad_t, pad_l, oh, ow, bn_groups)
 
 
 class _ConvTranspose2dIgemm(torch.autograd.Function):
@@ -466,7 +482,7 @@ class _ConvTranspose2dIgemm(torch.autograd.Function):
   data gradient is that forward convolution (lsi_conv2d_fwd)."""
 
   @staticmethod
-  def forward(ctx, x, weight, stride, pad):
+  def forward(ctx, x, weight, stride, pad, bn_groups=0):
     n, cin_t, h, w = x.shape
     _, cout_t, kh, kw = weight.shape
     desc = _conv_desc(n, stride * h, stride * w, cout_t, h, w, cin_t, kh, kw, stride, pad, pad)
@@ -474,7 +490,7 @@ class _ConvTranspose2dIgemm(torch.autograd.Function):
     ctx.save_for_backward(x, weight)
     ctx.args = (stride, pad)
     return _igemm('lsi_conv2d_bwd_data', desc, x, weight,
-                  _empty_cl(n, cout_t, stride * h, stride * w, x.device))
+                  _empty_cl(n, cout_t, stride * h, stride * w, x.device), bn_groups)
 
   @staticmethod
   def backward(ctx, g):
@@ -497,11 +513,11 @@ class _ConvTranspose2dIgemm(torch.autograd.Function):
         gw = torch.ops.aten.convolution_backward(
             g, x, weight.to(g.dtype), None, [stride, stride], [pad, pad], [1, 1], True,
             [0, 0], 1, [False, True, False])[1].to(weight.dtype)
-    return gx, gw, None, None
+    return gx, gw, None, None, None
 
 
-def conv_transpose2d(x, weight, stride=2, pad=1):
-  return _ConvTranspose2dIgemm.apply(x, weight, stride, pad)
+def conv_transpose2d(x, weight, stride=2, pad=1, bn_groups=0):
+  return _ConvTranspose2dIgemm.apply(x, weight, stride, pad, bn_groups)
 
 
 def convt_supported(x, cin, cout, k, stride):

@@ -103,14 +103,34 @@ def _per_group(fn, x):
   return torch.cat([fn(c) for c in x.chunk(g, dim=0)], dim=0)
 
 
-def _bn_relu(bn, x):
+def _bn_relu(bn, x, prestat=False):
   """relu(bn(x)): two HIP passes forward, two backward (statistics, normalise +
-  ReLU + store in x's dtype) where the layout allows, else torch / MIOpen."""
+  ReLU + store in x's dtype) where the layout allows, else torch / MIOpen.
+  prestat: the convolution kernel has left the statistics (see _stats_bn): only
+  the second pass runs."""
   if FUSED_BN and bn.is_training and x.is_cuda:
     from lsi.nnutils import _hip_bn  # pylint: disable=g-import-not-at-top
     if _hip_bn.supported(x, _BN_GROUPS[0]):
-      return _hip_bn.batch_norm_relu(x, bn.beta, bn.eps, True, _BN_GROUPS[0])
+      return _hip_bn.batch_norm_relu(x, bn.beta, bn.eps, True, _BN_GROUPS[0], prestat)
+  assert not prestat
   return F.relu(bn(x))
+
+
+CONV_BN_STATS = os.environ.get('LSI_CONV_BN_STATS', '1') != '0'
+
+
+def _stats_bn(bn, activation, n, cout):
+  """The sub-batch groups when the implicit-GEMM kernel may accumulate the batch
+  statistics of its output for the batch norm + ReLU behind it (training
+  statistics, the fused batch-norm kernels, whole images per group), else 0."""
+  if not (CONV_BN_STATS and FUSED_BN and bn is not None and bn.is_training and
+          activation == 'relu'):
+    return 0
+  from lsi.nnutils import _hip_bn  # pylint: disable=g-import-not-at-top
+  g = _BN_GROUPS[0]
+  if g < 1 or n % g or not _hip_bn.channels_ok(cout):
+    return 0
+  return g
 
 
 class SlimBatchNorm(nn.Module):
@@ -191,8 +211,11 @@ class SlimConv2d(nn.Module):
         # data gradient; weight gradient on lsi_conv3x3_wgrad or the library)
         ph = _same_pad(x.shape[2], self.k, self.stride)
         pw = _same_pad(x.shape[3], self.k, self.stride)
+        st = _stats_bn(self.bn, self.activation, x.shape[0], cout)
         x = _hip_conv.conv2d(x, self.conv.weight, self.stride, ph[0], pw[0],
-                             -(-x.shape[2] // self.stride), -(-x.shape[3] // self.stride))
+                             -(-x.shape[2] // self.stride), -(-x.shape[3] // self.stride), st)
+        if st:
+          return _bn_relu(self.bn, x, True)
         return self._bn_act(x)
       if (self.bn is not None and torch.is_grad_enabled() and
           self.conv.weight.requires_grad and
@@ -248,7 +271,9 @@ class SlimConvTranspose2d(nn.Module):
       # four parity classes of 2 x 2 taps on the implicit-GEMM kernel
       if (_hip_conv.convt_supported(x, cin, cout, 4, 2) and
           x.shape[0] * x.shape[2] * x.shape[3] >= IGEMM_MIN_PIXELS):
-        return _bn_relu(self.bn, _hip_conv.conv_transpose2d(x, self.conv.weight))
+        st = _stats_bn(self.bn, 'relu', x.shape[0], cout)
+        y = _hip_conv.conv_transpose2d(x, self.conv.weight, 2, 1, st)
+        return _bn_relu(self.bn, y, bool(st))
     return _bn_relu(self.bn, self.conv(x))
 
 

@@ -325,3 +325,89 @@ def test_repack_all_refreshes_every_layer_with_one_launch(dev):
   assert packs == dict((k, e.buf.data_ptr()) for k, e in _hip_conv._PACKED.items())
   assert float((y1 + 2 * y0).abs().max()) <= float(y1.abs().max()) * 2.0 ** -6
   assert float((z1 - 3 * z0).abs().max()) <= float(z1.abs().max()) * 2.0 ** -6
+
+
+# (n, cin, h, w, cout, k, stride, groups): odd sizes (partial tiles must not
+# count), stride 2 with TF's asymmetric padding, 7 x 7, bottleneck maps
+_BNSTAT_CASES = [(4, 32, 37, 53, 64, 3, 1, 2), (2, 64, 40, 66, 32, 5, 2, 1),
+                 (8, 32, 128, 384, 32, 7, 1, 2), (8, 512, 4, 12, 512, 3, 1, 2),
+                 (6, 128, 17, 9, 256, 3, 2, 3)]
+
+
+@pytest.mark.parametrize('case', _BNSTAT_CASES)
+def test_batch_norm_statistics_from_the_convolution_epilogue(case, dev):
+  """lsi_conv2d_fwd_bnstats + lsi_bn_relu_norm against lsi_conv2d_fwd +
+  lsi_bn_relu_fwd (whose first pass reads the tensor back): the same bf16
+  activations out, mean / rstd to fp32 summation noise -- and against fp64
+  moments of the convolution's output; gradients through the pair equal."""
+  from lsi.nnutils import _hip_bn, _hip_conv, nets
+  n, cin, h, w, cout, k, s, groups = case
+  g = torch.Generator().manual_seed(11)
+  x = torch.randn((n, cin, h, w), generator=g).to(dev).to(torch.bfloat16)
+  x = x.contiguous(memory_format=torch.channels_last).requires_grad_(True)
+  wt = (torch.randn((cout, cin, k, k), generator=g) * (0.5 / k)).to(dev).requires_grad_(True)
+  beta = (torch.randn((cout,), generator=g) * 0.3).to(dev).requires_grad_(True)
+  ph, pw = nets._same_pad(h, k, s), nets._same_pad(w, k, s)
+  oh, ow = -(-h // s), -(-w // s)
+  # separate passes
+  y0 = _hip_conv.conv2d(x, wt, s, ph[0], pw[0], oh, ow)
+  z0 = _hip_bn.batch_norm_relu(y0, beta, 1e-3, True, groups)
+  gz = torch.randn(z0.shape, generator=g).to(dev).to(torch.bfloat16)
+  gz = gz.contiguous(memory_format=torch.channels_last)
+  gx0, gw0, gb0 = torch.autograd.grad(z0, (x, wt, beta), gz)
+  # statistics from the epilogue
+  y1 = _hip_conv.conv2d(x, wt, s, ph[0], pw[0], oh, ow, groups)
+  assert torch.equal(y1, y0)
+  z1 = _hip_bn.batch_norm_relu(y1, beta, 1e-3, True, groups, True)
+  mr = z1.grad_fn.saved_tensors[2].clone()
+  gx1, gw1, gb1 = torch.autograd.grad(z1, (x, wt, beta), gz)
+  yf = y0.detach().double().view(groups, n // groups, cout, oh, ow)
+  mean = yf.mean(dim=(1, 3, 4))
+  var = yf.var(dim=(1, 3, 4), unbiased=False)
+  np.testing.assert_allclose(mr[:, 0].double().cpu().numpy(), mean.cpu().numpy(),
+                             rtol=1e-5, atol=1e-5 * float(yf.abs().max()))
+  np.testing.assert_allclose(mr[:, 1].double().cpu().numpy(),
+                             torch.rsqrt(var + 1e-3).cpu().numpy(), rtol=2e-5)
+  # activations: the two sets of constants differ in their last bits, so a value
+  # may round to the neighbouring bf16 now and then
+  dz = (z1.detach().float() - z0.detach().float()).abs()
+  assert float((dz - z0.detach().float().abs() * 2.0 ** -7).max()) <= 1e-6, float(dz.max())
+  assert float((dz > 0).float().mean()) < 0.02
+  for a, b in ((gx1, gx0), (gw1, gw0), (gb1, gb0)):
+    scale = float(b.float().abs().max())
+    assert float((a.float() - b.float()).abs().max()) <= 2e-2 * scale
+    assert float((a.float() - b.float()).abs().mean()) <= 2e-4 * scale
+  # a second pair finds accumulators and counter zero again
+  y2 = _hip_conv.conv2d(x, wt, s, ph[0], pw[0], oh, ow, groups)
+  z2 = _hip_bn.batch_norm_relu(y2, beta, 1e-3, True, groups, True)
+  # (fp32 atomics: the order of the sums differs from call to call)
+  same = lambda a, b: float((a.detach().float() - b.detach().float()).abs().max()) <= \
+      2.0 ** -7 * float(b.detach().float().abs().max())
+  assert same(z2, z1) and float((z2 != z1).float().mean()) < 0.02
+  # ... and so does the two-pass kernel that shares the workspace
+  z3 = _hip_bn.batch_norm_relu(y0, beta, 1e-3, True, groups)
+  assert same(z3, z0) and float((z3 != z0).float().mean()) < 0.02
+
+
+def test_transposed_convolution_leaves_the_statistics_too(dev):
+  from lsi.nnutils import _hip_bn, _hip_conv
+  g = torch.Generator().manual_seed(12)
+  n, cin, h, w, cout, groups = 4, 64, 9, 13, 32, 2
+  x = torch.randn((n, cin, h, w), generator=g).to(dev).to(torch.bfloat16)
+  x = x.contiguous(memory_format=torch.channels_last)
+  wt = (torch.randn((cin, cout, 4, 4), generator=g) * 0.1).to(dev)
+  beta = torch.zeros((cout,), device=dev)
+  y0 = _hip_conv.conv_transpose2d(x, wt)
+  beta.requires_grad_(True)
+  y1 = _hip_conv.conv_transpose2d(x, wt, 2, 1, groups)
+  assert torch.equal(y1, y0)
+  z1 = _hip_bn.batch_norm_relu(y1, beta, 1e-3, True, groups, True)
+  mr = z1.grad_fn.saved_tensors[2]
+  yf = y0.double().view(groups, n // groups, cout, 2 * h, 2 * w)
+  np.testing.assert_allclose(mr[:, 0].double().cpu().numpy(), yf.mean(dim=(1, 3, 4)).cpu().numpy(),
+                             rtol=1e-5, atol=1e-5 * float(yf.abs().max()))
+  np.testing.assert_allclose(
+      mr[:, 1].double().cpu().numpy(),
+      torch.rsqrt(yf.var(dim=(1, 3, 4), unbiased=False) + 1e-3).cpu().numpy(), rtol=2e-5)
+  z0 = _hip_bn.batch_norm_relu(y0, beta, 1e-3, True, groups)
+  assert float((z1.detach().float() - z0.detach().float()).abs().max()) <= 2.0 ** -7 * float(z0.detach().float().abs().max())
