@@ -601,6 +601,25 @@ int lsi_conv2d_bwd_data_bnstats(const LsiConvDesc* d, const void* gy, const void
                                 void* gx, float* bn_workspace, int32_t groups,
                                 lsi_stream_t stream);
 /*
+ * A convolution behind a skip connection (tf.concat([a, b], axis=3) in front of
+ * slim.conv2d: nets.py:104-106 `upcnv{n}b`, :300-345 `icnv{n}`): the input as
+ * TWO tensors -- channels [0, c1) of the descriptor's Cin from x1 (N x H x W x
+ * c1), the rest from x2 (N x H x W x (Cin - c1)) -- so that the concatenated
+ * tensor is never written, and its data gradient into two tensors likewise.
+ * c1 a multiple of 32 (forward, weight gradient) / of 64 when Cin is one (data
+ * gradient: the kernel's block of output channels), else LSI_EINVAL.
+ * lsi_conv2d_fwd_cat: bn_workspace != NULL adds the batch-norm sums as
+ * lsi_conv2d_fwd_bnstats does (groups is ignored otherwise).
+ */
+int lsi_conv2d_fwd_cat(const LsiConvDesc* d, const void* x1, const void* x2, int32_t c1,
+                       const void* packed, void* out, float* bn_workspace, int32_t groups,
+                       lsi_stream_t stream);
+int lsi_conv2d_bwd_data_cat(const LsiConvDesc* d, const void* gy, const void* packed,
+                            void* gx1, void* gx2, int32_t c1, lsi_stream_t stream);
+int lsi_conv2d_wgrad_cat(const LsiConvDesc* d, const void* x1, const void* x2, int32_t c1,
+                         const void* gy, float* g_weight, void* workspace,
+                         size_t workspace_bytes, lsi_stream_t stream);
+/*
  * Weight gradient of the convolution LsiConvDesc describes (TF autodiff of
  * slim.conv2d, reference nets.py:29-114, 244-348):
  *   g_weight[co][ci][ky][kx] = sum over n, oy, ox of

@@ -66,7 +66,19 @@ struct IgClass {
   signed char tdy[IG_MAXTAPS + 3], tdx[IG_MAXTAPS + 3];
 };
 struct IgArgs {
-  const __bf16* x;    // N x H x W x Cin
+  const __bf16* x;    // N x H x W x Cin (C1 channels of it when x2 != nullptr)
+  // The input as TWO tensors (the skip connections, nets.py:104-106, 300-345:
+  // tf.concat([upcnv, skip], axis=3) in front of a convolution): channels
+  // [0, C1) come from x (N x H x W x C1), channels [C1, Cin) from x2
+  // (N x H x W x (Cin - C1)) -- the concatenated tensor is never written.
+  // C1 a multiple of 32 (a chunk of 32 input channels is one tensor's).
+  const __bf16* x2;
+  int C1;
+  // ... and its data gradient as two tensors: output channels [0, O1) go to out
+  // (pitch O1), [O1, Cout) to out2 (pitch Cout - O1); O1 a multiple of the
+  // workgroup's block of output channels.
+  __bf16* out2;
+  int O1;
   const __bf16* wp;   // [taps of all classes][Cout][Cin]
   __bf16* out;        // N x OHF x OWF x Cout
   int N, H, W, Cin, Cout;
@@ -122,8 +134,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgArgs a) {
   unsigned char* const wts = ig_smem + (size_t)npix * IG_PIX;
 
   // The patch pieces this thread stages (16 bytes each: pixel, quarter of its
-  // 32 channels): element offsets into x (without the chunk's channel offset),
-  // -1 outside the input.  The same for every chunk.
+  // 32 channels): pixel index into the input, -1 outside it.  The same for
+  // every chunk.
   constexpr int MAXP = 12;  // (<= 768 staged pixels)
   int goff[MAXP];
   const int npiece = npix * 4;
@@ -132,11 +144,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgArgs a) {
 #pragma unroll
     for (int k = 0; k < MAXP; ++k) {
       const int idx = tid + 256 * k;
-      const int pix = idx >> 2, q = idx & 3;
+      const int pix = idx >> 2;
       const int py = pix / PW, px = pix - py * PW;
       const int iy = iy0 + py, ix = ix0 + px;
       const bool ok = idx < npiece && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-      goff[k] = ok ? (((n * a.H + iy) * a.W + ix) * a.Cin + 8 * q) : -1;
+      goff[k] = ok ? ((n * a.H + iy) * a.W + ix) : -1;   // (pixel index)
     }
   }
   f32x4 acc[RW][NCT];
@@ -167,11 +179,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgArgs a) {
     const int ch = u / ngrp, gi = u - ch * ngrp;
     const int c0 = ch * 32, t0 = gi * G;
     if (gi == 0) {
+      // (the chunk's tensor: its channel count is the pixel pitch)
+      const bool second = c0 >= a.C1;
+      const __bf16* const xb = second ? a.x2 + (c0 - a.C1) : a.x + c0;
+      const int pitch = second ? a.Cin - a.C1 : a.C1;
 #pragma unroll
       for (int kk = 0; kk < MAXP; ++kk) {
         pv[kk] = zero4;
         if (tid + 256 * kk < npiece && goff[kk] >= 0)
-          pv[kk] = *reinterpret_cast<const u32x4*>(a.x + (size_t)goff[kk] + c0);
+          pv[kk] = *reinterpret_cast<const u32x4*>(xb + (size_t)goff[kk] * pitch +
+                                                   8 * ((tid + 256 * kk) & 3));
       }
     }
     const __bf16* const wsrc = wp + ((size_t)t0 * a.Cout + co0) * a.Cin + c0;
@@ -285,9 +302,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgArgs a) {
     for (int r = 0; r < RW; ++r) {
       const int i = i0 + wave * RW + r;
       if (i < k.OHt) {
-        __bf16* const o = a.out +
-            (((size_t)n * a.OHF + (size_t)(i * a.os + k.ooy)) * a.OWF + (j * a.os + k.oox)) * a.Cout +
-            co0 + 4 * kg;
+        const bool o_second = co0 >= a.O1;
+        __bf16* const o = (o_second ? a.out2 + (co0 - a.O1) : a.out + co0) +
+            (((size_t)n * a.OHF + (size_t)(i * a.os + k.ooy)) * a.OWF + (j * a.os + k.oox)) *
+                (o_second ? a.Cout - a.O1 : a.O1) + 4 * kg;
 #pragma unroll
         for (int c = 0; c < NCT; ++c) {
           bf16x4 v;
@@ -562,7 +580,8 @@ struct IgStats {
 };
 
 static int ig_run(const LsiConvDesc* d, int mode, const void* src, const void* packed,
-                  void* dst, lsi_stream_t stream_, const IgStats* st = nullptr) {
+                  void* dst, lsi_stream_t stream_, const IgStats* st = nullptr,
+                  const void* src2 = nullptr, int c1 = 0, void* dst2 = nullptr) {
   if (!d || !src || !packed || !dst) return LSI_ENULL;
   if (!desc_ok(d)) return LSI_EUNSUPPORTED;
   if (((uintptr_t)src & 15) || ((uintptr_t)dst & 7) || ((uintptr_t)packed & 15)) return LSI_EINVAL;
@@ -570,6 +589,21 @@ static int ig_run(const LsiConvDesc* d, int mode, const void* src, const void* p
   int8_t tap[56];
   ig_classes(d, mode, k, tap);
   k.x = (const __bf16*)src; k.wp = (const __bf16*)packed; k.out = (__bf16*)dst;
+  k.C1 = k.Cin;
+  k.O1 = k.Cout;
+  if (dst2) {   // the data gradient as two tensors
+    const int bn = (k.Cout % 64 == 0) ? 64 : 32;
+    if (mode != 1 || ((uintptr_t)dst2 & 7)) return LSI_EINVAL;
+    if (c1 <= 0 || c1 >= k.Cout || c1 % bn) return LSI_EINVAL;
+    k.out2 = (__bf16*)dst2;
+    k.O1 = c1;
+  }
+  if (src2) {   // the input as two tensors (forward only)
+    if (mode != 0 || ((uintptr_t)src2 & 15)) return LSI_EINVAL;
+    if (c1 <= 0 || c1 >= k.Cin || c1 % 32) return LSI_EINVAL;
+    k.x2 = (const __bf16*)src2;
+    k.C1 = c1;
+  }
   if (st) {
     if (!st->ws) return LSI_ENULL;
     // (the accumulators of a group are 2 x 2048 floats; whole images per group)
@@ -594,6 +628,20 @@ extern "C" int lsi_conv2d_fwd_bnstats(const LsiConvDesc* d, const void* x, const
                                       lsi_stream_t stream) {
   const IgStats st = {bn_workspace, groups};
   return ig_run(d, 0, x, packed, out, stream, &st);
+}
+
+extern "C" int lsi_conv2d_fwd_cat(const LsiConvDesc* d, const void* x1, const void* x2,
+                                  int32_t c1, const void* packed, void* out,
+                                  float* bn_workspace, int32_t groups, lsi_stream_t stream) {
+  if (!x2) return LSI_ENULL;
+  const IgStats st = {bn_workspace, groups};
+  return ig_run(d, 0, x1, packed, out, stream, bn_workspace ? &st : nullptr, x2, c1);
+}
+
+extern "C" int lsi_conv2d_bwd_data_cat(const LsiConvDesc* d, const void* gy, const void* packed,
+                                       void* gx1, void* gx2, int32_t c1, lsi_stream_t stream) {
+  if (!gx2) return LSI_ENULL;
+  return ig_run(d, 1, gy, packed, gx1, stream, nullptr, nullptr, c1, gx2);
 }
 
 extern "C" int lsi_conv2d_bwd_data_bnstats(const LsiConvDesc* d, const void* gy,

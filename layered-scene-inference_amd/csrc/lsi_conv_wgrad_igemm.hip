@@ -51,7 +51,9 @@ constexpr size_t GW_LDS_CAP = 80 * 1024;
 constexpr size_t GW_PART_CAP = 96u << 20;  // partial sums: at most this many bytes
 
 struct GwArgs {
-  const __bf16* x;    // N x H x W x Cin
+  const __bf16* x2;   // the input as two tensors (lsi_conv_igemm.hip: IgArgs::x2): channels [C1, Cin)
+  int C1;
+  const __bf16* x;    // N x H x W x Cin (x C1 with x2)
   const __bf16* gy;   // N x OH x OW x Cout
   float* part;        // [pixel blocks][khw][Cout][Cin]
   int N, H, W, Cin, OH, OW, Cout;
@@ -103,6 +105,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_igemm_kernel(GwArgs a) {
   constexpr int MAXP = 12;
   int prow[MAXP], goff[MAXP];
   const int npiece = npix * 4;
+  // (this workgroup's 32 input channels: one tensor's; its channel count is the pitch)
+  const bool second = c0 >= a.C1;
+  const __bf16* const xsrc = second ? a.x2 + (c0 - a.C1) : a.x + c0;
+  const int xpitch = second ? a.Cin - a.C1 : a.C1;
   {
     const int ix0 = j0 * S + a.dx0;
 #pragma unroll
@@ -113,7 +119,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_igemm_kernel(GwArgs a) {
       const int ix = ix0 + px;
       const bool ok = idx < npiece && ix >= 0 && ix < a.W;
       prow[k] = ok ? py : -1;
-      goff[k] = ((n * a.H + py) * a.W + ix) * a.Cin + c0 + 8 * q;
+      goff[k] = ((n * a.H + py) * a.W + ix) * xpitch + 8 * q;
     }
   }
   f32x4 acc[PB][NCT];
@@ -139,14 +145,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_igemm_kernel(GwArgs a) {
     // ---- input patch: rows i0 * S + dy0 + py ---------------------------------
     {
       const int iy0 = i0 * S + a.dy0;
-      const int shift = (iy0 + (ni - n) * a.H) * a.W * a.Cin;
+      const int shift = (iy0 + (ni - n) * a.H) * a.W * xpitch;
       u32x4 pv[MAXP];
 #pragma unroll
       for (int k = 0; k < MAXP; ++k) {
         pv[k] = zero4;
         const int iy = iy0 + prow[k];
         if (prow[k] >= 0 && iy >= 0 && iy < a.H)
-          pv[k] = *reinterpret_cast<const u32x4*>(a.x + (size_t)(goff[k] + shift));
+          pv[k] = *reinterpret_cast<const u32x4*>(xsrc + (size_t)(goff[k] + shift));
       }
 #pragma unroll
       for (int k = 0; k < MAXP; ++k) {
@@ -369,9 +375,28 @@ extern "C" size_t lsi_conv2d_wgrad_workspace_bytes(const LsiConvDesc* d) {
   return (size_t)nblk * d->Cout * d->Cin * d->KH * d->KW * sizeof(float);
 }
 
+static int gw_run(const LsiConvDesc* d, const void* x, const void* x2, int c1, const void* gy,
+                  float* g_weight, void* workspace, size_t workspace_bytes,
+                  lsi_stream_t stream_);
+
 extern "C" int lsi_conv2d_wgrad(const LsiConvDesc* d, const void* x, const void* gy,
                                 float* g_weight, void* workspace, size_t workspace_bytes,
                                 lsi_stream_t stream_) {
+  return gw_run(d, x, nullptr, 0, gy, g_weight, workspace, workspace_bytes, stream_);
+}
+
+extern "C" int lsi_conv2d_wgrad_cat(const LsiConvDesc* d, const void* x1, const void* x2,
+                                    int32_t c1, const void* gy, float* g_weight,
+                                    void* workspace, size_t workspace_bytes,
+                                    lsi_stream_t stream_) {
+  if (!x2) return LSI_ENULL;
+  if (!d || c1 <= 0 || c1 >= d->Cin || c1 % 32 || ((uintptr_t)x2 & 15)) return LSI_EINVAL;
+  return gw_run(d, x1, x2, c1, gy, g_weight, workspace, workspace_bytes, stream_);
+}
+
+static int gw_run(const LsiConvDesc* d, const void* x, const void* x2, int c1, const void* gy,
+                  float* g_weight, void* workspace, size_t workspace_bytes,
+                  lsi_stream_t stream_) {
   if (!d || !x || !gy || !g_weight || !workspace) return LSI_ENULL;
   if (!gw_desc_ok(d)) return LSI_EUNSUPPORTED;
   if (((uintptr_t)x & 15) || ((uintptr_t)gy & 15) || ((uintptr_t)workspace & 15)) return LSI_EINVAL;
@@ -384,6 +409,7 @@ extern "C" int lsi_conv2d_wgrad(const LsiConvDesc* d, const void* x, const void*
   if (workspace_bytes < (size_t)nblk * nout * sizeof(float)) return LSI_EWORKSPACE;
   if (nout >= (1u << 31)) return LSI_EUNSUPPORTED;
   k.x = (const __bf16*)x; k.gy = (const __bf16*)gy; k.part = (float*)workspace;
+  k.x2 = (const __bf16*)x2; k.C1 = x2 ? c1 : d->Cin;
   k.N = d->N; k.H = d->H; k.W = d->W; k.Cin = d->Cin; k.OH = d->OH; k.OW = d->OW; k.Cout = d->Cout;
   hipStream_t stream = (hipStream_t)stream_;
   const void* fn = nullptr;

@@ -474,6 +474,90 @@ def conv2d(x, weight, stride, pad_t, pad_l, oh, ow, bn_groups=0):
   return _Conv2dIgemm.apply(x, weight, stride, pad_t, pad_l, oh, ow, bn_groups)
 
 
+CAT_CONV = os.environ.get('LSI_CAT_CONV', '1') != '0'
+
+
+def cat_supported(x1, x2, cout, k, stride):
+  """A convolution over tf.concat([x1, x2], axis=3) read from the two tensors
+  (lsi_conv2d_fwd_cat / _bwd_data_cat / _wgrad_cat): both bf16 channels-last on
+  the GPU with the same N, H, W; channel counts multiples of 32, x1's also of the
+  data-gradient kernel's channel block (64 when the sum is a multiple of 64)."""
+  if not (CAT_CONV and OWN_WGRAD and _cl_bf16(x1) and _cl_bf16(x2)):
+    return False
+  if x1.shape[0] != x2.shape[0] or x1.shape[2:] != x2.shape[2:]:
+    return False
+  c1, c2 = x1.shape[1], x2.shape[1]
+  blk = 64 if (c1 + c2) % 64 == 0 else 32
+  return (c1 % 32 == 0 and c2 % 32 == 0 and c1 % blk == 0 and cout % 32 == 0 and
+          1 <= k <= 7 and stride in (1, 2) and
+          x1.shape[0] * x1.shape[2] * x1.shape[3] >= IGEMM_MIN_PIXELS)
+
+
+class _Conv2dCatIgemm(torch.autograd.Function):
+  """slim.conv2d over a skip connection's concatenation (reference nets.py:104-106,
+  300-345) without the concatenated tensor: forward, data gradient (into two
+  tensors) and weight gradient read / write the two activations directly."""
+
+  @staticmethod
+  def forward(ctx, x1, x2, weight, stride, pad_t, pad_l, oh, ow, bn_groups=0):
+    n, c1, h, w = x1.shape
+    c2 = x2.shape[1]
+    cout, cin, kh, kw = weight.shape
+    assert cin == c1 + c2
+    desc = _conv_desc(n, h, w, cin, oh, ow, cout, kh, kw, stride, pad_t, pad_l)
+    ctx.desc = desc
+    ctx.save_for_backward(x1, x2, weight)
+    dev = x1.device
+    out = _empty_cl(n, cout, oh, ow, dev)
+    packed = _packed(desc, 0, weight)
+    ws_ptr = 0
+    if bn_groups:
+      from lsi.nnutils import _hip_bn  # pylint: disable=g-import-not-at-top
+      ws_ptr = _hip_bn.stats_workspace(tuple(out.shape), dev, 1, bn_groups).data_ptr()
+    rc = _C.lib().lsi_conv2d_fwd_cat(ctypes.byref(desc), x1.data_ptr(), x2.data_ptr(), c1,
+                                     packed.data_ptr(), out.data_ptr(), ws_ptr,
+                                     int(bn_groups), _C.stream_ptr(dev))
+    if rc:
+      _C.check(rc, 'lsi_conv2d_fwd_cat')
+    return out
+
+  @staticmethod
+  def backward(ctx, g):
+    x1, x2, weight = ctx.saved_tensors
+    d = ctx.desc
+    dev = x1.device
+    c1 = x1.shape[1]
+    if g.dtype != torch.bfloat16:
+      g = g.to(torch.bfloat16)
+    g = g.contiguous(memory_format=torch.channels_last)
+    lib = _C.lib()
+    gx1 = gx2 = gw = None
+    if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+      gx1 = _empty_cl(d.N, c1, d.H, d.W, dev)
+      gx2 = _empty_cl(d.N, d.Cin - c1, d.H, d.W, dev)
+      packed = _packed(d, 1, weight)
+      rc = lib.lsi_conv2d_bwd_data_cat(ctypes.byref(d), g.data_ptr(), packed.data_ptr(),
+                                       gx1.data_ptr(), gx2.data_ptr(), c1, _C.stream_ptr(dev))
+      if rc:
+        _C.check(rc, 'lsi_conv2d_bwd_data_cat')
+    if ctx.needs_input_grad[2]:
+      nbytes = _igemm_wgrad_bytes(d)
+      ws = _wgrad_workspace(dev, nbytes)
+      gw = torch.empty(tuple(weight.shape), dtype=torch.float32, device=dev)
+      rc = lib.lsi_conv2d_wgrad_cat(ctypes.byref(d), x1.data_ptr(), x2.data_ptr(), c1,
+                                    g.data_ptr(), gw.data_ptr(), ws.data_ptr(),
+                                    ws.numel() * 4, _C.stream_ptr(dev))
+      if rc:
+        _C.check(rc, 'lsi_conv2d_wgrad_cat')
+      if weight.dtype != torch.float32:
+        gw = gw.to(weight.dtype)
+    return gx1, gx2, gw, None, None, None, None, None, None
+
+
+def conv2d_cat(x1, x2, weight, stride, pad_t, pad_l, oh, ow, bn_groups=0):
+  return _Conv2dCatIgemm.apply(x1, x2, weight, stride, pad_t, pad_l, oh, ow, bn_groups)
+
+
 class _ConvTranspose2dIgemm(torch.autograd.Function):
   """slim.conv2d_transpose 4 x 4 stride 2 (torch ConvTranspose2d(k, stride 2,
   padding p); reference nets.py:100-103, 295-345): the data gradient of the

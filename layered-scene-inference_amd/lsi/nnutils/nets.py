@@ -193,7 +193,10 @@ class SlimConv2d(nn.Module):
     self.bn = SlimBatchNorm(cout) if batch_norm else None
     self.activation = activation
 
-  def forward(self, x):
+  def forward(self, x, x2=None):
+    """x2: the layer reads tf.concat([x, x2], axis=3) (a skip connection)."""
+    if x2 is not None:
+      return self.forward_cat(x, x2)
     if MFMA_CONV and x.is_cuda and x.dtype == torch.bfloat16:
       from lsi.nnutils import _hip_conv  # pylint: disable=g-import-not-at-top
       cout, cin = self.conv.weight.shape[:2]
@@ -240,6 +243,31 @@ class SlimConv2d(nn.Module):
         x = F.pad(x, (pw[0], pw[1], ph[0], ph[1]))
       x = self.conv(x)
     return self._bn_act(x)
+
+  def forward_cat(self, x1, x2):
+    """forward(tf.concat([x1, x2], axis=3)) -- the skip connections -- with the
+    convolution kernels reading the two tensors where they can."""
+    if (MFMA_CONV and IGEMM_CONV and self.bn is not None and x1.is_cuda and
+        x1.dtype == torch.bfloat16 and x2.dtype == torch.bfloat16):
+      from lsi.nnutils import _hip_conv  # pylint: disable=g-import-not-at-top
+      cout = self.conv.weight.shape[0]
+      if (_hip_conv.cat_supported(x1, x2, cout, self.k, self.stride) and
+          _igemm_pays(x1, self.stride) and
+          _hip_conv._igemm_wgrad_bytes(_hip_conv._conv_desc(
+              x1.shape[0], x1.shape[2], x1.shape[3], x1.shape[1] + x2.shape[1],
+              -(-x1.shape[2] // self.stride), -(-x1.shape[3] // self.stride), cout,
+              self.k, self.k, self.stride, _same_pad(x1.shape[2], self.k, self.stride)[0],
+              _same_pad(x1.shape[3], self.k, self.stride)[0])) > 0):
+        ph = _same_pad(x1.shape[2], self.k, self.stride)
+        pw = _same_pad(x1.shape[3], self.k, self.stride)
+        st = _stats_bn(self.bn, self.activation, x1.shape[0], cout)
+        y = _hip_conv.conv2d_cat(x1, x2, self.conv.weight, self.stride, ph[0], pw[0],
+                                 -(-x1.shape[2] // self.stride),
+                                 -(-x1.shape[3] // self.stride), st)
+        if st:
+          return _bn_relu(self.bn, y, True)
+        return self._bn_act(y)
+    return self.forward(torch.cat([x1, x2], dim=1))
 
   def _bn_act(self, x):
     """Batch norm (if any) and the activation behind the convolution."""
@@ -386,8 +414,9 @@ class DecoderSimple(nn.Module):
     for nc in range(self.nconv, 0, -1):
       feat = getattr(self, 'upcnv%d' % nc)(feat)
       if nc > 1 and skip_feat is not None:
-        feat = torch.cat([feat, skip_feat[-nc + 1]], dim=1)
-      feat = getattr(self, 'upcnv%db' % nc)(feat)
+        feat = getattr(self, 'upcnv%db' % nc)(feat, skip_feat[-nc + 1])
+      else:
+        feat = getattr(self, 'upcnv%db' % nc)(feat)
     return feat
 
 
@@ -526,8 +555,9 @@ class EncoderDecoderUnet(nn.Module):
     for tag, _, skip in self._DEC[:self.n_dec]:
       x = getattr(self, 'upcnv' + tag)(x)
       if skip is not None:
-        x = torch.cat([x, feats[skip]], dim=1)
-      x = getattr(self, 'icnv' + tag)(x)
+        x = getattr(self, 'icnv' + tag)(x, feats[skip])
+      else:
+        x = getattr(self, 'icnv' + tag)(x)
       feats['icnv' + tag] = x
     skip_feat = [feats[k] for k in ('cnv6b', 'cnv5b', 'cnv4b', 'cnv3b', 'cnv2b',
                                     'cnv1b')]

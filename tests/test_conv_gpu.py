@@ -411,3 +411,56 @@ def test_transposed_convolution_leaves_the_statistics_too(dev):
       torch.rsqrt(yf.var(dim=(1, 3, 4), unbiased=False) + 1e-3).cpu().numpy(), rtol=2e-5)
   z0 = _hip_bn.batch_norm_relu(y0, beta, 1e-3, True, groups)
   assert float((z1.detach().float() - z0.detach().float()).abs().max()) <= 2.0 ** -7 * float(z0.detach().float().abs().max())
+
+
+# (n, c1, c2, h, w, cout, k): the heads' upcnv2b / upcnv3b and the U-Net's icnv
+# layers in small; odd sizes
+@pytest.mark.parametrize('case', [(2, 64, 32, 21, 37, 64, 3), (2, 128, 64, 16, 24, 128, 3),
+                                  (4, 512, 512, 4, 12, 512, 3), (1, 64, 64, 9, 70, 32, 5)])
+def test_convolution_over_a_skip_connection_reads_the_two_tensors(case, dev):
+  """lsi_conv2d_fwd_cat / _bwd_data_cat / _wgrad_cat against the same kernels on
+  the concatenated tensor: the same products in the same order -- equal bits."""
+  from lsi.nnutils import _hip_conv, nets
+  n, c1, c2, h, w, cout, k = case
+  g = torch.Generator().manual_seed(21)
+  mk = lambda c: torch.randn((n, c, h, w), generator=g).to(dev).to(torch.bfloat16) \
+      .contiguous(memory_format=torch.channels_last).requires_grad_(True)
+  x1, x2 = mk(c1), mk(c2)
+  wt = (torch.randn((cout, c1 + c2, k, k), generator=g) * (0.5 / k)).to(dev).requires_grad_(True)
+  ph, pw = nets._same_pad(h, k, 1), nets._same_pad(w, k, 1)
+  assert _hip_conv.cat_supported(x1, x2, cout, k, 1)
+  y0 = _hip_conv.conv2d(torch.cat([x1, x2], dim=1).contiguous(memory_format=torch.channels_last),
+                        wt, 1, ph[0], pw[0], h, w)
+  y1 = _hip_conv.conv2d_cat(x1, x2, wt, 1, ph[0], pw[0], h, w)
+  assert torch.equal(y1, y0)
+  gy = torch.randn(y0.shape, generator=g).to(dev).to(torch.bfloat16)
+  gy = gy.contiguous(memory_format=torch.channels_last)
+  a1, a2, aw = torch.autograd.grad(y0, (x1, x2, wt), gy)
+  b1, b2, bw = torch.autograd.grad(y1, (x1, x2, wt), gy)
+  assert torch.equal(a1, b1) and torch.equal(a2, b2)
+  assert float((aw - bw).abs().max()) <= 1e-6 * float(aw.abs().max())
+
+
+def test_skip_connection_layer_module_matches_the_concatenated_form(dev, monkeypatch):
+  """SlimConv2d.forward_cat (two-tensor kernels + statistics in the epilogue)
+  against forward(torch.cat(...)) with LSI_CAT_CONV off."""
+  from lsi.nnutils import _hip_conv, nets
+  g = torch.Generator().manual_seed(22)
+  layer = nets.SlimConv2d(192, 128, 3, 1).to(dev)
+  mk = lambda c: torch.randn((4, c, 16, 24), generator=g).to(dev).to(torch.bfloat16) \
+      .contiguous(memory_format=torch.channels_last).requires_grad_(True)
+  x1, x2 = mk(128), mk(64)
+  with nets.bn_groups(2):
+    z1 = layer(x1, x2)
+    monkeypatch.setattr(_hip_conv, 'CAT_CONV', False)
+    z0 = layer(x1, x2)
+  gz = torch.randn(z0.shape, generator=g).to(dev).to(torch.bfloat16)
+  p = [x1, x2, layer.conv.weight, layer.bn.beta]
+  g1 = torch.autograd.grad(z1, p, gz)
+  g0 = torch.autograd.grad(z0, p, gz)
+  d = (z1.detach().float() - z0.detach().float()).abs()
+  assert float(d.max()) <= 2.0 ** -7 * float(z0.detach().float().abs().max())
+  for a, b in zip(g1, g0):
+    scale = float(b.float().abs().max())
+    assert float((a.float() - b.float()).abs().max()) <= 2e-2 * scale
+    assert float((a.float() - b.float()).abs().mean()) <= 2e-4 * scale
