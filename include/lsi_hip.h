@@ -550,7 +550,12 @@ int lsi_stream_adapt_state(const LsiSplatDesc* d);
  * parameter -- mode 0 for lsi_conv2d_fwd, mode 1 for lsi_conv2d_bwd_data (roles
  * of the channels swapped, taps in parity-class order) -- into
  * lsi_conv2d_packed_bytes(d) bytes (16-byte aligned; LSI_EWORKSPACE if
- * smaller).  A caller whose weights have not changed may keep the packed form.
+ * smaller).  mode | 2: the parameter is stored with torch's channels-last
+ * strides (Cout x KH x KW x Cin in memory: what module.to(memory_format=
+ * torch.channels_last) leaves) instead of contiguously.  A caller whose weights
+ * have not changed may keep the packed form -- and one whose optimiser updates
+ * them has to pack again after every update (torch's fused optimisers do not
+ * move a parameter's version counter: a stale pack is silent).
  */
 typedef struct LsiConvDesc {
   int32_t N, H, W, Cin;    /* input  N x H x W x Cin   */

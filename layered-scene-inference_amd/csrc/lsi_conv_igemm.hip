@@ -336,13 +336,17 @@ __device__ __forceinline__ void pack_tile(const PackArgs& a, int bx, int by,
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int r = r0 + 8 * j;
-      tile[r][c] = a.w[((size_t)(a0 + r) * a.D1 + b0 + c) * a.khw + tap];
+      // (the parameter D0 x D1 x KH x KW as torch stores it: contiguous, or --
+      // tr & 2 -- channels-last strides, D0 x KH x KW x D1 in memory: what
+      // module.to(memory_format=torch.channels_last) leaves)
+      tile[r][c] = (a.tr & 2) ? a.w[((size_t)(a0 + r) * a.khw + tap) * a.D1 + b0 + c]
+                              : a.w[((size_t)(a0 + r) * a.D1 + b0 + c) * a.khw + tap];
     }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int r = r0 + 8 * j;
-      if (a.tr)   // dst[t][d1][d0]
+      if (a.tr & 1)   // dst[t][d1][d0]
         dst[(size_t)t * per + (size_t)(b0 + r) * a.D0 + a0 + c] = (__bf16)tile[c][r];
       else        // dst[t][d0][d1]
         dst[(size_t)t * per + (size_t)(a0 + r) * a.D1 + b0 + c] = (__bf16)tile[r][c];
@@ -541,12 +545,12 @@ extern "C" int lsi_conv2d_pack_job(const LsiConvDesc* d, int32_t mode, const flo
                                    int32_t* nblocks) {
   if (!d || !weight || !packed || !job || !nblocks) return LSI_ENULL;
   if (!desc_ok(d)) return LSI_EUNSUPPORTED;
-  if (mode != 0 && mode != 1) return LSI_EINVAL;
+  if (mode < 0 || mode > 3) return LSI_EINVAL;
   if ((uintptr_t)packed & 15) return LSI_EINVAL;
   if (packed_bytes < lsi_conv2d_packed_bytes(d)) return LSI_EWORKSPACE;
   IgArgs k;
   memset(job, 0, sizeof(*job));
-  ig_classes(d, mode, k, job->tap);
+  ig_classes(d, mode & 1, k, job->tap);
   job->w = weight; job->dst = packed;
   job->D0 = d->Cout; job->D1 = d->Cin; job->khw = d->KH * d->KW; job->tr = mode;
   job->ntaps = d->KH * d->KW;

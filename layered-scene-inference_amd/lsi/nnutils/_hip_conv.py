@@ -277,36 +277,79 @@ import weakref
 
 class _Pack(object):
   """One layer's weights in the kernel's operand order for one direction."""
-  __slots__ = ('wref', 'version', 'geo', 'buf', 'mode', 'desc')
+  __slots__ = ('wref', 'version', 'geo', 'buf', 'mode', 'desc', 'managed')
 
 
 _PACKED = {}   # (id(weight), mode) -> _Pack
 _PACK_TABLE = {}  # device index -> (key, device table, njobs, blocks, entries)
 
 
-def _packed(desc, mode, weight):
-  """The layer's weights in the kernel's operand order (lsi_conv2d_pack), kept
-  until the parameter changes (its version counter: the optimiser's in-place
-  step moves it) -- an evaluation loop packs once; a training loop calls
-  repack_all() after the optimiser's step: one launch for all layers."""
+def _pack_layout(w):
+  """Layout bit of lsi_conv2d_pack for a parameter it can read in place: fp32,
+  stored contiguously (0) or with channels-last strides (2:
+  module.to(memory_format=torch.channels_last)); None: a copy is needed."""
+  if w.dtype == torch.float32:
+    if w.is_contiguous():
+      return 0
+    if w.dim() == 4 and w.is_contiguous(memory_format=torch.channels_last):
+      return 2
+  return None
+
+
+def _pack_source(weight):
+  """(tensor whose memory lsi_conv2d_pack reads, layout bit)."""
+  w = weight.detach()
+  cl = _pack_layout(w)
+  if cl is None:
+    return w.float().contiguous(), 0
+  return w, cl
+
+
+def _packed(desc, mode, weight, training=False):
+  """The layer's weights in the kernel's operand order (lsi_conv2d_pack).
+
+  A parameter that requires a gradient is packed on EVERY forward call unless its
+  packs are managed (repack_all() has refreshed them: whoever calls it -- the
+  Trainer, after each optimiser step, one launch for all layers -- goes on
+  calling it after every update) -- its version counter cannot be trusted: torch's fused
+  optimisers update parameters without moving it, and a stale pack is silent
+  (found in round 5: the trainer's channels-last parameters were skipped by
+  repack_all, and every implicit-GEMM layer ran on its initial weights).  The
+  backward of the same call takes the other direction's pack from the cache:
+  the forward call drops it.  Frozen parameters keep their packs until the
+  version counter moves (load_state_dict, copy_)."""
   key = (id(weight), mode)
   hit = _PACKED.get(key)
+  # (`training`: a forward call -- not the backward of one, which takes what the
+  # forward left -- with a parameter somebody may be updating)
+  training = training and weight.requires_grad
+  if training and not (hit is not None and hit.managed):
+    _PACKED.pop((id(weight), 1 - mode), None)   # (this step's backward packs afresh)
+    hit_ok = False
+  else:
+    hit_ok = True
+  geo = (desc.Cin, desc.Cout, desc.KH, desc.KW, desc.stride, desc.pad_t, desc.pad_l)
   if hit is not None and hit.wref() is weight and hit.buf.device == weight.device:
-    geo = (desc.Cin, desc.Cout, desc.KH, desc.KW, desc.stride, desc.pad_t, desc.pad_l)
-    if hit.version == weight._version and hit.geo == geo:
+    if hit_ok and hit.version == weight._version and hit.geo == geo:
       return hit.buf
   lib = _C.lib()
   dev = weight.device
   nbytes = lib.lsi_conv2d_packed_bytes(ctypes.byref(desc))
-  buf = torch.empty((nbytes // 2,), dtype=torch.bfloat16, device=dev)
-  rc = lib.lsi_conv2d_pack(ctypes.byref(desc), mode, _C.ptr(_f32(weight)), _C.ptr(buf),
+  if (hit is not None and hit.wref() is weight and hit.buf.device == dev and
+      hit.buf.numel() * 2 == nbytes and hit.geo == geo):
+    buf = hit.buf          # (same place: a captured graph or a job table keeps its address)
+  else:
+    buf = torch.empty((nbytes // 2,), dtype=torch.bfloat16, device=dev)
+  src, cl = _pack_source(weight)
+  rc = lib.lsi_conv2d_pack(ctypes.byref(desc), mode | cl, _C.ptr(src), _C.ptr(buf),
                            nbytes, _C.stream_ptr(dev))
   _C.check(rc, 'lsi_conv2d_pack')
   e = _Pack()
   e.wref = weakref.ref(weight, lambda _r, k=key: _PACKED.pop(k, None))
   e.version = weight._version
-  e.geo = (desc.Cin, desc.Cout, desc.KH, desc.KW, desc.stride, desc.pad_t, desc.pad_l)
+  e.geo = geo
   e.buf, e.mode, e.desc = buf, mode, desc
+  e.managed = False
   _PACKED[key] = e
   return buf
 
@@ -317,14 +360,23 @@ def repack_all(device=None):
   after the optimiser's step, so that the step's forward and backward find their
   operands ready (eagerly: two launches per layer less; captured in a HIP graph:
   the packs belong to the graph, whatever the version counters said at capture
-  time).  Parameters that are not plain fp32 tensors are left to _packed()."""
+  time).  fp32 parameters stored contiguously or with channels-last strides are
+  read in place; others are dropped from the cache (_packed() packs a copy at
+  the next call).  The packs it refreshes are MANAGED from then on: _packed()
+  trusts them, and whoever updates the parameters calls this after every
+  update."""
   if not _PACKED:
     return 0
   lib = _C.lib()
   by_dev = {}
-  for e in list(_PACKED.values()):
+  for k, e in list(_PACKED.items()):
     w = e.wref()
-    if w is None or not w.is_cuda or w.dtype != torch.float32 or not w.is_contiguous():
+    if w is None:
+      continue
+    if not w.is_cuda or _pack_layout(w) is None:
+      # (not fp32 in one of the two layouts: _packed() packs a copy, now)
+      if device is None or w.device == device:
+        _PACKED.pop(k, None)
       continue
     if device is not None and w.device != device:
       continue
@@ -340,7 +392,7 @@ def repack_all(device=None):
       nb = ctypes.c_int32(0)
       blocks = 0
       for j, (e, w) in enumerate(items):
-        rc = lib.lsi_conv2d_pack_job(ctypes.byref(e.desc), e.mode, w.data_ptr(),
+        rc = lib.lsi_conv2d_pack_job(ctypes.byref(e.desc), e.mode | _pack_layout(w), w.data_ptr(),
                                      e.buf.data_ptr(), e.buf.numel() * 2,
                                      ctypes.byref(jobs[j]), ctypes.byref(nb))
         _C.check(rc, 'lsi_conv2d_pack_job')
@@ -354,15 +406,16 @@ def repack_all(device=None):
     _C.check(rc, 'lsi_conv2d_pack_many')
     for e, w in items:
       e.version = w._version
+      e.managed = True
     n += len(items)
   return n
 
 
-def _igemm(entry, desc, src, weight, out, bn_groups=0):
+def _igemm(entry, desc, src, weight, out, bn_groups=0, training=False):
   """bn_groups > 0: the kernel also adds the batch-norm sums of `out` to the
   workspace (lsi_conv2d_*_bnstats) for the lsi_bn_relu_norm that has to follow."""
   mode = 1 if entry == 'lsi_conv2d_bwd_data' else 0
-  packed = _packed(desc, mode, weight)
+  packed = _packed(desc, mode, weight, training)
   lib = _C.lib()
   if bn_groups:
     from lsi.nnutils import _hip_bn  # pylint: disable=g-import-not-at-top
@@ -434,7 +487,7 @@ class _Conv2dIgemm(torch.autograd.Function):
     ctx.desc = desc
     ctx.save_for_backward(x, weight)
     return _igemm('lsi_conv2d_fwd', desc, x, weight, _empty_cl(n, cout, oh, ow, x.device),
-                  bn_groups)
+                  bn_groups, True)
 
   @staticmethod
   def backward(ctx, g):
@@ -509,7 +562,7 @@ class _Conv2dCatIgemm(torch.autograd.Function):
     ctx.save_for_backward(x1, x2, weight)
     dev = x1.device
     out = _empty_cl(n, cout, oh, ow, dev)
-    packed = _packed(desc, 0, weight)
+    packed = _packed(desc, 0, weight, True)
     ws_ptr = 0
     if bn_groups:
       from lsi.nnutils import _hip_bn  # pylint: disable=g-import-not-at-top
@@ -574,7 +627,8 @@ class _ConvTranspose2dIgemm(torch.autograd.Function):
     ctx.save_for_backward(x, weight)
     ctx.args = (stride, pad)
     return _igemm('lsi_conv2d_bwd_data', desc, x, weight,
-                  _empty_cl(n, cout_t, stride * h, stride * w, x.device), bn_groups)
+                  _empty_cl(n, cout_t, stride * h, stride * w, x.device), bn_groups,
+                  True)
 
   @staticmethod
   def backward(ctx, g):

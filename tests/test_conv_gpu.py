@@ -464,3 +464,36 @@ def test_skip_connection_layer_module_matches_the_concatenated_form(dev, monkeyp
     scale = float(b.float().abs().max())
     assert float((a.float() - b.float()).abs().max()) <= 2e-2 * scale
     assert float((a.float() - b.float()).abs().mean()) <= 2e-4 * scale
+
+
+def test_packs_of_channels_last_parameters_and_of_silent_updates(dev):
+  """(1) A parameter with channels-last strides (module.to(memory_format=
+  torch.channels_last): what the trainer's model has) is packed in place
+  (mode | 2) to the same operand as its contiguous copy.  (2) A parameter that
+  is being trained is packed on every forward call while nobody manages its
+  packs: an update that does not move the version counter (torch's fused
+  optimisers; `.data` here) must be seen by the next call, forward and
+  backward."""
+  from lsi.nnutils import _hip_conv
+  g = torch.Generator().manual_seed(31)
+  x = _clast(torch.randn((2, 64, 10, 12), generator=g).to(dev).to(torch.bfloat16)).requires_grad_(True)
+  w0 = (torch.randn((32, 64, 3, 3), generator=g) * 0.1).to(dev)
+  wc = w0.clone().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+  assert not wc.is_contiguous() and _hip_conv._pack_layout(wc) == 2
+  yc = _hip_conv.conv2d(x, wc, 1, 1, 1, 10, 12)
+  y0 = _hip_conv.conv2d(x, w0, 1, 1, 1, 10, 12)
+  assert torch.equal(yc, y0)
+  gy = _clast(torch.randn(y0.shape, generator=g).to(dev).to(torch.bfloat16))
+  gx_c, = torch.autograd.grad(yc, x, gy)
+  v = wc._version
+  wc.data.mul_(-2.0)                # (no version bump)
+  assert wc._version == v
+  y2 = _hip_conv.conv2d(x, wc, 1, 1, 1, 10, 12)
+  assert float((y2.float() + 2 * y0.float()).abs().max()) <= float(y2.float().abs().max()) * 2.0 ** -6
+  gx_2, = torch.autograd.grad(y2, x, gy)
+  assert float((gx_2.float() + 2 * gx_c.float()).abs().max()) <= float(gx_2.float().abs().max()) * 2.0 ** -6
+  # managed packs: repack_all brings them up to date and the calls trust them
+  wc.data.mul_(-0.5)
+  assert _hip_conv.repack_all(dev) >= 2
+  y3 = _hip_conv.conv2d(x, wc, 1, 1, 1, 10, 12)
+  assert float((y3.float() - y0.float()).abs().max()) <= float(y0.float().abs().max()) * 2.0 ** -6

@@ -392,3 +392,45 @@ def test_paired_splat_equals_one_call_per_direction(tmp_path, built_lib):
   scale = float(gb.abs().max())
   assert scale > 0
   assert float((ga - gb).abs().max()) <= 2e-5 * scale, float((ga - gb).abs().max()) / scale
+
+
+@pytest.mark.parametrize('graph', ['false', 'true'])
+def test_convolutions_run_on_the_weights_of_the_step(tmp_path, built_lib, graph):
+  """The implicit-GEMM layers keep their weights in operand order
+  (lsi_conv2d_pack); after every optimiser step the packs have to be those of
+  the updated parameters.  (Round 5 found them stale: the trainer's parameters
+  have channels-last strides, which the re-pack skipped, and torch's fused Adam
+  does not move a parameter's version counter -- every such layer ran on its
+  initial weights, silently.)  Checked after every step against a fresh pack of
+  the present weights, eager and as a captured graph."""
+  import ctypes
+  from lsi import _C
+  from lsi.nnutils import _hip_conv
+  tr = _trainer(tmp_path, bf16='true', hip_graph=graph)
+  batch = tr.feed()
+  tr.feed = lambda: batch
+  lib = _C.lib()
+
+  def fresh(e, w):
+    buf = torch.empty_like(e.buf)
+    rc = lib.lsi_conv2d_pack(ctypes.byref(e.desc), e.mode, _C.ptr(w.float().contiguous()),
+                             _C.ptr(buf), buf.numel() * 2, _C.stream_ptr(w.device))
+    assert rc == 0
+    return buf
+
+  mine = lambda: {k: e for k, e in _hip_conv._PACKED.items()
+                  if e.wref() is not None and any(e.wref() is p for p in tr.model.parameters())}
+  first, checked = None, 0
+  for step in range(6):
+    tr.train_step()
+    torch.cuda.synchronize()
+    # the trainer re-packs right after the optimiser's update: what the next
+    # step's forward and backward will read is the pack of the present weights
+    for k, e in mine().items():
+      assert torch.equal(fresh(e, e.wref().detach()), e.buf), (step, k)
+      checked += 1
+    first = first or {k: e.wref().detach().clone() for k, e in mine().items()}
+  assert checked >= 6 * 40, checked     # (dozens of layers, both directions)
+  # ... and the parameters did move
+  assert all(float((e.wref().detach() - first[k]).abs().max()) > 0
+             for k, e in mine().items() if k in first)
