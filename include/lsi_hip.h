@@ -615,6 +615,11 @@ int lsi_conv2d_bwd_data_bnstats(const LsiConvDesc* d, const void* gy, const void
  * gradient: the kernel's block of output channels), else LSI_EINVAL.
  * lsi_conv2d_fwd_cat: bn_workspace != NULL adds the batch-norm sums as
  * lsi_conv2d_fwd_bnstats does (groups is ignored otherwise).
+ * lsi_conv2d_wgrad_cat: x2 may be NULL (one tensor, c1 ignored);
+ * weight_layout 0 writes g_weight contiguously (Cout x Cin x KH x KW), 2 with
+ * torch's channels-last strides (Cout x KH x KW x Cin in memory: the layout of
+ * the parameter after module.to(memory_format=torch.channels_last) -- autograd
+ * then takes the gradient as it is instead of copying it into that layout).
  */
 int lsi_conv2d_fwd_cat(const LsiConvDesc* d, const void* x1, const void* x2, int32_t c1,
                        const void* packed, void* out, float* bn_workspace, int32_t groups,
@@ -622,8 +627,8 @@ int lsi_conv2d_fwd_cat(const LsiConvDesc* d, const void* x1, const void* x2, int
 int lsi_conv2d_bwd_data_cat(const LsiConvDesc* d, const void* gy, const void* packed,
                             void* gx1, void* gx2, int32_t c1, lsi_stream_t stream);
 int lsi_conv2d_wgrad_cat(const LsiConvDesc* d, const void* x1, const void* x2, int32_t c1,
-                         const void* gy, float* g_weight, void* workspace,
-                         size_t workspace_bytes, lsi_stream_t stream);
+                         const void* gy, float* g_weight, int32_t weight_layout,
+                         void* workspace, size_t workspace_bytes, lsi_stream_t stream);
 /*
  * Weight gradient of the convolution LsiConvDesc describes (TF autodiff of
  * slim.conv2d, reference nets.py:29-114, 244-348):

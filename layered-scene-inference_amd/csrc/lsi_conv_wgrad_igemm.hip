@@ -226,8 +226,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_igemm_kernel(GwArgs a) {
 
 // out[co][ci][tap] = sum over the pixel blocks' partials [blk][tap][co][ci]
 // (lsi_conv_wgrad.hip's fold; the transposition happens on the small result)
+// cl: the parameter (and so its gradient) has torch's channels-last strides --
+// [co][tap][ci] in memory -- instead of [co][ci][tap]
 __global__ __launch_bounds__(1024) void conv_wgrad_fold_kernel(const float* part, int nblk,
-                                                               int nout, float* out, int khw) {
+                                                               int nout, float* out, int khw,
+                                                               int Cin, int cl) {
   __shared__ float red[16][64];
   const int o = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
   float s = 0.0f;
@@ -251,7 +254,12 @@ __global__ __launch_bounds__(1024) void conv_wgrad_fold_kernel(const float* part
     for (int k = 0; k < 16; ++k) v += red[k][threadIdx.x];
     const int per = nout / khw;            // Cout * Cin
     const int tap = o / per, rest = o - tap * per;
-    out[(size_t)rest * khw + tap] = v;
+    if (cl) {
+      const int co = rest / Cin, ci = rest - co * Cin;
+      out[((size_t)co * khw + tap) * Cin + ci] = v;
+    } else {
+      out[(size_t)rest * khw + tap] = v;
+    }
   }
 }
 
@@ -264,7 +272,7 @@ __global__ __launch_bounds__(1024) void conv_wgrad_fold_kernel(const float* part
 // layer whatever its map size; this one: a plain stream).
 __global__ __launch_bounds__(256) void conv_wgrad_fold_t_kernel(const float* part, int nblk,
                                                                 int Cout, int Cin, int khw,
-                                                                float* out) {
+                                                                float* out, int cl) {
   extern __shared__ float ft_tile[];  // [64][khw + 1]
   const int ncc = Cin / 64;
   const int co = blockIdx.x / ncc, ci0 = (blockIdx.x - co * ncc) * 64;
@@ -284,6 +292,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_fold_t_kernel(const float* par
     ft_tile[l * (khw + 1) + tap] = (s0 + s1) + (s2 + s3);
   }
   __syncthreads();
+  if (cl) {   // [co][tap][ci]: a 256-byte run per tap
+    for (int i = threadIdx.x; i < 64 * khw; i += 256) {
+      const int tap = i >> 6, c = i & 63;
+      out[((size_t)co * khw + tap) * Cin + ci0 + c] = ft_tile[c * (khw + 1) + tap];
+    }
+    return;
+  }
   float* o = out + ((size_t)co * Cin + ci0) * khw;
   for (int i = threadIdx.x; i < 64 * khw; i += 256) {
     const int c = i / khw, tap = i - c * khw;
@@ -377,7 +392,7 @@ extern "C" size_t lsi_conv2d_wgrad_workspace_bytes(const LsiConvDesc* d) {
 
 static int gw_run(const LsiConvDesc* d, const void* x, const void* x2, int c1, const void* gy,
                   float* g_weight, void* workspace, size_t workspace_bytes,
-                  lsi_stream_t stream_);
+                  lsi_stream_t stream_, int cl = 0);
 
 extern "C" int lsi_conv2d_wgrad(const LsiConvDesc* d, const void* x, const void* gy,
                                 float* g_weight, void* workspace, size_t workspace_bytes,
@@ -387,16 +402,17 @@ extern "C" int lsi_conv2d_wgrad(const LsiConvDesc* d, const void* x, const void*
 
 extern "C" int lsi_conv2d_wgrad_cat(const LsiConvDesc* d, const void* x1, const void* x2,
                                     int32_t c1, const void* gy, float* g_weight,
-                                    void* workspace, size_t workspace_bytes,
-                                    lsi_stream_t stream_) {
-  if (!x2) return LSI_ENULL;
-  if (!d || c1 <= 0 || c1 >= d->Cin || c1 % 32 || ((uintptr_t)x2 & 15)) return LSI_EINVAL;
-  return gw_run(d, x1, x2, c1, gy, g_weight, workspace, workspace_bytes, stream_);
+                                    int32_t weight_layout, void* workspace,
+                                    size_t workspace_bytes, lsi_stream_t stream_) {
+  if (weight_layout != 0 && weight_layout != 2) return LSI_EINVAL;
+  if (x2 && (!d || c1 <= 0 || c1 >= d->Cin || c1 % 32 || ((uintptr_t)x2 & 15))) return LSI_EINVAL;
+  return gw_run(d, x1, x2, x2 ? c1 : 0, gy, g_weight, workspace, workspace_bytes, stream_,
+                weight_layout);
 }
 
 static int gw_run(const LsiConvDesc* d, const void* x, const void* x2, int c1, const void* gy,
                   float* g_weight, void* workspace, size_t workspace_bytes,
-                  lsi_stream_t stream_) {
+                  lsi_stream_t stream_, int cl) {
   if (!d || !x || !gy || !g_weight || !workspace) return LSI_ENULL;
   if (!gw_desc_ok(d)) return LSI_EUNSUPPORTED;
   if (((uintptr_t)x & 15) || ((uintptr_t)gy & 15) || ((uintptr_t)workspace & 15)) return LSI_EINVAL;
@@ -428,9 +444,9 @@ static int gw_run(const LsiConvDesc* d, const void* x, const void* x2, int c1, c
   if (d->Cin % 64 == 0 && (long)d->Cout * (d->Cin / 64) >= 1024)
     hipLaunchKernelGGL(conv_wgrad_fold_t_kernel, dim3((unsigned)(d->Cout * (d->Cin / 64))), dim3(256),
                        (size_t)64 * (khw + 1) * sizeof(float), stream, k.part, nblk, d->Cout,
-                       d->Cin, khw, g_weight);
+                       d->Cin, khw, g_weight, cl);
   else
     hipLaunchKernelGGL(conv_wgrad_fold_kernel, dim3((unsigned)((nout + 63) / 64)), dim3(1024), 0,
-                       stream, k.part, nblk, (int)nout, g_weight, khw);
+                       stream, k.part, nblk, (int)nout, g_weight, khw, d->Cin, cl);
   return hipGetLastError() == hipSuccess ? LSI_OK : LSI_ELAUNCH;
 }

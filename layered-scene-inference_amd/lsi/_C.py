@@ -123,7 +123,7 @@ SIGNATURES = {
     'lsi_conv2d_bwd_data_bnstats': (ctypes.c_int, [_CP] + [_VP] * 4 + [_I32, _VP]),
     'lsi_conv2d_fwd_cat': (ctypes.c_int, [_CP, _VP, _VP, _I32, _VP, _VP, _VP, _I32, _VP]),
     'lsi_conv2d_bwd_data_cat': (ctypes.c_int, [_CP, _VP, _VP, _VP, _VP, _I32, _VP]),
-    'lsi_conv2d_wgrad_cat': (ctypes.c_int, [_CP, _VP, _VP, _I32, _VP, _VP, _VP, _SZ, _VP]),
+    'lsi_conv2d_wgrad_cat': (ctypes.c_int, [_CP, _VP, _VP, _I32, _VP, _VP, _I32, _VP, _SZ, _VP]),
     'lsi_conv2d_wgrad_workspace_bytes': (_SZ, [_CP]),
     'lsi_conv2d_wgrad': (ctypes.c_int, [_CP] + [_VP] * 4 + [_SZ, _VP]),
     'lsi_bn_workspace_floats': (_SZ, [_I64, _I32, _I32, _I32]),

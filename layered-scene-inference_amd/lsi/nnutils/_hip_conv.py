@@ -460,16 +460,25 @@ def _igemm_wgrad_bytes(d):
   return n
 
 
-def _igemm_wgrad(d, x, gy, weight):
-  """lsi_conv2d_wgrad: x = the descriptor's input tensor, gy its output gradient."""
+def _igemm_wgrad(d, x, gy, weight, x2=None):
+  """lsi_conv2d_wgrad[_cat]: x (and x2: the input as two tensors) = the
+  descriptor's input, gy its output gradient.  The gradient comes out in the
+  parameter's own memory layout (contiguous or channels-last strides), so that
+  autograd's accumulation takes it as it is instead of cloning it into that
+  layout (one copy kernel per parameter and step)."""
   dev = x.device
   nbytes = _igemm_wgrad_bytes(d)
   ws = _wgrad_workspace(dev, nbytes)
-  gw = torch.empty(tuple(weight.shape), dtype=torch.float32, device=dev)
-  rc = _C.lib().lsi_conv2d_wgrad(ctypes.byref(d), x.data_ptr(), gy.data_ptr(), gw.data_ptr(),
-                                 ws.data_ptr(), ws.numel() * 4, _C.stream_ptr(dev))
+  cl = 2 if (weight.dim() == 4 and not weight.is_contiguous() and
+             weight.is_contiguous(memory_format=torch.channels_last)) else 0
+  gw = torch.empty(tuple(weight.shape), dtype=torch.float32, device=dev,
+                   memory_format=torch.channels_last if cl else torch.contiguous_format)
+  rc = _C.lib().lsi_conv2d_wgrad_cat(
+      ctypes.byref(d), x.data_ptr(), x2.data_ptr() if x2 is not None else 0,
+      x.shape[1] if x2 is not None else 0, gy.data_ptr(), gw.data_ptr(), cl, ws.data_ptr(),
+      ws.numel() * 4, _C.stream_ptr(dev))
   if rc:
-    _C.check(rc, 'lsi_conv2d_wgrad')
+    _C.check(rc, 'lsi_conv2d_wgrad_cat')
   return gw if weight.dtype == torch.float32 else gw.to(weight.dtype)
 
 
@@ -594,16 +603,7 @@ class _Conv2dCatIgemm(torch.autograd.Function):
       if rc:
         _C.check(rc, 'lsi_conv2d_bwd_data_cat')
     if ctx.needs_input_grad[2]:
-      nbytes = _igemm_wgrad_bytes(d)
-      ws = _wgrad_workspace(dev, nbytes)
-      gw = torch.empty(tuple(weight.shape), dtype=torch.float32, device=dev)
-      rc = lib.lsi_conv2d_wgrad_cat(ctypes.byref(d), x1.data_ptr(), x2.data_ptr(), c1,
-                                    g.data_ptr(), gw.data_ptr(), ws.data_ptr(),
-                                    ws.numel() * 4, _C.stream_ptr(dev))
-      if rc:
-        _C.check(rc, 'lsi_conv2d_wgrad_cat')
-      if weight.dtype != torch.float32:
-        gw = gw.to(weight.dtype)
+      gw = _igemm_wgrad(d, x1, g, weight, x2)
     return gx1, gx2, gw, None, None, None, None, None, None
 
 

@@ -497,3 +497,24 @@ def test_packs_of_channels_last_parameters_and_of_silent_updates(dev):
   assert _hip_conv.repack_all(dev) >= 2
   y3 = _hip_conv.conv2d(x, wc, 1, 1, 1, 10, 12)
   assert float((y3.float() - y0.float()).abs().max()) <= float(y0.float().abs().max()) * 2.0 ** -6
+
+
+def test_weight_gradient_comes_in_the_parameters_layout(dev):
+  """lsi_conv2d_wgrad_cat(weight_layout=2): the gradient of a channels-last
+  parameter has its strides (autograd then takes it instead of cloning it) and
+  the values of the contiguous one -- plain and two-tensor input, narrow and wide
+  layers (the two folds)."""
+  from lsi.nnutils import _hip_conv
+  g = torch.Generator().manual_seed(41)
+  for (n, c1, c2, h, w, cout, k) in [(2, 64, 0, 12, 20, 32, 3), (2, 64, 32, 9, 17, 64, 3),
+                                     (4, 512, 0, 4, 12, 512, 3), (1, 32, 0, 11, 33, 32, 7)]:
+    mk = lambda c: _clast(torch.randn((n, c, h, w), generator=g).to(dev).to(torch.bfloat16))
+    x1 = mk(c1); x2 = mk(c2) if c2 else None
+    w0 = (torch.randn((cout, c1 + c2, k, k), generator=g) * 0.1).to(dev)
+    wc = w0.clone().contiguous(memory_format=torch.channels_last)
+    gy = mk(cout)
+    d = _hip_conv._conv_desc(n, h, w, c1 + c2, h, w, cout, k, k, 1, k // 2, k // 2)
+    a = _hip_conv._igemm_wgrad(d, x1, gy, w0, x2)
+    b = _hip_conv._igemm_wgrad(d, x1, gy, wc, x2)
+    assert a.is_contiguous() and b.stride() == wc.stride()
+    assert float((a - b).abs().max()) <= 1e-6 * float(a.abs().max())
