@@ -446,11 +446,11 @@ def test_own_convolutions_follow_the_librarys_training_trajectory(tmp_path, buil
   runs = {}
   for own in (True, False):
     monkeypatch.setattr(nets, 'IGEMM_CONV', own)
-    tr = _trainer(tmp_path / ('own' if own else 'lib'), bf16='true', learning_rate=1e-3)
+    tr = _trainer(tmp_path / ('own' if own else 'lib'), bf16='true')
     batch = tr.feed()
     tr.feed = lambda batch=batch: batch
     runs[own] = [float(tr.train_step()[0]) for _ in range(8)]
   a, b = runs[True], runs[False]
   assert a[-1] < a[0] and b[-1] < b[0]
   for x, y in zip(a, b):
-    assert abs(x - y) <= 8e-2 * abs(y), (a, b)   # (bf16 noise at this step size: up to 4 %)
+    assert abs(x - y) <= 2e-2 * abs(y), (a, b)   # (the tolerance of the graph-vs-eager test)
