@@ -325,43 +325,62 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgArgs a) {
 // (d0, d1) per tap through LDS, so that reads and (transposed) writes are both
 // contiguous runs.
 typedef LsiPackJob PackArgs;   // {w, dst, D0, D1, khw, tr, ntaps, block0, tap[]}
+// PACK_TC taps per round: their 4 x PACK_TC loads per thread are in flight
+// together and a round costs one pair of barriers (one tap per round was 338 us
+// for the 36 M parameters x 2 directions of the networks: a chain of load
+// latencies; the trainer packs after every optimiser step).
+constexpr int PACK_TC = 8;
 __device__ __forceinline__ void pack_tile(const PackArgs& a, int bx, int by,
-                                          float (*tile)[33]) {
+                                          float (*tile)[32][33]) {
   const int a0 = by * 32, b0 = bx * 32;
   const int c = threadIdx.x & 31, r0 = threadIdx.x >> 5;
   const size_t per = (size_t)a.D0 * a.D1;
   __bf16* const dst = reinterpret_cast<__bf16*>(a.dst);
-  for (int t = 0; t < a.ntaps; ++t) {
-    const int tap = a.tap[t];
+  for (int t0 = 0; t0 < a.ntaps; t0 += PACK_TC) {
+    float v[PACK_TC][4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int r = r0 + 8 * j;
-      // (the parameter D0 x D1 x KH x KW as torch stores it: contiguous, or --
-      // tr & 2 -- channels-last strides, D0 x KH x KW x D1 in memory: what
-      // module.to(memory_format=torch.channels_last) leaves)
-      tile[r][c] = (a.tr & 2) ? a.w[((size_t)(a0 + r) * a.khw + tap) * a.D1 + b0 + c]
+    for (int tt = 0; tt < PACK_TC; ++tt) {
+      const int tap = a.tap[min(t0 + tt, a.ntaps - 1)];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = r0 + 8 * j;
+        // (the parameter D0 x D1 x KH x KW as torch stores it: contiguous, or --
+        // tr & 2 -- channels-last strides, D0 x KH x KW x D1 in memory: what
+        // module.to(memory_format=torch.channels_last) leaves)
+        v[tt][j] = (a.tr & 2) ? a.w[((size_t)(a0 + r) * a.khw + tap) * a.D1 + b0 + c]
                               : a.w[((size_t)(a0 + r) * a.D1 + b0 + c) * a.khw + tap];
+      }
     }
+#pragma unroll
+    for (int tt = 0; tt < PACK_TC; ++tt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) tile[tt][r0 + 8 * j][c] = v[tt][j];
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int r = r0 + 8 * j;
-      if (a.tr & 1)   // dst[t][d1][d0]
-        dst[(size_t)t * per + (size_t)(b0 + r) * a.D0 + a0 + c] = (__bf16)tile[c][r];
-      else        // dst[t][d0][d1]
-        dst[(size_t)t * per + (size_t)(a0 + r) * a.D1 + b0 + c] = (__bf16)tile[r][c];
+    for (int tt = 0; tt < PACK_TC; ++tt) {
+      const int t = t0 + tt;
+      if (t < a.ntaps) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int r = r0 + 8 * j;
+          if (a.tr & 1)   // dst[t][d1][d0]
+            dst[(size_t)t * per + (size_t)(b0 + r) * a.D0 + a0 + c] = (__bf16)tile[tt][c][r];
+          else        // dst[t][d0][d1]
+            dst[(size_t)t * per + (size_t)(a0 + r) * a.D1 + b0 + c] = (__bf16)tile[tt][r][c];
+        }
+      }
     }
     __syncthreads();
   }
 }
 __global__ __launch_bounds__(256) void conv_pack_kernel(PackArgs a) {
-  __shared__ float tile[32][33];
+  __shared__ float tile[PACK_TC][32][33];
   pack_tile(a, blockIdx.x, blockIdx.y, tile);
 }
 // Many layers in one launch: job j owns blocks [block0_j, block0_{j+1}) (the
 // table lives in device memory; the last entry's block0 + its blocks = grid).
 __global__ __launch_bounds__(256) void conv_pack_many_kernel(const PackArgs* jobs, int njobs) {
-  __shared__ float tile[32][33];
+  __shared__ float tile[PACK_TC][32][33];
   __shared__ int which;
   if (threadIdx.x == 0) {
     int j = 0;
