@@ -209,3 +209,21 @@ def test_host_copy_of_cameras_follows_the_tensor_not_its_address():
   assert ldi._host_copy(k64).dtype == torch.float32
   # (the cache is only used for GPU tensors; CPU tensors are converted per call)
   assert not ldi._HOST_COPIES
+
+
+def test_pack_layout_of_parameters():
+  """Which parameter memory layouts lsi_conv2d_pack reads in place (the
+  trainer's model is channels_last: its k x k parameters have channels-last
+  strides, which round 5 once skipped) and which need a copy."""
+  import torch
+  from lsi.nnutils import _hip_conv
+  w = torch.zeros((8, 4, 3, 3))
+  assert _hip_conv._pack_layout(w) == 0
+  wc = w.contiguous(memory_format=torch.channels_last)
+  assert not wc.is_contiguous() and _hip_conv._pack_layout(wc) == 2
+  assert _hip_conv._pack_layout(w.to(torch.bfloat16)) is None
+  assert _hip_conv._pack_layout(w[:, :2]) is None            # a slice: neither layout
+  assert _hip_conv._pack_layout(torch.zeros((8, 4, 1, 1)).contiguous(
+      memory_format=torch.channels_last)) == 0               # 1 x 1: both at once
+  src, cl = _hip_conv._pack_source(w[:, :2])
+  assert cl == 0 and src.is_contiguous() and src.dtype == torch.float32
