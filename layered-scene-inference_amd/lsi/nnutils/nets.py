@@ -331,6 +331,23 @@ class SlimFC(nn.Module):
                                self.gamma, self.beta, False, 0.0, self.eps))
 
 
+def own_kernel_param_layouts(module):
+  """After module.to(memory_format=torch.channels_last): the 3 x 3 layers over 32
+  channels (`upcnv1b`, the `pred_l` heads) go back to contiguous parameters --
+  their kernels (csrc/lsi_conv.hip, lsi_conv_wgrad.hip) read the fp32 parameter
+  itself and return its gradient contiguously; with channels-last strides every
+  call made a contiguous copy first and autograd cloned every gradient into the
+  parameter's layout (about 40 small kernels per 4-layer step).  The
+  implicit-GEMM layers take either layout (_hip_conv._pack_layout)."""
+  for m in module.modules():
+    if (isinstance(m, SlimConv2d) and m.k == 3 and m.stride == 1 and
+        m.conv.weight.shape[1] == 32 and
+        (m.conv.weight.shape[0] in (16, 32) or m.bn is None)):
+      with torch.no_grad():
+        m.conv.weight.data = m.conv.weight.data.contiguous()
+  return module
+
+
 def set_is_training(module, is_training):
   """slim's `is_training` switch for every batch norm below `module`."""
   for m in module.modules():

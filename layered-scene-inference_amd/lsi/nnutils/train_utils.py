@@ -105,6 +105,9 @@ class Trainer(object):
     self.model = self.build_model().to(self.device)
     if getattr(opts, 'channels_last', False):
       self.model = self.model.to(memory_format=torch.channels_last)
+      if use_gpu:
+        from lsi.nnutils import nets  # pylint: disable=g-import-not-at-top
+        nets.own_kernel_param_layouts(self.model)
     self.train_model = self.model
     # --hip_graph: the step (about 1500 kernels eagerly) is captured once into
     # HIP graphs and replayed.  One process: one graph (forward, losses,
