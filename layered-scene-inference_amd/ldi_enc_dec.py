@@ -336,8 +336,25 @@ class Trainer(train_utils.Trainer):
     def ones_like_mask(l):
       return l[1] if l[1] is not None else torch.ones_like(l[2])
 
+    # The network's output is one buffer of 2 B LDIs (source views, then target
+    # views) whose halves `ldi_src` / `ldi_trg` are views of it.  A loss taken on
+    # a half sends its gradient back through a slice: autograd fills a zero
+    # tensor of the whole buffer per half and adds them up (texture, masks,
+    # disparities: a dozen kernels over 25 - 100 MB each per step).  Every term
+    # below is a mean over the batch, so the term of the pair is twice the mean
+    # over the 2 B LDIs: one call per term on the whole buffer, no slices.
+    pair = getattr(getattr(self, 'model', None), 'pair_ldi', None)
+    paired = (pair is not None and getattr(opts, 'paired_splat', True) and
+              not (opts.debug_synth_texture and len(staged) >= 6))
+
     # self-consistency (ldi_enc_dec.py:269-294)
-    if opts.l0_self_cons:
+    if paired and not opts.l0_self_cons:
+      self_cons_loss = 2.0 * loss.zbuffer_composition_loss(
+          pair[0], ones_like_mask(pair), pair[2],
+          torch.cat([imgs_src, imgs_trg], dim=0),
+          zbuf_scale=opts.zbuf_scale, bg_layer_disp=opts.bg_layer_disp,
+          max_disp=opts.max_disp)
+    elif opts.l0_self_cons:
       sc_src = torch.mean(torch.abs(imgs_src - ldi_src[0][0]))
       sc_trg = torch.mean(torch.abs(imgs_trg - ldi_trg[0][0]))
     else:
@@ -349,7 +366,8 @@ class Trainer(train_utils.Trainer):
           ldi_trg[0], ones_like_mask(ldi_trg), ldi_trg[2], imgs_trg,
           zbuf_scale=opts.zbuf_scale, bg_layer_disp=opts.bg_layer_disp,
           max_disp=opts.max_disp)
-    self_cons_loss = sc_src + sc_trg
+    if not (paired and not opts.l0_self_cons):
+      self_cons_loss = sc_src + sc_trg
 
     # view synthesis via forward splatting (ldi_enc_dec.py:296-357)
     zero = imgs_src.new_zeros(())
@@ -357,10 +375,7 @@ class Trainer(train_utils.Trainer):
     # One sweep per direction renders the per-layer AND the composed view
     # (the reference makes four forward_splat calls whose per-layer splats
     # are identical pairwise).
-    pair = getattr(getattr(self, 'model', None), 'pair_ldi', None)
-    if (pair is not None and getattr(opts, 'paired_splat', True) and
-        not (opts.debug_synth_texture and len(staged) >= 6) and
-        (opts.indep_splat_wt > 0 or opts.compose_splat_wt > 0)):
+    if paired and (opts.indep_splat_wt > 0 or opts.compose_splat_wt > 0):
       # Both directions of the pair from ONE launch (and one in the backward):
       # the network's output is one buffer of 2 B LDIs -- the B source views'
       # then the B target views' -- so the src -> trg and the trg -> src
@@ -402,10 +417,15 @@ class Trainer(train_utils.Trainer):
     # regularisers (ldi_enc_dec.py:388-396): both from one read of each
     # disparity tensor (fused HIP kernel lsi_disp_reg_loss_fwd)
     from lsi.loss import _hip as loss_hip  # pylint: disable=g-import-not-at-top
-    sm_s, dc_s = loss_hip.disp_regularisers(ldi_src[2])
-    sm_t, dc_t = loss_hip.disp_regularisers(ldi_trg[2])
-    disp_smoothness_loss = sm_s + sm_t
-    incr_depth_loss = (dc_s + dc_t) if opts.n_layers > 1 else zero
+    if paired:
+      sm_p, dc_p = loss_hip.disp_regularisers(pair[2])
+      disp_smoothness_loss = 2.0 * sm_p
+      incr_depth_loss = 2.0 * dc_p if opts.n_layers > 1 else zero
+    else:
+      sm_s, dc_s = loss_hip.disp_regularisers(ldi_src[2])
+      sm_t, dc_t = loss_hip.disp_regularisers(ldi_trg[2])
+      disp_smoothness_loss = sm_s + sm_t
+      incr_depth_loss = (dc_s + dc_t) if opts.n_layers > 1 else zero
 
     total = zero
     if opts.self_cons_wt > 0:
