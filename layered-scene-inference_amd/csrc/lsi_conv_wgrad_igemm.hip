@@ -59,8 +59,14 @@ struct GwArgs {
   int N, H, W, Cin, OH, OW, Cout;
   int khw, ntaps, ntg;        // kernel taps; tap groups of GW_GT
   int dy0, dx0, PH, PW, TH;   // patch origin (smallest dy, dx), size; tile rows per stage
-  int nstrip, nrowblk, RB;
-  int NI;             // images per pixel block (small maps: all of them -- no partial sums to fold)
+  int nstrip;
+  // Stages = (image, TH output rows) of a 32-column strip; the strip's N * nrs
+  // stages are dealt to its PS workgroups round-robin (workgroup p: stages p,
+  // p + PS, ...), PS chosen so that ALL workgroups of the launch are resident at
+  // once (two per CU by registers: 512) -- a grid of 576 or 768 workgroups was two
+  // rounds of the chip for 1.1 - 1.5 rounds of work.  Every workgroup writes one
+  // partial sum (nstrip * PS of them to fold).
+  int nrs, PS;
   signed char tdy[GW_MAXTAPS + 3], tdx[GW_MAXTAPS + 3];
 };
 
@@ -90,15 +96,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_igemm_kernel(GwArgs a) {
   __bf16* const xs = reinterpret_cast<__bf16*>(gw_smem);
   __bf16* const gs = xs + (size_t)npix * XS;
 
-  int pb = blockIdx.x;
-  const int rb = pb % a.nrowblk;
-  pb /= a.nrowblk;
-  const int st = pb % a.nstrip, n = (pb / a.nstrip) * a.NI;
-  const int n_end = min(a.N, n + a.NI);
+  const int st = blockIdx.x % a.nstrip, slot = blockIdx.x / a.nstrip;
+  const int n = 0;   // (goff below is relative to image 0; `shift` adds the image)
   const int tg = blockIdx.y % a.ntg, c0 = (blockIdx.y / a.ntg) * 32;
   const int o0 = blockIdx.z * BN;
   const int t0 = tg * GW_GT, nt = min(GW_GT, a.ntaps - t0);
-  const int i_beg = rb * a.RB, i_end = min(a.OH, i_beg + a.RB), j0 = st * 32;
+  const int i_end = a.OH, j0 = st * 32;
+  const int nstage = a.N * a.nrs;
 
   // patch pieces of this thread (pixel, quarter of the 32 channels): row of the
   // patch and element offset for the block's first stage; -1: column outside
@@ -139,8 +143,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_igemm_kernel(GwArgs a) {
       poff[j] = ((a.tdy[t0 + tl] - a.dy0) * PW + (a.tdx[t0 + tl] - a.dx0)) * XS + 16 * c;
   }
 
-  for (int ni = n; ni < n_end; ++ni)
-  for (int i0 = i_beg; i0 < i_end; i0 += TH) {
+  for (int sg = slot; sg < nstage; sg += a.PS) {
+    const int ni = sg / a.nrs, i0 = (sg - ni * a.nrs) * TH;
     __syncthreads();  // (the previous stage's fragments have been read)
     // ---- input patch: rows i0 * S + dy0 + py ---------------------------------
     {
@@ -347,32 +351,18 @@ bool gw_plan(const LsiConvDesc* d, GwArgs& k, int* nct_out, size_t* lds_out, int
   if (!th) return false;
   k.TH = th;
   k.nstrip = (d->OW + 31) / 32;
-  // rows per pixel block: enough workgroups for the chip, partial sums bounded
+  // workgroups per strip: as many as keep the whole launch resident (512 = two per
+  // CU), at most one per stage, partial sums bounded
   const long chan_wgs = (long)(d->Cin / 32) * k.ntg * (d->Cout / bn);
   const size_t wbytes = (size_t)d->Cout * d->Cin * k.khw * sizeof(float);
-  int rb = d->OH;
-  // images per pixel block: all of them while the channel blocks alone fill the
-  // chip (the bottleneck layers: 512 - 1024 channels on 2 x 6 ... 8 x 24 maps --
-  // one block, nothing to fold), fewer until there are enough workgroups
-  int ni = d->N;
-  while (ni > 1 && (long)((d->N + ni - 1) / ni) * k.nstrip * chan_wgs < 192) ni = (ni + 1) / 2;
-  while (ni < d->N && (size_t)((d->N + ni - 1) / ni) * k.nstrip * wbytes > GW_PART_CAP) ni *= 2;
-  if (ni > d->N) ni = d->N;
-  k.NI = ni;
-  const long nimg = (d->N + ni - 1) / ni;
-  for (;;) {
-    const long nrb = (d->OH + rb - 1) / rb;
-    const long nblk = nimg * k.nstrip * nrb;
-    if (nblk * chan_wgs >= 512 || rb <= th) break;
-    const int half = ((rb / 2 + th - 1) / th) * th;
-    if (half >= rb) break;
-    const long nblk2 = nimg * k.nstrip * ((d->OH + half - 1) / half);
-    if ((size_t)nblk2 * wbytes > GW_PART_CAP) break;
-    rb = half;
-  }
-  k.RB = rb;
-  k.nrowblk = (d->OH + rb - 1) / rb;
-  const long nblk = nimg * k.nstrip * k.nrowblk;
+  k.nrs = (d->OH + th - 1) / th;
+  const long nstage = (long)d->N * k.nrs;
+  long ps = 512 / (chan_wgs * k.nstrip);
+  if (ps < 1) ps = 1;
+  if (ps > nstage) ps = nstage;
+  while (ps > 1 && (size_t)(ps * k.nstrip) * wbytes > GW_PART_CAP) --ps;
+  k.PS = (int)ps;
+  const long nblk = ps * k.nstrip;
   if ((size_t)nblk * wbytes > GW_PART_CAP || nblk > 65535 * 32L) return false;
   *nblk_out = (int)nblk;
   *nct_out = nct;
