@@ -37,6 +37,7 @@
 // multiplies.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -486,6 +487,13 @@ int ig_launch(IgArgs& k, hipStream_t stream) {
 #undef IG_CASES
 #undef IG_CASE
   if (!fn) return LSI_EINVAL;
+  {
+    static const char* dbg = getenv("LSI_IG_DEBUG");   // (experiments: the plan of every call)
+    if (dbg)
+      fprintf(stderr, "ig N%d %dx%d cin %d cout %d s%d os%d ncls %d taps %d: RW %d NCT %d G %d grid %u x %u x %u = %u WGs, lds %zu\n",
+              k.N, k.H, k.W, k.Cin, k.Cout, k.s, k.os, k.ncls, k.cls[0].ntaps, rw, nct, k.G, grid.x, grid.y,
+              grid.z, grid.x * grid.y * grid.z, lds);
+  }
   if (lsi_ensure_dynamic_lds(fn, lds) != LSI_OK) return LSI_ELAUNCH;
   void* kargs[1] = {&k};
   if (hipLaunchKernel(fn, grid, dim3(256), kargs, lds, stream) != hipSuccess) return LSI_ELAUNCH;
