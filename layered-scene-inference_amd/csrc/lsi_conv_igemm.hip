@@ -427,6 +427,14 @@ bool ig_shape(IgArgs& k, int* rw_out, int* nct_out, size_t* lds_out) {
     if (rw == 8 && (long)((maxoh + 31) / 32) * ((k.cls[0].OWt + 15) / 16) * k.N * k.ncls *
                            (k.Cout / bn) < 1024)
       continue;
+    // (... and shorter tiles while the launch would leave CUs without a
+    // workgroup: `icnv5` 512 -> 256 at 16 x 48 had 96 workgroups of 16 rows,
+    // 58 us; 192 of 8 rows: 40 us)
+    static const char* fill_env = getenv("LSI_IGEMM_MINWG");   // experiments
+    const long min_wg = fill_env ? atol(fill_env) : 256;
+    if (rw > 1 && (long)((maxoh + 4 * rw - 1) / (4 * rw)) * ((k.cls[0].OWt + 15) / 16) * k.N *
+                          k.ncls * (k.Cout / bn) < min_wg)
+      continue;
     const int th = 4 * rw;
     k.PH = (th - 1) * k.s + spany;
     const size_t patch = (size_t)k.PH * k.PW * IG_PIX;
