@@ -66,6 +66,7 @@ struct WgradArgs {
   float* part;       // [pixel blocks][Cout][Cin][9]
   int N, H, W, Cin, Cout;
   int nstrip, nrowblk;
+  int rows;   // rows per pixel block (>= WG_ROWS: the workspace is sized for WG_ROWS)
   // PRED (the prediction head, 32 -> cout <= 4 + bias + sigmoid): gy = g y (1 - y)
   // is formed while the row is staged, from the incoming gradient and the saved
   // output (fp32 RGBD pixels, N x H x W x 4)
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_wgrad_kernel(WgradArgs a) {
   const int rb = pb % a.nrowblk;
   pb /= a.nrowblk;
   const int st = pb % a.nstrip, n = pb / a.nstrip;
-  const int x0 = st * SW, y0 = rb * WG_ROWS, y1 = min(a.H, y0 + WG_ROWS);
+  const int x0 = st * SW, y0 = rb * a.rows, y1 = min(a.H, y0 + a.rows);
   const int c0 = blockIdx.y * (CIB * 16);  // first input channel
   const int o0 = blockIdx.z * (CO16 * 16);  // first output channel
   static_assert(!PRED || (CO16 == 1 && SW <= T), "PRED: one tile of output channels, a thread per pixel");
@@ -350,6 +351,7 @@ int lsi_pred_wgrad_launch(int N, int H, int W, int cout, const float* g, const f
   a.part = reinterpret_cast<float*>(workspace);
   a.N = N; a.H = H; a.W = W; a.Cin = 32; a.Cout = cout;
   a.nstrip = (W + WG_SW - 1) / WG_SW;
+  a.rows = WG_ROWS;
   a.nrowblk = (H + WG_ROWS - 1) / WG_ROWS;
   const int nblk = pixel_blocks(N, H, W), nout = cout * 288 + cout;
   hipLaunchKernelGGL((conv3x3_wgrad_kernel<1, 4, WG_SW, true>), dim3(nblk), dim3(256), 0, stream,
@@ -384,8 +386,26 @@ extern "C" int lsi_conv3x3_wgrad(int32_t N, int32_t H, int32_t W, int32_t cin, i
   a.g = a.yf = nullptr;
   a.N = N; a.H = H; a.W = W; a.Cin = cin; a.Cout = cout;
   a.nstrip = (W + WG_SW - 1) / WG_SW;
-  a.nrowblk = (H + WG_ROWS - 1) / WG_ROWS;
-  const int nblk = pixel_blocks(N, H, W);
+  // Rows per pixel block: WG_ROWS, or more when that brings the launch down to
+  // what is resident at once (the 8-wave build: two workgroups per CU, 512; the
+  // 4-wave build: four, 1024) -- `upcnv2b` (96 -> 64 at 128 x 384) was 576
+  // workgroups: two rounds of the chip for 1.1 rounds of work.
+  {
+    const long per_blk = (long)(cin / 32) * (cout % 64 ? cout / 32 : cout / 64);
+    const long resident = (cout % 64) ? 1024 : 512;
+    int rows = WG_ROWS;
+    const long strips = (long)N * a.nstrip;
+    while (rows < H && strips * ((H + rows - 1) / rows) * per_blk > resident &&
+           strips * per_blk <= resident)
+      ++rows;
+    // (the smallest number of row blocks that fits, then rows evened out)
+    const int nrb = (H + rows - 1) / rows;
+    rows = (H + nrb - 1) / nrb;
+    if (rows < WG_ROWS) rows = WG_ROWS;
+    a.rows = rows;
+  }
+  a.nrowblk = (H + a.rows - 1) / a.rows;
+  const int nblk = N * a.nstrip * a.nrowblk;
   if (cout % 64 != 0)
     hipLaunchKernelGGL((conv3x3_wgrad_kernel<2, 4, WG_SW>), dim3(nblk, cin / 32, cout / 32),
                        dim3(256), 0, (hipStream_t)stream, a);
