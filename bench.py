@@ -626,7 +626,16 @@ def main():
   world = int(os.environ.get('WORLD_SIZE', '1'))
   if args.gpus > 1 and 'RANK' not in os.environ:
     # bare `python bench.py --gpus N`: become the launcher (one rank per GPU)
-    sys.exit(subprocess.call(self_launch_argv(sys.argv[1:], args.gpus)))
+    # (the port was free a moment ago; if another process took it before the
+    # rendezvous bound it -- EADDRINUSE -- once more on a fresh one)
+    for _ in range(4):
+      res = subprocess.run(self_launch_argv(sys.argv[1:], args.gpus), stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, text=True)
+      if res.returncode == 0 or 'EADDRINUSE' not in res.stderr:
+        break
+    sys.stdout.write(res.stdout)
+    sys.stderr.write(res.stderr)
+    sys.exit(res.returncode)
   rank = int(os.environ.get('RANK', '0'))
   local_rank = int(os.environ.get('LOCAL_RANK', '0'))
   if args.gpus > 1 and world != args.gpus:

@@ -23,6 +23,21 @@ def _free_port():
   return port
 
 
+def _torchrun(nproc, bench_args, env):
+  """`python -m torch.distributed.run ... bench.py` on a port that was free a
+  moment ago; another process may take it before the rendezvous binds it
+  (EADDRINUSE: seen once in a suite run) -- then once more on a fresh port."""
+  for _ in range(4):
+    out = subprocess.run(
+        [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+         '--nproc-per-node', str(nproc), '--master-addr', '127.0.0.1', '--master-port',
+         str(_free_port()), os.path.join(ROOT, 'bench.py')] + bench_args,
+        env=env, capture_output=True, text=True, timeout=900)
+    if out.returncode == 0 or 'EADDRINUSE' not in out.stderr:
+      break
+  return out
+
+
 def _one_json_line(out):
   lines = [l for l in out.stdout.splitlines() if l.strip()]
   assert len(lines) == 1, out.stdout[-2000:] + out.stderr[-2000:]
@@ -56,13 +71,8 @@ def test_bench_line_as_a_rank_of_torch_distributed_run(built_lib):
     pytest.fail('gpu test selected but no ROCm device is visible')
   env = {k: v for k, v in os.environ.items()
          if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
-  out = subprocess.run(
-      [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
-       '--nproc-per-node', '1', '--master-addr', '127.0.0.1', '--master-port',
-       str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps',
-       '5', '--warmup', '2', '--workload', 'cfg2', '--no-cpu-baseline',
-       '--no-extra', '--traffic', 'off'],
-      env=env, capture_output=True, text=True, timeout=900)
+  out = _torchrun(1, ['--gpus', '1', '--steps', '5', '--warmup', '2', '--workload', 'cfg2',
+                      '--no-cpu-baseline', '--no-extra', '--traffic', 'off'], env)
   assert out.returncode == 0, out.stderr[-2000:]
   rec = _one_json_line(out)
   assert rec['n_gpus'] == 1 and rec['scaling'] == 'weak'
@@ -82,12 +92,8 @@ def test_two_ranks_split_the_batch_and_add_the_weak_figure(built_lib):
   env = {k: v for k, v in os.environ.items()
          if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
   env['LSI_BENCH_SHARE_GPU'] = '1'
-  out = subprocess.run(
-      [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
-       '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port',
-       str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps',
-       '5', '--warmup', '2', '--no-cpu-baseline', '--no-extra', '--traffic', 'off'],
-      env=env, capture_output=True, text=True, timeout=900)
+  out = _torchrun(2, ['--gpus', '2', '--steps', '5', '--warmup', '2', '--no-cpu-baseline',
+                      '--no-extra', '--traffic', 'off'], env)
   assert out.returncode == 0, out.stderr[-3000:]
   rec = _one_json_line(out)
   assert rec['n_gpus'] == 2 and rec['scaling'] == 'strong'

@@ -22,6 +22,19 @@ def _free_port():
   return port
 
 
+def _spawn(fn, args_of_port, nprocs):
+  """mp.spawn on a port that was free a moment ago; if another process took it
+  before the rendezvous bound it (EADDRINUSE), once more on a fresh one."""
+  for attempt in range(4):
+    try:
+      return mp.spawn(fn, args=args_of_port(_free_port()), nprocs=nprocs, join=True)
+    except Exception as e:  # pylint: disable=broad-except
+      if 'EADDRINUSE' not in str(e) and 'address already in use' not in str(e).lower():
+        raise
+      if attempt == 3:
+        raise
+
+
 def _worker(rank, world, port, out):
   sys.path.insert(0, ROOT)
   sys.path.insert(0, os.path.join(ROOT, 'layered-scene-inference_amd'))
@@ -54,7 +67,7 @@ def test_two_rank_gloo_sharding_and_timing_reduction():
   world = 2
   mgr = mp.Manager()
   out = mgr.dict()
-  mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+  _spawn(_worker, lambda port: (world, port, out), world)
   r0, r1 = out[0], out[1]
   assert r0['cfg2'] == (4, 'weak') and r1['cfg2'] == (4, 'weak')
   # default: the workload's batch split over the ranks (32 -> B/N) ...

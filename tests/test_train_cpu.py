@@ -154,6 +154,19 @@ def _free_port():
   return port
 
 
+def _spawn(fn, args_of_port, nprocs):
+  """mp.spawn on a port that was free a moment ago; if another process took it
+  before the rendezvous bound it (EADDRINUSE), once more on a fresh one."""
+  for attempt in range(4):
+    try:
+      return mp.spawn(fn, args=args_of_port(_free_port()), nprocs=nprocs, join=True)
+    except Exception as e:  # pylint: disable=broad-except
+      if 'EADDRINUSE' not in str(e) and 'address already in use' not in str(e).lower():
+        raise
+      if attempt == 3:
+        raise
+
+
 def _ddp_worker(rank, world, port, tmpdir, out, flat='false', complete='false'):
   os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
                     RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
@@ -176,16 +189,14 @@ def test_ddp_gradient_allreduce_two_gloo_ranks(tmp_path):
   world = 2
   mgr = mp.Manager()
   out = mgr.dict()
-  mp.spawn(_ddp_worker, args=(world, _free_port(), str(tmp_path), out),
-           nprocs=world, join=True)
+  _spawn(_ddp_worker, lambda port: (world, port, str(tmp_path), out), world)
   # different data shards, identical parameters after the all-reduced step
   assert out[0][2] != out[1][2]
   assert out[0][0] == out[1][0] and out[0][1] == out[1][1]
   # --flat_grads (the data-parallel step --hip_graph replays: no DDP wrapper,
   # every gradient a view of one buffer, one all-reduce): the same parameters
   out2 = mgr.dict()
-  mp.spawn(_ddp_worker, args=(world, _free_port(), str(tmp_path / 'flat'), out2,
-                              'true'), nprocs=world, join=True)
+  _spawn(_ddp_worker, lambda port: (world, port, str(tmp_path / 'flat'), out2, 'true'), world)
   assert out2[0][0] == out2[1][0] and out2[0][1] == out2[1][1]
   assert abs(out2[0][0] - out[0][0]) <= 1e-6 * abs(out[0][1])
   assert abs(out2[0][1] - out[0][1]) <= 1e-6 * abs(out[0][1])
@@ -199,8 +210,7 @@ def test_ddp_with_the_complete_tf_variable_list_two_gloo_ranks(tmp_path):
   world = 2
   mgr = mp.Manager()
   out = mgr.dict()
-  mp.spawn(_ddp_worker, args=(world, _free_port(), str(tmp_path), out, 'false',
-                              'true'), nprocs=world, join=True)
+  _spawn(_ddp_worker, lambda port: (world, port, str(tmp_path), out, 'false', 'true'), world)
   assert out[0][0] == out[1][0] and out[0][1] == out[1][1]
   script, opts = _opts(tmp_path / 'x', tf_checkpoint_complete='true')
   net = script.LdiNet(opts)
