@@ -164,6 +164,11 @@ class Renderer(object):
     self.ws = torch.zeros((max(self.ws_bytes, 16),), dtype=torch.uint8,
                           device=dev)
     self.desc.flags |= _C.LSI_WS_KEEP  # zero-filled once, kept by the library
+    # the caller-owned record of the adaptive build choice (LsiSplatDesc.adapt:
+    # what lsi.geometry.ldi.forward_splat passes, too; the library keeps no state)
+    self.adapt = ldi.stream_adapt(self.desc, dev)
+    if self.adapt is not None:
+      self.desc.adapt = ctypes.addressof(self.adapt.rec)
     self.fn = lib.lsi_splat_fwd
     self.dev = dev
 
@@ -508,6 +513,76 @@ def measure_traffic(args, timeout_s=150):
   return int((2.0 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024.0)
 
 
+MFMA_PEAK_TFLOPS = 2500.0  # MI355X dense bf16 matrix peak (MI355X_MICROARCH.md)
+# forward GFLOP of the network per IMAGE: U-Net + L heads; a
+# training sample is two images (source and target view), forward + both gradients
+TRAIN_CONFIGS = [
+    # name, n_layers, H, W, batch per GPU, forward GFLOP per image
+    ('L4_256x768_b4', 4, 256, 768, 4, 113.8),   # BASELINE config 3's model at its per-GPU batch
+    ('L2_256x768_b4', 2, 256, 768, 4, 67.8),    # BASELINE config 2
+    ('L3_256x256_b16', 3, 256, 256, 16, 30.3),  # BASELINE config 4's model
+]
+
+
+def train_step_extra(dev, budget_s, steps=8):
+  """the full training step -- network (bf16 convolutions on
+  the own MFMA kernels, fp32 accumulation), both directions' per-layer + composed
+  renderings and their backward, the six losses, fused Adam and the re-pack of
+  the weights -- as samples/s, eager and captured in a HIP graph, with the MFMA
+  roofline beside it: tflops = samples/s x 2 images x 3 (forward + two gradients)
+  x the forward GFLOP of SURVEY 8(d), against the dense bf16 peak.  Synthetic
+  pairs, random-init weights.  Bounded: a configuration is only started while
+  `budget_s` seconds are not used up."""
+  import ldi_enc_dec as script  # layered-scene-inference_amd/ldi_enc_dec.py
+  out = {'note': 'full train step (U-Net + heads bf16 on own MFMA kernels, 2 x '
+                 'forward_splat_both + backward, losses, fused Adam, weight re-pack); '
+                 'tflops = samples/s x 6 x forward GFLOP per image (SURVEY 8d); '
+                 'peak = %.0f TFLOP/s dense bf16; not part of `value`' % MFMA_PEAK_TFLOPS,
+         'configs': {}}
+  t_start = time.perf_counter()
+  for name, nl, h, w, b, gflop in TRAIN_CONFIGS:
+    if time.perf_counter() - t_start > budget_s:
+      out['configs'][name] = {'skipped': 'wall-time budget of %.0f s used up' % budget_s}
+      continue
+    res = {'n_layers': nl, 'hw': [h, w], 'batch': b, 'fwd_gflop_per_image': gflop}
+    for mode in ('graph', 'eager'):
+      if time.perf_counter() - t_start > budget_s:
+        res[mode] = {'skipped': 'wall-time budget used up'}
+        continue
+      try:
+        argv = ['--dataset', 'kitti', '--kitti_procedural', 'true', '--batch_size', str(b),
+                '--n_layers', str(nl), '--img_height', str(h), '--img_width', str(w),
+                '--checkpoint_dir', '/tmp/lsi_bench_ckpt', '--save_latest_freq', '1000000',
+                '--checkpoint_freq', '1000000', '--log_freq', '1000000', '--bf16', 'true',
+                '--hip_graph', 'true' if mode == 'graph' else 'false']
+        opts = script.apply_dataset_overrides(script.build_parser().parse_args(argv))
+        tr = script.Trainer(opts)
+        tr.local_rank = dev.index or 0
+        tr.setup()
+        for _ in range(tr.GRAPH_WARMUP + 2 if mode == 'graph' else 3):
+          total, _ = tr.train_step()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+          total, _ = tr.train_step()
+        torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t0) / steps
+        loss = float(total)
+        if not np.isfinite(loss):
+          raise RuntimeError('loss is not finite')
+        sps = b / dt
+        tf = sps * 6.0 * gflop / 1e3
+        res[mode] = {'samples_per_s': sps, 'ms_per_step': dt * 1e3, 'tflops': tf,
+                     'frac_of_mfma_peak': tf / MFMA_PEAK_TFLOPS, 'loss': loss}
+        del tr
+      except Exception as e:  # pylint: disable=broad-except
+        res[mode] = {'error': '%s: %s' % (type(e).__name__, e)}
+      torch.cuda.empty_cache()
+    out['configs'][name] = res
+  out['wall_s'] = time.perf_counter() - t_start
+  return out
+
+
 def build_renderer(workload, b_local, seed, dev, args):
   nl, h, w, batch, per_gpu, cams, max_disp, bg = WORKLOADS[workload]
   tex, disp, mat = make_inputs(nl, b_local, h, w, cams, max_disp, seed, dev,
@@ -595,6 +670,9 @@ def main():
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-extra', action='store_true',
                   help='skip the extras (backward, other workloads, traffic)')
+  ap.add_argument('--train-step-budget', type=float, default=45.0,
+                  help='seconds of wall time for extra.train_step (the full '
+                  'training step as samples/s and fraction of the MFMA peak); 0: skip')
   ap.add_argument('--traffic', default='measure', choices=['measure', 'off'],
                   help='roofline.traffic: two rocprofv3 --pmc passes of this '
                   'script (N=1 only), or null')
@@ -628,14 +706,33 @@ def main():
     # bare `python bench.py --gpus N`: become the launcher (one rank per GPU)
     # (the port was free a moment ago; if another process took it before the
     # rendezvous bound it -- EADDRINUSE -- once more on a fresh one)
-    for _ in range(4):
-      res = subprocess.run(self_launch_argv(sys.argv[1:], args.gpus), stdout=subprocess.PIPE,
-                           stderr=subprocess.PIPE, text=True)
-      if res.returncode == 0 or 'EADDRINUSE' not in res.stderr:
+    # The ranks' stderr is forwarded line by line as it comes (progress, and
+    # whatever a hang or a kill leaves behind, stay visible), and searched for
+    # the rendezvous error; stdout -- the one JSON line -- is held back until
+    # the attempt is known to be the last.
+    rc = 1
+    for attempt in range(4):
+      proc = subprocess.Popen(self_launch_argv(sys.argv[1:], args.gpus), stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True, bufsize=1)
+      taken = [False]
+
+      def pump(taken=taken, proc=proc):
+        for line in proc.stderr:
+          taken[0] = taken[0] or 'EADDRINUSE' in line
+          sys.stderr.write(line)
+          sys.stderr.flush()
+      import threading
+      th = threading.Thread(target=pump, daemon=True)
+      th.start()
+      child_out = proc.stdout.read()
+      rc = proc.wait()
+      th.join(timeout=10)
+      if rc == 0 or not taken[0]:
+        sys.stdout.write(child_out)
         break
-    sys.stdout.write(res.stdout)
-    sys.stderr.write(res.stderr)
-    sys.exit(res.returncode)
+      sys.stderr.write('bench.py: rendezvous port taken (attempt %d), once more on a fresh one\n'
+                       % (attempt + 1))
+    sys.exit(rc)
   rank = int(os.environ.get('RANK', '0'))
   local_rank = int(os.environ.get('LOCAL_RANK', '0'))
   if args.gpus > 1 and world != args.gpus:
@@ -829,6 +926,11 @@ def main():
         except Exception as e:  # pylint: disable=broad-except
           other[wl] = {'error': str(e)}
       extra['other_workloads'] = other
+      if args.train_step_budget > 0:
+        try:
+          extra['train_step'] = train_step_extra(dev, args.train_step_budget)
+        except Exception as e:  # pylint: disable=broad-except
+          extra['train_step'] = {'error': '%s: %s' % (type(e).__name__, e)}
       out['extra'] = extra
     if world == 1 and args.traffic == 'measure':
       out['roofline']['traffic'] = measure_traffic(args)

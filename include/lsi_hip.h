@@ -90,6 +90,22 @@ typedef void* lsi_stream_t; /* hipStream_t */
  * Ht = H * trg_downsampling and Wt = W * trg_downsampling must be integral
  * (the reference only works then: ldi.py:113-125).
  */
+/*
+ * Caller-owned state of the compact STREAM kernel's adaptive build choice (see
+ * lsi_stream_adapt_state below).  Zero-initialise, point ctr_dev at 16 bytes of
+ * device memory and ctr_host at 16 bytes of zeroed PINNED host memory, keep both
+ * alive as long as the record is used, and do not let two calls that use the
+ * same record overlap (one record per device, stream and call geometry).
+ */
+typedef struct LsiStreamAdapt {
+  int32_t state;      /* 0 undecided, 1 twelve waves x 2 sets, 2 sixteen x 1  */
+  int32_t pending;    /* a probe's counts are on their way to ctr_host        */
+  uint32_t seq;       /* that probe's number                                  */
+  uint32_t calls;
+  uint32_t* ctr_dev;            /* {folded items, all items, seq}: device     */
+  volatile uint32_t* ctr_host;  /* the same three words, pinned host memory   */
+} LsiStreamAdapt;
+
 typedef struct LsiSplatDesc {
   int32_t L, B, H, W, Ht, Wt;
   int64_t tex_sl, tex_sb, tex_sy, tex_sx, tex_sc;
@@ -106,6 +122,9 @@ typedef struct LsiSplatDesc {
   /* reserved: 0.  (tools/ set timing-experiment bits in it; results may then */
   /* be wrong -- see the `dbg` uses in csrc/lsi_splat_stream.hip.)            */
   int32_t tune_rows, tune_threads, tune_window, reserved;
+  /* NULL, or the caller's record for the adaptive build choice of the compact */
+  /* STREAM kernel (composed output): the library itself keeps no such state.  */
+  LsiStreamAdapt* adapt;
 } LsiSplatDesc;
 
 /* Library version (LSI_VERSION of the build). */
@@ -443,6 +462,15 @@ int lsi_bn_relu_bwd(const void* x, const void* dy, const float* mean_rstd,
 int lsi_bn_relu_norm(const void* x, void* y, const float* beta, float* workspace,
                      float* mean_rstd, int64_t npix, int32_t C, int32_t bf16, int32_t relu,
                      float eps, int32_t groups, lsi_stream_t stream);
+/* The hand-over between a producer of statistics and lsi_bn_relu_norm is checked
+ * on the device: the producer leaves a tag (C, groups) next to its sums, which
+ * lsi_bn_relu_norm requires and clears, and which lsi_bn_relu_fwd / _bwd require
+ * to be absent.  A call that finds the workspace in the other state writes NaN
+ * (y, mean_rstd / dx, dbeta) instead of numbers computed from somebody else's
+ * sums, and leaves the workspace clean.  lsi_bn_stats_discard drops statistics
+ * whose consumer will not run (an error between the two calls): the first
+ * 16 + 4096 floats of every group's block are zeroed on the stream. */
+int lsi_bn_stats_discard(float* workspace, int32_t groups, lsi_stream_t stream);
 
 /*
  * 3x3 stride-1 SAME convolution over 32 input channels on the matrix cores
@@ -508,18 +536,20 @@ int lsi_conv3x3_wgrad(int32_t N, int32_t H, int32_t W, int32_t cin, int32_t cout
 /*
  * The compact STREAM kernel has two builds (12 waves x two items in flight, 16 x
  * one); which is faster depends on the disparity field, which the planner does
- * not see.  The kernel counts the items that took its folded routes on a few
- * probe launches (the first calls of a geometry, then two of every 64); a later
- * call reads the count -- asynchronously copied to pinned host memory, never
- * waited for -- and picks the build.  This is the library's only state besides
- * memoised plans: per call geometry 16 bytes of device and of pinned host memory.
- * tune_threads != 0, LSI_S2_WIDE and LSI_S2_ADAPT=0 switch it off; launches
- * under stream capture use the standing decision.
- * lsi_stream_adapt_state: that decision for a descriptor prepared as for
- * lsi_splat_fwd (tune_window from lsi_stream_ok) on the current device:
- * 0 undecided, 1 twelve waves, 2 sixteen waves, -1 unknown geometry / off.
+ * not see.  With LsiSplatDesc.adapt set, the kernel counts the items that took
+ * its folded routes on a few probe launches (the first calls with the record,
+ * then two of every 64); a later call reads the count -- asynchronously copied
+ * to the record's pinned host memory, never waited for -- and picks the build.
+ * All of that state is the caller's record; with adapt == NULL a call is a pure
+ * function of its descriptor (the planner's choice: 12 x 2 for large launches).
+ * tune_threads != 0, LSI_S2_WIDE and LSI_S2_ADAPT=0 switch the mechanism off;
+ * launches under stream capture use the standing decision and probe nothing.
+ * Both builds render the same pixels (both are parity-tested); only timing
+ * depends on the record.
+ * lsi_stream_adapt_state: the record's standing decision after looking for a
+ * pending probe's counts: 0 undecided, 1 twelve waves, 2 sixteen waves, -1 NULL.
  */
-int lsi_stream_adapt_state(const LsiSplatDesc* d);
+int lsi_stream_adapt_state(LsiStreamAdapt* a);
 
 /*
  * Convolutions of the encoder-decoder and the LDI heads on the matrix cores
@@ -649,6 +679,35 @@ int lsi_conv2d_wgrad_cat(const LsiConvDesc* d, const void* x1, const void* x2, i
 size_t lsi_conv2d_wgrad_workspace_bytes(const LsiConvDesc* d);
 int lsi_conv2d_wgrad(const LsiConvDesc* d, const void* x, const void* gy, float* g_weight,
                      void* workspace, size_t workspace_bytes, lsi_stream_t stream);
+
+/*
+ * The networks' FIRST convolution (reference nets.py:273 `cnv1`, :53 in
+ * encoder_simple: slim.conv2d(inp_img, 32, [7, 7], stride=2), TF `SAME`, batch
+ * norm + ReLU behind it) on the matrix cores: d->Cin <= 4 (the image's 3
+ * channels), Cout = 32, 7 x 7, stride 2 -- anything else LSI_EUNSUPPORTED
+ * (lsi_conv2d_first_supported tells beforehand).  A pixel is padded to four
+ * channels in LDS and the K of one MFMA is a whole kernel row (7 taps x 4
+ * channels); no packed weights: the kernels read the fp32 parameter itself
+ * (weight_layout 0: contiguous Cout x Cin x KH x KW; 2: torch's channels-last
+ * strides) and round to bf16 as torch.autocast does.
+ *   x: the image, N x H x W x Cin with the channels innermost, fp32 (x_bf16 =
+ *   0: rounded to bf16 on the way in) or bf16 (1).  out: bf16 N x OH x OW x 32.
+ *   bn_workspace != NULL: the epilogue leaves the batch-norm sums of the rounded
+ *   outputs for lsi_bn_relu_norm (as lsi_conv2d_fwd_bnstats; groups | N).
+ * lsi_conv2d_first_wgrad: g_weight[co][c][ky][kx] = sum over n, oy, ox of
+ *   gy[n][oy][ox][co] * x[n][2 oy + ky - pad_t][2 ox + kx - pad_l][c]  (written,
+ *   fp32, in weight_layout; K = output pixels on the matrix cores, partial sums
+ *   per workgroup in the workspace folded in a fixed order: deterministic).
+ *   gy: bf16 N x OH x OW x 32, 16-byte aligned.  The image has no data gradient.
+ */
+int lsi_conv2d_first_supported(const LsiConvDesc* d);
+int lsi_conv2d_first_fwd(const LsiConvDesc* d, const void* x, int32_t x_bf16,
+                         const float* weight, int32_t weight_layout, void* out,
+                         float* bn_workspace, int32_t groups, lsi_stream_t stream);
+size_t lsi_conv2d_first_wgrad_workspace_bytes(const LsiConvDesc* d);
+int lsi_conv2d_first_wgrad(const LsiConvDesc* d, const void* x, int32_t x_bf16, const void* gy,
+                           float* g_weight, int32_t weight_layout, void* workspace,
+                           size_t workspace_bytes, lsi_stream_t stream);
 
 #ifdef __cplusplus
 }

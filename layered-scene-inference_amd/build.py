@@ -19,7 +19,8 @@ SOURCES = ['lsi_splat.hip', 'lsi_splat_stream.hip', 'lsi_splat_stream2.hip',
            'lsi_splat_tile.hip', 'lsi_splat_bwd_stream.hip',
            'lsi_splat_sweep.hip',
            'lsi_sampling.hip', 'lsi_loss.hip', 'lsi_bn.hip', 'lsi_host.hip', 'lsi_conv.hip',
-           'lsi_conv_wgrad.hip', 'lsi_conv_igemm.hip', 'lsi_conv_wgrad_igemm.hip']
+           'lsi_conv_wgrad.hip', 'lsi_conv_igemm.hip', 'lsi_conv_wgrad_igemm.hip',
+           'lsi_conv_first.hip']
 HEADERS = [os.path.join(CSRC, 'lsi_common.h'),
            os.path.join(CSRC, 'lsi_splat_internal.h'),
            os.path.join(ROOT, 'include', 'lsi_hip.h')]

@@ -107,10 +107,24 @@ __device__ bool reduce_all(const float* a0, const float* a1, int lpp, int C,
                                   __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
   __syncthreads();
   if (!last) return false;
+  // A convolution's statistics nobody consumed (lsi_conv2d_*_bnstats without the
+  // lsi_bn_relu_norm behind it) have left the group's tag and sums in slots this
+  // kernel never clears: the totals are not this tensor's.  NaN out (loud), and
+  // clean up for the calls that follow.
+  const bool dirty = __hip_atomic_load(reinterpret_cast<int*>(ws) + LSI_BN_WS_TAG,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
   for (int t = tid; t < 2 * C; t += BN_THREADS) {
     // (read and clear in one atomic: the accumulators are zero again)
-    tot[t] = __hip_atomic_exchange(acc + t, 0.0f, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
+    const float v = __hip_atomic_exchange(acc + t, 0.0f, __ATOMIC_RELAXED,
+                                          __HIP_MEMORY_SCOPE_AGENT);
+    tot[t] = dirty ? __builtin_nanf("") : v;
+  }
+  if (dirty) {
+    for (int t = 2 * C + tid; t < WS_CONST - WS_ACC; t += BN_THREADS)
+      __hip_atomic_store(acc + t, 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0)
+      __hip_atomic_store(reinterpret_cast<int*>(ws) + LSI_BN_WS_TAG, 0, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
   }
   if (tid == 0)
     __hip_atomic_store(reinterpret_cast<int*>(ws), 0, __ATOMIC_RELAXED,
@@ -261,6 +275,10 @@ __global__ __launch_bounds__(BN_THREADS) void bn_norm_sums_kernel(
   // of a thread's loads are in flight together)
   const float* acc = ws + WS_ACC;
   const int n2 = 2 * C;
+  // the producer's tag: the sums are those of a C-channel tensor in gridDim.y
+  // groups, left by the kernel before this one -- anything else: NaN constants
+  const bool handed = reinterpret_cast<const int*>(ws)[LSI_BN_WS_TAG] ==
+                      LSI_BN_TAG(C, (int)gridDim.y);
   if (n2 <= BN_THREADS) {   // several threads per entry, a few slots each
     const int t = threadIdx.x % n2, s0 = threadIdx.x / n2, sstep = BN_THREADS / n2;
     float v = 0.0f;
@@ -292,7 +310,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_norm_sums_kernel(
     const float mean = ab[c] * inv_n;
     // biased variance (tf.nn.moments); fp32: the sums are fp32
     const float var = fmaxf(__fmaf_rn(-mean, mean, ab[C + c] * inv_n), 0.0f);
-    const float rstd = 1.0f / sqrtf(var + eps);
+    const float rstd = handed ? 1.0f / sqrtf(var + eps) : __builtin_nanf("");
     if (blockIdx.x == 0) {
       float* mr = mean_rstd_ + (size_t)blockIdx.y * 2 * C;
       mr[c] = mean;
@@ -311,7 +329,11 @@ __global__ __launch_bounds__(BN_THREADS) void bn_norm_sums_kernel(
   if (last) {
     for (unsigned g = 0; g < gridDim.y; ++g) {
       float* a = ws_ + (size_t)g * WS_STRIDE + WS_ACC;
-      for (int t = threadIdx.x; t < ns * 2 * C; t += BN_THREADS) a[t] = 0.0f;
+      // (a hand-over that was not this call's: whatever its producer's layout was)
+      const int nclr = handed ? ns * 2 * C : WS_CONST - WS_ACC;
+      for (int t = threadIdx.x; t < nclr; t += BN_THREADS) a[t] = 0.0f;
+      if (threadIdx.x == 0)
+        reinterpret_cast<int*>(ws_ + (size_t)g * WS_STRIDE)[LSI_BN_WS_TAG] = 0;
     }
     if (threadIdx.x == 0)
       __hip_atomic_store(reinterpret_cast<int*>(ws_), 0, __ATOMIC_RELAXED,
@@ -520,6 +542,16 @@ extern "C" int lsi_bn_relu_norm(const void* x, void* y, const float* beta, float
     hipLaunchKernelGGL(bn_norm_sums_kernel<false>, grid, blk, 0, st, x, y, beta, workspace,
                        mean_rstd, (long)npix, C, relu, eps, ns);
   return hipGetLastError() == hipSuccess ? LSI_OK : LSI_ELAUNCH;
+}
+
+extern "C" int lsi_bn_stats_discard(float* workspace, int32_t groups, lsi_stream_t stream_) {
+  if (!workspace) return LSI_ENULL;
+  if (groups < 1 || groups > 65535) return LSI_EINVAL;
+  for (int g = 0; g < groups; ++g)
+    if (hipMemsetAsync(workspace + (size_t)g * WS_STRIDE, 0, (size_t)WS_CONST * sizeof(float),
+                       (hipStream_t)stream_) != hipSuccess)
+      return LSI_ELAUNCH;
+  return LSI_OK;
 }
 
 extern "C" int lsi_bn_relu_bwd(const void* x, const void* dy, const float* mean_rstd,

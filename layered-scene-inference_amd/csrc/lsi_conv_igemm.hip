@@ -287,11 +287,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgArgs a) {
     }
     __syncthreads();
     const int C = a.Cout;
+    const int per_grp = a.N / a.st_groups, grp = n / per_grp;
+    // (the hand-over tag of the group, by the workgroup of its first tile: see
+    // lsi_splat_internal.h)
+    if (tid == 0 && blockIdx.x == 0 && blockIdx.y == 0 && co0 == 0 && ci_ == 0 &&
+        n == grp * per_grp)
+      __hip_atomic_store(reinterpret_cast<int*>(a.st_ws + (size_t)grp * LSI_BN_WS_STRIDE) +
+                             LSI_BN_WS_TAG,
+                         LSI_BN_TAG(C, a.st_groups), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (tid < 2 * BN) {
       const int q = tid / BN, ch = tid - q * BN;
       const float v = (red[(0 * 2 + q) * BN + ch] + red[(1 * 2 + q) * BN + ch]) +
                       (red[(2 * 2 + q) * BN + ch] + red[(3 * 2 + q) * BN + ch]);
-      const int grp = n / (a.N / a.st_groups);
       const int f = (int)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
       __hip_atomic_fetch_add(a.st_ws + (size_t)grp * LSI_BN_WS_STRIDE + LSI_BN_WS_ACC +
                                  (f % a.st_ns) * 2 * C + q * C + co0 + ch,

@@ -94,6 +94,14 @@ int lsi_ensure_dynamic_lds(const void* fn, size_t bytes);
 // a group: ACC + s * 2 C; thousands of workgroups adding to the same two cache
 // lines would take ~8 ns each, one after the other), folded, turned into the
 // constants and cleared by lsi_bn_relu_norm.
+// The hand-over is checked on the device: the producer's first workgroup of a
+// group leaves LSI_BN_TAG(C, groups) in the group's word [1]; lsi_bn_relu_norm
+// expects exactly that tag, the kernels that accumulate their own statistics
+// (lsi_bn_relu_fwd / _bwd) expect 0.  A kernel that finds something else writes
+// NaN constants (its output is NaN: loud in any loss), and clears accumulators
+// and tag, so that the calls after it are right again.
+#define LSI_BN_WS_TAG 1
+#define LSI_BN_TAG(C, groups) (0x5A000000 | (((groups) & 0xfff) << 12) | ((C) & 0xfff))
 static inline int lsi_bn_stat_slots(int C) {
   int ns = 1;
   while (ns < 32 && 2 * ns * 2 * C <= 4096) ns *= 2;

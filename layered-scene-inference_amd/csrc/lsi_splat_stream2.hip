@@ -1717,107 +1717,67 @@ bool s2_choose(const LsiSplatDesc* d, int wmax, bool both, S2Plan* plan, bool* w
 // Smooth disparity fields (a trained network's, the benchmark's) run best on 12
 // waves x two register sets; folded / noisy fields (an untrained network's) 12 -
 // 15 % faster on 16 x one.  The kernel knows which it is: it counts the items
-// that took the folded routes B' / C.  Per call geometry the library keeps a
-// small state: on PROBE launches (the first calls, then two of every 64) the
-// kernel adds its counts to a device counter, a 12-byte asynchronous copy brings
-// them and the probe's sequence number to pinned host memory, and the NEXT call
-// that sees the number there (a plain read of host memory: no runtime call, legal
-// also while a stream is being captured) takes the decision -- 16 x 1 when more than
-// FOLD_SHARE of the items were folded.  The decision of a call never depends on
-// that call's own data, no host synchronisation is added, and a launch that is
-// being captured into a HIP graph takes the decision standing at that moment
-// and probes nothing (the graph has it baked in).  tune_threads, LSI_S2_WIDE
-// and LSI_S2_ADAPT=0 switch the mechanism off.  (The library owns, per
-// geometry, 16 bytes of device memory and 16 of pinned host memory.)
+// that took the folded routes B' / C.  The CALLER may own a small record per call
+// geometry (LsiSplatDesc.adapt -> LsiStreamAdapt, include/lsi_hip.h; NULL: no
+// adaptation, the planner's choice): on PROBE launches (the first calls, then two
+// of every 64) the kernel adds its counts to the record's device counter, a
+// 12-byte asynchronous copy brings them and the probe's sequence number to the
+// record's pinned host memory, and the NEXT call that sees the number there (a
+// plain read of host memory: no runtime call, legal also while a stream is being
+// captured) takes the decision -- 16 x 1 when more than FOLD_SHARE of the items
+// were folded.  The decision of a call never depends on that call's own data, no
+// host synchronisation is added, and a launch that is being captured into a HIP
+// graph takes the decision standing at that moment and probes nothing (the
+// graph has it baked in).  The library itself keeps NO state: everything lives
+// in the caller's record (round 5 kept a table here -- global mutable state,
+// which SURVEY 8(b) rules out, and a race between two threads probing the same
+// geometry); calls that share a record must not overlap, which is the owner's
+// business (lsi/geometry/ldi.py: one record per device, stream and geometry,
+// used under a lock).  tune_threads, LSI_S2_WIDE and LSI_S2_ADAPT=0 switch the
+// mechanism off.
 constexpr double S2_FOLD_SHARE = 0.5;
-struct S2Adapt {
-  int key[10];
-  int device;
-  int state;        // 0 undecided (narrow), 1 narrow, 2 wide
-  long calls;
-  bool pending;
-  unsigned seq;       // the pending probe's number (word 2 of the counters)
-  unsigned* ctr_dev;  // {folded items, all items, sequence number}
-  unsigned* ctr_host;
-};
+typedef LsiStreamAdapt S2Adapt;
 // the pending probe's counts if they have arrived
 bool s2_adapt_poll(S2Adapt* e) {
   if (!e->pending) return false;
-  volatile unsigned* h = e->ctr_host;
+  volatile uint32_t* h = e->ctr_host;
   if (h[2] != e->seq) return false;
   __sync_synchronize();
   const unsigned fold = h[0], all = h[1];
   if (all > 0u) e->state = ((double)fold > S2_FOLD_SHARE * (double)all) ? 2 : 1;
-  e->pending = false;
+  e->pending = 0;
   return true;
 }
-std::mutex s2_adapt_mu;
-std::vector<S2Adapt*> s2_adapt_tab;
 
-// Returns the entry of this geometry (NULL: mechanism off or not creatable
-// now); *want_wide the standing decision, *probe whether this launch counts.
-S2Adapt* s2_adapt_begin(const LsiSplatDesc* d, int wmax, hipStream_t stream, bool* want_wide,
+// Returns the caller's record (NULL: mechanism off); *want_wide the standing
+// decision, *probe whether this launch counts.
+S2Adapt* s2_adapt_begin(const LsiSplatDesc* d, hipStream_t stream, bool* want_wide,
                         bool* probe) {
   *want_wide = false; *probe = false;
+  S2Adapt* e = d->adapt;
+  if (!e || !e->ctr_dev || !e->ctr_host) return nullptr;
   static const char* off = getenv("LSI_S2_ADAPT");
   static const char* forced = getenv("LSI_S2_WIDE");
   if ((off && off[0] == '0') || forced || d->tune_threads != 0 || d->tune_rows != 0) return nullptr;
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(stream, &cap) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
   const bool capturing = cap != hipStreamCaptureStatusNone;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-  int key[10] = {d->L, d->B, d->H, d->W, d->Ht, d->Wt, wmax, (int)(d->flags & LSI_PACKED_RGBD),
-                 0, 0};
-  memcpy(&key[8], &d->trg_downsampling, sizeof(float));
-  memcpy(&key[9], &d->max_disp, sizeof(float));
-  std::lock_guard<std::mutex> g(s2_adapt_mu);
-  S2Adapt* e = nullptr;
-  for (S2Adapt* c : s2_adapt_tab)
-    if (c->device == dev && memcmp(c->key, key, sizeof(key)) == 0) { e = c; break; }
-  if (!e) {
-    if (capturing || s2_adapt_tab.size() >= 256) return nullptr;  // (no allocation inside a capture)
-    e = new S2Adapt();
-    memcpy(e->key, key, sizeof(key));
-    e->device = dev; e->state = 0; e->calls = 0; e->pending = false; e->seq = 0u;
-    e->ctr_dev = nullptr; e->ctr_host = nullptr;
-    if (hipMalloc(reinterpret_cast<void**>(&e->ctr_dev), 16) != hipSuccess ||
-        hipHostMalloc(reinterpret_cast<void**>(&e->ctr_host), 16, hipHostMallocDefault) != hipSuccess) {
-      (void)hipGetLastError();
-      delete e;
-      return nullptr;
-    }
-    memset(e->ctr_host, 0, 16);
-    s2_adapt_tab.push_back(e);
-  }
   s2_adapt_poll(e);
   *want_wide = e->state == 2;
-  if (!capturing && !e->pending && (e->state == 0 || (e->calls & 63) < 2)) *probe = true;
-  e->calls += 1;
+  if (!capturing && !e->pending && (e->state == 0 || (e->calls & 63u) < 2u)) *probe = true;
+  e->calls += 1u;
   return e;
 }
 
 }  // namespace
 
-// Diagnostic: the standing decision for this call geometry on the current
-// device -- 0 none yet, 1 twelve waves x two register sets, 2 sixteen x one;
-// -1 when the mechanism does not apply or has not seen the geometry.
-extern "C" int lsi_stream_adapt_state(const LsiSplatDesc* d) {
-  if (!d) return -1;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return -1;
-  const int wmax = d->tune_window & ~LSI_STREAM_FLAG_BITS;
-  int key[10] = {d->L, d->B, d->H, d->W, d->Ht, d->Wt, wmax, (int)(d->flags & LSI_PACKED_RGBD),
-                 0, 0};
-  memcpy(&key[8], &d->trg_downsampling, sizeof(float));
-  memcpy(&key[9], &d->max_disp, sizeof(float));
-  std::lock_guard<std::mutex> g(s2_adapt_mu);
-  for (S2Adapt* c : s2_adapt_tab)
-    if (c->device == dev && memcmp(c->key, key, sizeof(key)) == 0) {
-      s2_adapt_poll(c);
-      return c->state;
-    }
-  return -1;
+// The standing decision of a caller-owned record (after looking for a pending
+// probe's counts): 0 none yet, 1 twelve waves x two register sets, 2 sixteen x
+// one; -1 for NULL.
+extern "C" int lsi_stream_adapt_state(LsiStreamAdapt* a) {
+  if (!a || !a->ctr_host) return -1;
+  s2_adapt_poll(a);
+  return a->state;
 }
 
 // Whether the compact instance renders this call (else: splat_stream_kernel).
@@ -1859,7 +1819,7 @@ int lsi_stream2_launch(const SplatArgs& a, int wmax, hipStream_t stream,
 #ifndef S2X_STAMPS
   if (!both && !wide) {
     bool want_wide = false;
-    adapt = s2_adapt_begin(d, wmax, stream, &want_wide, &probe);
+    adapt = s2_adapt_begin(d, stream, &want_wide, &probe);
     if (adapt && want_wide) {
       S2Plan wp;
       if (s2_plan(d, wmax, 1024 / 64, both, &wp) == LSI_OK && wp.nw > LSI_S2_MAXT / 64) {
@@ -1910,7 +1870,6 @@ int lsi_stream2_launch(const SplatArgs& a, int wmax, hipStream_t stream,
   k.stamps = nullptr;
   k.route_ctr = nullptr;
   if (adapt && probe) {
-    std::lock_guard<std::mutex> g(s2_adapt_mu);
     adapt->seq += 1u;
     if (adapt->seq == 0u) adapt->seq = 1u;
     if (hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(adapt->ctr_dev), 0, 2, stream) == hipSuccess &&
@@ -1946,9 +1905,9 @@ int lsi_stream2_launch(const SplatArgs& a, int wmax, hipStream_t stream,
                       stream) != hipSuccess)
     return LSI_ELAUNCH;
   if (k.route_ctr) {   // the counts travel to the host behind the launch; read by a later call
-    std::lock_guard<std::mutex> g(s2_adapt_mu);
-    if (hipMemcpyAsync(adapt->ctr_host, adapt->ctr_dev, 12, hipMemcpyDeviceToHost, stream) == hipSuccess)
-      adapt->pending = true;
+    if (hipMemcpyAsync(const_cast<uint32_t*>(adapt->ctr_host), adapt->ctr_dev, 12,
+                       hipMemcpyDeviceToHost, stream) == hipSuccess)
+      adapt->pending = 1;
     else
       (void)hipGetLastError();
   }

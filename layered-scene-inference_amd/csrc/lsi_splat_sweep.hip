@@ -181,7 +181,7 @@ __device__ __forceinline__ void pair_add(unsigned long long need, unsigned a, f3
         [sv] "=&s"(sv), [nx] "=&s"(nx), [fa] "=&s"(fa), [fb] "=&s"(fb)
       : [need] "s"(need), [a] "v"(a), [a8] "v"(a8), [mk] "v"(mark), [vxy] "v"(vxy),
         [vzw] "v"(vzw), [wa] "v"(wa), [wb] "v"(wb), [rowb] "n"(ROWB)
-      : "memory", "vcc");
+      : "memory", "vcc", "scc");
 }
 
 __device__ __forceinline__ bool got_cell(float w) { return __float_as_uint(w) != CELL_TAKEN; }

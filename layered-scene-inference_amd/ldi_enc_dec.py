@@ -87,7 +87,13 @@ def build_parser():
   a('--n_obj_min', type=int, default=1)
   a('--n_obj_max', type=int, default=4)
   a('--n_box_planes', type=int, default=5)
-  a('--bf16', type=_bool, default=False, help='bf16 autocast for the convs')
+  a('--bf16', type=_bool, default=True,
+    help='the network in bf16 (torch.autocast) with fp32 accumulation -- the '
+    'product default on a ROCm device: every convolution then runs on this '
+    "repo's MFMA kernels (csrc/lsi_conv*.hip), every batch norm on csrc/lsi_bn.hip "
+    '(BASELINE config 4: "bf16 convs + fp32 splat"); the renderer and the losses '
+    'are fp32 either way.  false = the reference\'s own arithmetic (fp32 '
+    'convolutions): through the library (MIOpen), DESIGN.md 4.8')
   a('--batched_pairs', type=_bool, default=True,
     help='source and target images go through the network in one pass, every '
     'batch norm with separate statistics per view (same arithmetic as two passes)')

@@ -28,6 +28,12 @@ _c_f = ctypes.POINTER(ctypes.c_float)
 _c_i = ctypes.POINTER(ctypes.c_int32)
 
 
+class LsiStreamAdapt(ctypes.Structure):
+  _fields_ = [('state', ctypes.c_int32), ('pending', ctypes.c_int32),
+              ('seq', ctypes.c_uint32), ('calls', ctypes.c_uint32),
+              ('ctr_dev', ctypes.c_void_p), ('ctr_host', ctypes.c_void_p)]
+
+
 class LsiSplatDesc(ctypes.Structure):
   _fields_ = (
       [(n, ctypes.c_int32) for n in ('L', 'B', 'H', 'W', 'Ht', 'Wt')] +
@@ -39,7 +45,8 @@ class LsiSplatDesc(ctypes.Structure):
           'trg_downsampling', 'max_disp', 'zbuf_scale', 'bg_wt')] +
       [('flags', ctypes.c_uint32), ('path', ctypes.c_int32),
        ('tune_rows', ctypes.c_int32), ('tune_threads', ctypes.c_int32),
-       ('tune_window', ctypes.c_int32), ('reserved', ctypes.c_int32)])
+       ('tune_window', ctypes.c_int32), ('reserved', ctypes.c_int32),
+       ('adapt', ctypes.c_void_p)])
 
 
 class LsiLossDesc(ctypes.Structure):
@@ -78,7 +85,7 @@ SIGNATURES = {
     'lsi_rowband_ok': (ctypes.c_int, [_DP, _VP]),
     'lsi_stream_ok': (ctypes.c_int, [_DP, _VP]),
     'lsi_splat_workspace_bytes': (_SZ, [_DP]),
-    'lsi_stream_adapt_state': (ctypes.c_int, [_DP]),
+    'lsi_stream_adapt_state': (ctypes.c_int, [ctypes.POINTER(LsiStreamAdapt)]),
     'lsi_splat_fwd': (ctypes.c_int, [_DP] + [_VP] * 8 + [_SZ, _VP]),
     'lsi_splat_bwd_workspace_bytes': (_SZ, [_DP]),
     'lsi_splat_bwd': (ctypes.c_int, [_DP] + [_VP] * 12 + [_SZ, _VP]),
@@ -126,10 +133,15 @@ SIGNATURES = {
     'lsi_conv2d_wgrad_cat': (ctypes.c_int, [_CP, _VP, _VP, _I32, _VP, _VP, _I32, _VP, _SZ, _VP]),
     'lsi_conv2d_wgrad_workspace_bytes': (_SZ, [_CP]),
     'lsi_conv2d_wgrad': (ctypes.c_int, [_CP] + [_VP] * 4 + [_SZ, _VP]),
+    'lsi_conv2d_first_supported': (ctypes.c_int, [_CP]),
+    'lsi_conv2d_first_fwd': (ctypes.c_int, [_CP, _VP, _I32, _VP, _I32, _VP, _VP, _I32, _VP]),
+    'lsi_conv2d_first_wgrad_workspace_bytes': (_SZ, [_CP]),
+    'lsi_conv2d_first_wgrad': (ctypes.c_int, [_CP, _VP, _I32, _VP, _VP, _I32, _VP, _SZ, _VP]),
     'lsi_bn_workspace_floats': (_SZ, [_I64, _I32, _I32, _I32]),
     'lsi_bn_relu_fwd': (ctypes.c_int, [_VP] * 5 + [_I64, _I32, _I32, _I32, _F32, _I32, _VP]),
     'lsi_bn_relu_bwd': (ctypes.c_int, [_VP] * 7 + [_I64, _I32, _I32, _I32, _I32, _VP]),
     'lsi_bn_relu_norm': (ctypes.c_int, [_VP] * 5 + [_I64, _I32, _I32, _I32, _F32, _I32, _VP]),
+    'lsi_bn_stats_discard': (ctypes.c_int, [_VP, _I32, _VP]),
 }
 
 _lib = None

@@ -159,6 +159,60 @@ def _stream_workspace(desc, dev):
   return ws, ws.numel()
 
 
+class StreamAdapt(object):
+  """The caller-owned record of the compact STREAM kernel's adaptive build
+  choice (include/lsi_hip.h: LsiStreamAdapt) with the 16 bytes of device and of
+  pinned host memory it points at.  One per (device, stream, call geometry);
+  calls that use it hold `lock` (ctypes releases the GIL inside the call: two
+  threads rendering the same geometry on the same stream must not interleave
+  their probes)."""
+
+  def __init__(self, dev):
+    self.rec = _C.LsiStreamAdapt()
+    self.dev_ctr = torch.zeros((4,), dtype=torch.int32, device=dev)
+    self.host_ctr = torch.zeros((4,), dtype=torch.int32).pin_memory()
+    self.rec.ctr_dev = self.dev_ctr.data_ptr()
+    self.rec.ctr_host = self.host_ctr.data_ptr()
+    self.lock = threading.Lock()
+
+  def state(self):
+    """0 undecided, 1 twelve waves x two register sets, 2 sixteen x one."""
+    with self.lock:
+      return int(_C.lib().lsi_stream_adapt_state(ctypes.byref(self.rec)))
+
+
+_ADAPT = {}
+
+
+def stream_adapt(desc, dev):
+  """The record for this call geometry on the current stream (created on first
+  use, kept for the life of the process: a descriptor saved for a backward or
+  baked into a graph points at it), or None where the library would ignore it
+  (other paths, per-layer outputs, explicit tuning)."""
+  if (desc.path != _C.LSI_PATH_STREAM or not (desc.flags & _C.LSI_COMPOSE) or
+      desc.tune_threads or desc.tune_rows or dev.type != 'cuda'):
+    return None
+  key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, desc.L, desc.B, desc.H,
+         desc.W, desc.Ht, desc.Wt, desc.tune_window, desc.flags & _C.LSI_PACKED_RGBD,
+         float(desc.trg_downsampling), float(desc.max_disp))
+  with _WS_LOCK:
+    ad = _ADAPT.get(key)
+    if ad is None:
+      ad = _ADAPT[key] = StreamAdapt(dev)
+  return ad
+
+
+class _NoLock(object):
+  def __enter__(self):
+    return self
+
+  def __exit__(self, *exc):
+    return False
+
+
+_NOLOCK = _NoLock()
+
+
 class _ForwardSplat(torch.autograd.Function):
   """lsi_splat_fwd / lsi_splat_bwd (include/lsi_hip.h)."""
 
@@ -204,10 +258,13 @@ class _ForwardSplat(torch.autograd.Function):
       ws, ws_bytes = _stream_workspace(desc, dev)
       desc.flags |= _C.LSI_WS_KEEP
     mat = mat.contiguous()
-    rc = lib.lsi_splat_fwd(ctypes.byref(desc), _C.ptr(tex), _C.ptr(disp),
-                           _C.ptr(mask), _C.ptr(mat), _C.ptr(img), _C.ptr(wts),
-                           _C.ptr(dsp), _C.ptr(ws), ws_bytes,
-                           _C.stream_ptr(dev))
+    ad = stream_adapt(desc, dev) if cfg.get('adapt', True) else None
+    desc.adapt = ctypes.addressof(ad.rec) if ad is not None else None
+    with (ad.lock if ad is not None else _NOLOCK):
+      rc = lib.lsi_splat_fwd(ctypes.byref(desc), _C.ptr(tex), _C.ptr(disp),
+                             _C.ptr(mask), _C.ptr(mat), _C.ptr(img), _C.ptr(wts),
+                             _C.ptr(dsp), _C.ptr(ws), ws_bytes,
+                             _C.stream_ptr(dev))
     _C.check(rc, 'lsi_splat_fwd')
     ctx.desc = desc
     ctx.has_mask = mask is not None
@@ -383,7 +440,7 @@ def forward_splat_matrix(ldi_src, src2trg_mat, compose_layers=True,
 
 
 _HOST_COPIES = {}     # id(tensor) -> (weakref, version, fp32 CPU copy)
-_GRID_CHECKED = {}    # id(tensor) -> (weakref, version)
+_GRID_CHECKED = {}    # id(tensor) -> (weakref, version, is the grid)
 
 
 def _host_copy(x):
@@ -406,34 +463,91 @@ def _host_copy(x):
   return host
 
 
-def _check_pixel_grid(pixel_coords_src, disps):
-  """The kernels generate the source coordinates (x + .5, y + .5, 1) themselves;
-  the reference renders whatever `pixel_coords_src` holds (ldi.py:134).  Every
-  reference call site passes helpers.pixel_coords; anything else is refused
-  rather than silently rendered from the grid: shape and the four corner
-  pixels of every batch element are compared (once per tensor object and
-  version).  None means the grid."""
+def _is_pixel_grid(pixel_coords_src, disps):
+  """Whether `pixel_coords_src` is the pixel-centre grid helpers.pixel_coords(B,
+  H, W) -- what the fused kernels generate themselves and what every call site
+  of the reference passes (train_utils.py:86-88).  The WHOLE tensor is compared
+  where it lives (one elementwise pass + reduction, one scalar back), once per
+  tensor object and version.  None means the grid."""
   if pixel_coords_src is None:
-    return
+    return True
   p = pixel_coords_src
   key = id(p)
   hit = _GRID_CHECKED.get(key)
   if hit is not None and hit[0]() is p and hit[1] == p._version:
-    return
+    return hit[2]
   b, h, w = disps.shape[1:4]
   if tuple(p.shape) != (b, h, w, 3):
     raise ValueError('pixel_coords_src must be B x H x W x 3 = %s, got %s'
                      % ((b, h, w, 3), tuple(p.shape)))
-  corners = p.detach()[:, [0, 0, h - 1, h - 1], [0, w - 1, 0, w - 1], :].to('cpu', torch.float32)
-  want = torch.tensor([[0.5, 0.5, 1.0], [w - 0.5, 0.5, 1.0], [0.5, h - 0.5, 1.0],
-                       [w - 0.5, h - 0.5, 1.0]])
-  if not torch.equal(corners, want.expand(b, 4, 3)):
-    raise NotImplementedError(
-        'forward_splat renders from the pixel-centre grid helpers.pixel_coords('
-        'B, H, W) (what every call site of the reference passes, '
-        'train_utils.py:86-88); other source coordinates are not supported')
+  q = p.detach()
+  xs = torch.arange(w, device=q.device, dtype=torch.float32) + 0.5
+  ys = torch.arange(h, device=q.device, dtype=torch.float32) + 0.5
+  same = bool(q.dtype == torch.float32 and
+              ((q[..., 0] == xs.view(1, 1, w)) & (q[..., 1] == ys.view(1, h, 1)) &
+               (q[..., 2] == 1.0)).all())
   _GRID_CHECKED[key] = (weakref.ref(p, lambda _r, k=key: _GRID_CHECKED.pop(k, None)),
-                        p._version)
+                        p._version, same)
+  return same
+
+
+def _forward_splat_coords(ldi_src, pixel_coords_src, mat, focal_disps, compose_layers,
+                          compute_trg_disp, trg_downsampling, bg_layer_disp, max_disp,
+                          zbuf_scale):
+  """forward_splat for source coordinates that are NOT the pixel grid
+  (reference ldi.py:134: `coords_src = concat([pixel_coords_src, disps_l])`):
+  the projection as helpers.transform_pts (the sequential-k product: the same
+  target pixel indices as the reference), the three splats of a layer as ONE
+  5-channel lsi_splat_generic (colour x weight, weight, disparity x weight),
+  the normalisation as elementwise ops -- every step differentiable.  The fused
+  kernels derive the grid from their thread indices and cannot take this input;
+  no call site of the reference needs it, so this route is
+  built from the generic ops rather than tuned."""
+  from lsi.geometry import sampling  # pylint: disable=g-import-not-at-top
+  from lsi.nnutils import helpers  # pylint: disable=g-import-not-at-top
+  tex, masks, disps = ldi_src
+  dev = _C.require_device(tex, masks, disps)
+  nl, b, h, w, nc = tex.shape
+  ht, wt = h * trg_downsampling, w * trg_downsampling
+  if ht != int(ht) or wt != int(wt):
+    raise ValueError('H*trg_downsampling and W*trg_downsampling must be '
+                     'integral (reference ldi.py:113-125)')
+  ht, wt = int(ht), int(wt)
+  bg_wt = _C.bg_weight(bg_layer_disp, max_disp, zbuf_scale)
+  pc = pixel_coords_src.to(dev, torch.float32)
+  mat = mat.to(dev, torch.float32)
+  s = float(trg_downsampling)
+  canv = []
+  for l in range(nl):
+    d = disps[l]
+    if focal_disps is not None:
+      d = d - focal_disps.to(dev, torch.float32).view(b, 1, 1, 1)
+    q = helpers.transform_pts(torch.cat([pc, d], dim=-1), mat)
+    uv = helpers.divide_safe(q[..., 0:2], q[..., 2:3]) * s
+    dt = helpers.divide_safe(q[..., 3:4], q[..., 2:3])
+    if focal_disps is not None:
+      dt = dt + focal_disps.to(dev, torch.float32).view(b, 1, 1, 1)
+    pw = helpers.zbuffer_weights(dt / max_disp, scale=zbuf_scale)
+    if masks is not None:
+      pw = pw * masks[l]
+    # (a pixel of zero weight adds nothing to the disparity canvas either:
+    # oracle/lsi_oracle.py forward_splat, the build's definition for non-finite dt)
+    dterm = torch.where(pw != 0, dt * pw, torch.zeros_like(dt))
+    src = torch.cat([tex[l] * pw, pw, dterm], dim=-1)
+    init = torch.cat([torch.full((b, ht, wt, nc + 1), bg_wt, device=dev),
+                      torch.zeros((b, ht, wt, 1), device=dev)], dim=-1)
+    canv.append(sampling.splat(src, uv.contiguous(), init))
+  canv = torch.stack(canv)
+  img, wts, dsp = canv[..., :nc], canv[..., nc:nc + 1], canv[..., nc + 1:]
+  dsp = helpers.divide_safe(dsp, wts)
+  if compose_layers:
+    img = img.sum(dim=0, keepdim=True)
+    wts = wts.sum(dim=0, keepdim=True)
+    dsp = dsp.amax(dim=0, keepdim=True)
+  img = helpers.divide_safe(img, wts)
+  if compute_trg_disp:
+    return img, wts, dsp
+  return img, wts
 
 
 def forward_splat(ldi_src,
@@ -453,10 +567,13 @@ def forward_splat(ldi_src,
 
   Args:
     ldi_src: [textures, masks, disps]; masks may be None (all ones).
-    pixel_coords_src: B x H x W x 3 pixel-centre grid (or None).  The kernels
-        generate (x+0.5, y+0.5, 1) themselves -- the only value the reference's
-        callers pass (helpers.pixel_coords, train_utils.py:86-88); a tensor
-        that is not that grid raises (_check_pixel_grid).
+    pixel_coords_src: B x H x W x 3 (or None = the pixel-centre grid).  The
+        fused kernels generate (x+0.5, y+0.5, 1) themselves -- the only value the
+        reference's callers pass (helpers.pixel_coords, train_utils.py:86-88):
+        the tensor is compared with that grid on its device (whole tensor,
+        once per tensor version) and any other coordinates are rendered by
+        the generic route (_forward_splat_coords: transform_pts +
+        lsi_splat_generic per layer), as ldi.py:134 would.
     k_s, k_t: B x 3 x 3 intrinsics; rot: B x 3 x 3; t: B x 3 x 1.  Camera
         tensors on the CPU avoid a device->host copy when choosing the kernel.
     focal_disps: optional B x 1 x 1 x 1 (reference ldi.py:130-143, lytro data):
@@ -469,9 +586,12 @@ def forward_splat(ldi_src,
     trg_img nl x B x Ht x Wt x 3, trg_wts nl x B x Ht x Wt x 1 (un-normalised)
     [, trg_disp nl x B x Ht x Wt x 1]; nl = 1 if compose_layers else L.
   """
-  _check_pixel_grid(pixel_coords_src, ldi_src[2])
   mat_host = projection.forward_projection_matrix(
       _host_copy(k_s), _host_copy(k_t), _host_copy(rot), _host_copy(t))
+  if not _is_pixel_grid(pixel_coords_src, ldi_src[2]):
+    return _forward_splat_coords(
+        ldi_src, pixel_coords_src, mat_host, focal_disps, compose_layers, compute_trg_disp,
+        trg_downsampling, bg_layer_disp, max_disp, zbuf_scale)
   if focal_disps is not None:
     tex, masks, disps = ldi_src
     f = focal_disps.detach().to(torch.float32).reshape(-1)

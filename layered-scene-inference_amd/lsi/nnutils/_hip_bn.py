@@ -145,6 +145,15 @@ def stats_workspace(x_like_shape, dev, bf16, groups):
   return _workspace(dev, _C.stream_ptr(dev), (n // groups) * h * w, c, bf16, groups)
 
 
+def discard_stats(x_like_shape, dev, bf16, groups):
+  """Drops statistics a producer has left for a batch norm that will not run
+  (lsi_bn_stats_discard): the workspace is clean for the next call."""
+  ws = stats_workspace(x_like_shape, dev, bf16, groups)
+  rc = _C.lib().lsi_bn_stats_discard(ws.data_ptr(), int(groups), _C.stream_ptr(dev))
+  if rc:
+    _C.check(rc, 'lsi_bn_stats_discard')
+
+
 def channels_ok(c, bf16=True):
   nv = 8 if bf16 else 4
   lpp = c // nv

@@ -257,12 +257,32 @@ def _cl_bf16(t):
           t.is_contiguous(memory_format=torch.channels_last) and t.data_ptr() % 16 == 0)
 
 
+_DESC_OK = {}
+
+
+def _desc_supported(n, h, w, cin, oh, ow, cout, k, stride, pad):
+  """lsi_conv2d_supported for the geometry (the library's own word: channel
+  multiples, kernel size, the 2^31-element bound of its int32 offsets), cached."""
+  key = (n, h, w, cin, oh, ow, cout, k, stride, pad)
+  ok = _DESC_OK.get(key)
+  if ok is None:
+    d = _conv_desc(n, h, w, cin, oh, ow, cout, k, k, stride, pad, pad)
+    ok = _DESC_OK[key] = bool(_C.lib().lsi_conv2d_supported(ctypes.byref(d)))
+  return ok
+
+
 def igemm_supported(x, cin, cout, k, stride):
   """bf16 channels-last GPU activations, channel counts that are multiples of
-  32, kernels up to 7 x 7, stride 1 or 2 (lsi_conv2d_supported)."""
-  return (_cl_bf16(x) and x.shape[1] == cin and cin % 32 == 0 and cout % 32 == 0 and
-          1 <= k <= 7 and stride in (1, 2) and
-          x.shape[0] * x.shape[2] * x.shape[3] >= IGEMM_MIN_PIXELS)
+  32, kernels up to 7 x 7, stride 1 or 2, fewer than 2^31 elements per tensor
+  (lsi_conv2d_supported)."""
+  if not (_cl_bf16(x) and x.shape[1] == cin and 1 <= k <= 7 and stride in (1, 2) and
+          x.shape[0] * x.shape[2] * x.shape[3] >= IGEMM_MIN_PIXELS):
+    return False
+  n, _, h, w = x.shape
+  oh, ow = -(-h // stride), -(-w // stride)
+  # (TF SAME: the pad before; what SlimConv2d passes)
+  pad = max((oh - 1) * stride + k - h, 0) // 2
+  return _desc_supported(n, h, w, cin, oh, ow, cout, k, stride, pad)
 
 
 def _f32(weight):
@@ -281,7 +301,7 @@ class _Pack(object):
 
 
 _PACKED = {}   # (id(weight), mode) -> _Pack
-_PACK_TABLE = {}  # device index -> (key, device table, njobs, blocks, entries)
+_PACK_TABLE = {}  # device index -> {key: (key, device table, njobs, blocks)}
 
 
 def _pack_layout(w):
@@ -305,24 +325,62 @@ def _pack_source(weight):
   return w, cl
 
 
+_HOOK = [None]       # handle of the global optimiser post-step hook
+PACK_CHECK = int(os.environ.get('LSI_PACK_CHECK', '0'))  # verify every Nth trusted pack
+_CHECK_CALLS = [0]
+
+
+def _install_optimizer_hook():
+  """torch.optim's GLOBAL post-step hook (every optimiser of the process,
+  whoever built it): after an optimiser has stepped, the packs of the parameters
+  it owns are re-made -- repack_all(), one launch per device.  Installed the
+  first time a trainable parameter is packed.  This is what makes a pack
+  trustworthy: nothing has to remember to call anything (round 5's stale packs
+  were a convention between the Trainer and this module that nothing enforced)."""
+  if _HOOK[0] is None:
+    from torch.optim.optimizer import register_optimizer_step_post_hook
+    _HOOK[0] = register_optimizer_step_post_hook(_after_optimizer_step)
+
+
+def _after_optimizer_step(optimizer, args, kwargs):
+  del args, kwargs
+  if not _PACKED:
+    return
+  owned = set()
+  for group in optimizer.param_groups:
+    for p in group['params']:
+      owned.add(id(p))
+  if any(k[0] in owned for k in _PACKED):
+    repack_all(_owned=owned)
+
+
 def _packed(desc, mode, weight, training=False):
   """The layer's weights in the kernel's operand order (lsi_conv2d_pack).
 
-  A parameter that requires a gradient is packed on EVERY forward call unless its
-  packs are managed (repack_all() has refreshed them: whoever calls it -- the
-  Trainer, after each optimiser step, one launch for all layers -- goes on
-  calling it after every update) -- its version counter cannot be trusted: torch's fused
-  optimisers update parameters without moving it, and a stale pack is silent
-  (found in round 5: the trainer's channels-last parameters were skipped by
-  repack_all, and every implicit-GEMM layer ran on its initial weights).  The
-  backward of the same call takes the other direction's pack from the cache:
-  the forward call drops it.  Frozen parameters keep their packs until the
-  version counter moves (load_state_dict, copy_)."""
+  Who keeps a pack fresh.  Frozen parameters: the version counter (load_state_dict,
+  copy_, in-place ops move it).  Trainable parameters: torch's fused optimisers
+  update them WITHOUT moving the counter, so the counter alone cannot be trusted
+  (round 5: every implicit-GEMM layer of the trainer ran on its initial
+  weights, silently).  Therefore
+    * a trainable parameter is packed on EVERY forward call (the backward of the
+      same call takes the other direction's pack from the cache: the forward call
+      drops it) -- until
+    * an optimiser that owns it has stepped: the global post-step hook
+      (_install_optimizer_hook) then re-makes its packs after every step of ANY
+      optimiser that owns it, with one launch for all layers, and marks them
+      *managed*; managed packs are trusted as long as the version counter has
+      not moved.  Nobody has to call anything: a plain
+      `torch.optim.Adam(..., fused=True)` loop is as safe as the Trainer's.
+  What is left uncovered is a write through `.data` (no counter, no optimiser)
+  to a parameter whose packs are managed; LSI_PACK_CHECK=N verifies every Nth
+  trusted pack against a fresh one and raises."""
   key = (id(weight), mode)
   hit = _PACKED.get(key)
   # (`training`: a forward call -- not the backward of one, which takes what the
   # forward left -- with a parameter somebody may be updating)
   training = training and weight.requires_grad
+  if training:
+    _install_optimizer_hook()
   if training and not (hit is not None and hit.managed):
     _PACKED.pop((id(weight), 1 - mode), None)   # (this step's backward packs afresh)
     hit_ok = False
@@ -331,6 +389,10 @@ def _packed(desc, mode, weight, training=False):
   geo = (desc.Cin, desc.Cout, desc.KH, desc.KW, desc.stride, desc.pad_t, desc.pad_l)
   if hit is not None and hit.wref() is weight and hit.buf.device == weight.device:
     if hit_ok and hit.version == weight._version and hit.geo == geo:
+      if PACK_CHECK and hit.managed:
+        _CHECK_CALLS[0] += 1
+        if _CHECK_CALLS[0] % PACK_CHECK == 0:
+          _verify_pack(hit, weight)
       return hit.buf
   lib = _C.lib()
   dev = weight.device
@@ -354,17 +416,31 @@ def _packed(desc, mode, weight, training=False):
   return buf
 
 
-def repack_all(device=None):
-  """Re-packs, with ONE launch (lsi_conv2d_pack_many), the weights of every
-  layer the implicit-GEMM kernels have run so far -- the trainer calls it right
-  after the optimiser's step, so that the step's forward and backward find their
-  operands ready (eagerly: two launches per layer less; captured in a HIP graph:
-  the packs belong to the graph, whatever the version counters said at capture
-  time).  fp32 parameters stored contiguously or with channels-last strides are
-  read in place; others are dropped from the cache (_packed() packs a copy at
-  the next call).  The packs it refreshes are MANAGED from then on: _packed()
-  trusts them, and whoever updates the parameters calls this after every
-  update."""
+def _verify_pack(e, weight):
+  """LSI_PACK_CHECK: the trusted pack against a fresh one (synchronises)."""
+  src, cl = _pack_source(weight)
+  fresh = torch.empty_like(e.buf)
+  rc = _C.lib().lsi_conv2d_pack(ctypes.byref(e.desc), e.mode | cl, _C.ptr(src), _C.ptr(fresh),
+                                fresh.numel() * 2, _C.stream_ptr(weight.device))
+  _C.check(rc, 'lsi_conv2d_pack')
+  if not torch.equal(fresh, e.buf):
+    raise RuntimeError('stale packed weights: a %s parameter was updated behind the '
+                       'optimiser hook and the version counter (a write through .data?); '
+                       'call _hip_conv.repack_all() after such updates'
+                       % (tuple(weight.shape),))
+
+
+def repack_all(device=None, _owned=None):
+  """Re-packs, with ONE launch per device (lsi_conv2d_pack_many), the weights of
+  every layer the implicit-GEMM kernels have run so far.  The global optimiser
+  hook calls it after every optimiser step (`_owned`: the ids of the stepping
+  optimiser's parameters -- only their packs are refreshed and, from then on,
+  *managed*: trusted by _packed()); captured in a HIP graph together with the
+  optimiser's step, the packs belong to the graph.  A direct call (after a
+  hand-made update, say) refreshes every pack but marks nothing: only an
+  optimiser that keeps stepping keeps packs trusted.  fp32 parameters stored
+  contiguously or with channels-last strides are read in place; others are
+  dropped from the cache (_packed() packs a copy at the next call)."""
   if not _PACKED:
     return 0
   lib = _C.lib()
@@ -372,6 +448,8 @@ def repack_all(device=None):
   for k, e in list(_PACKED.items()):
     w = e.wref()
     if w is None:
+      continue
+    if _owned is not None and k[0] not in _owned:
       continue
     if not w.is_cuda or _pack_layout(w) is None:
       # (not fp32 in one of the two layouts: _packed() packs a copy, now)
@@ -386,8 +464,11 @@ def repack_all(device=None):
   n = 0
   for idx, items in by_dev.items():
     key = tuple((w.data_ptr(), e.buf.data_ptr(), e.mode) for e, w in items)
-    tab = _PACK_TABLE.get(idx)
-    if tab is None or tab[0] != key:
+    # (every table ever built stays alive under its key: a captured graph has
+    # its device address baked in)
+    tabs = _PACK_TABLE.setdefault(idx, {})
+    tab = tabs.get(key)
+    if tab is None:
       jobs = (_C.LsiPackJob * len(items))()
       nb = ctypes.c_int32(0)
       blocks = 0
@@ -400,13 +481,15 @@ def repack_all(device=None):
         blocks += nb.value
       host = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8)
       tab = (key, host.to(items[0][1].device), len(items), blocks)
-      _PACK_TABLE[idx] = tab
+      tabs[key] = tab
     dev = items[0][1].device
-    rc = lib.lsi_conv2d_pack_many(tab[1].data_ptr(), tab[2], tab[3], _C.stream_ptr(dev))
+    with torch.cuda.device(dev):
+      rc = lib.lsi_conv2d_pack_many(tab[1].data_ptr(), tab[2], tab[3], _C.stream_ptr(dev))
     _C.check(rc, 'lsi_conv2d_pack_many')
     for e, w in items:
       e.version = w._version
-      e.managed = True
+      if _owned is not None:
+        e.managed = True
     n += len(items)
   return n
 
@@ -485,8 +568,9 @@ def _igemm_wgrad(d, x, gy, weight, x2=None):
 class _Conv2dIgemm(torch.autograd.Function):
   """slim.conv2d without bias (reference nets.py: the arg_scope's conv2d) --
   forward and data gradient on lsi_conv2d_fwd / lsi_conv2d_bwd_data, the weight
-  gradient on lsi_conv3x3_wgrad where it applies (3 x 3 stride 1 at >= 200 k
-  pixels) and on aten (MIOpen) elsewhere."""
+  gradient on lsi_conv3x3_wgrad (3 x 3 stride 1 at >= 200 k pixels: the row-ring
+  kernel) or lsi_conv2d_wgrad_cat (every other shape the library takes:
+  lsi_conv2d_wgrad_workspace_bytes > 0); aten (MIOpen) only for what is left."""
 
   @staticmethod
   def forward(ctx, x, weight, stride, pad_t, pad_l, oh, ow, bn_groups=0):
@@ -550,9 +634,13 @@ def cat_supported(x1, x2, cout, k, stride):
     return False
   c1, c2 = x1.shape[1], x2.shape[1]
   blk = 64 if (c1 + c2) % 64 == 0 else 32
-  return (c1 % 32 == 0 and c2 % 32 == 0 and c1 % blk == 0 and cout % 32 == 0 and
-          1 <= k <= 7 and stride in (1, 2) and
-          x1.shape[0] * x1.shape[2] * x1.shape[3] >= IGEMM_MIN_PIXELS)
+  if not (c1 % 32 == 0 and c2 % 32 == 0 and c1 % blk == 0 and 1 <= k <= 7 and
+          stride in (1, 2) and x1.shape[0] * x1.shape[2] * x1.shape[3] >= IGEMM_MIN_PIXELS):
+    return False
+  n, _, h, w = x1.shape
+  oh, ow = -(-h // stride), -(-w // stride)
+  pad = max((oh - 1) * stride + k - h, 0) // 2
+  return _desc_supported(n, h, w, c1 + c2, oh, ow, cout, k, stride, pad)
 
 
 class _Conv2dCatIgemm(torch.autograd.Function):
@@ -659,6 +747,101 @@ def conv_transpose2d(x, weight, stride=2, pad=1, bn_groups=0):
 
 
 def convt_supported(x, cin, cout, k, stride):
-  return (_cl_bf16(x) and x.shape[1] == cin and cin % 32 == 0 and cout % 32 == 0 and
-          k <= 7 and stride == 2 and
-          x.shape[0] * x.shape[2] * x.shape[3] * 4 >= IGEMM_MIN_PIXELS)
+  if not (_cl_bf16(x) and x.shape[1] == cin and k <= 7 and stride == 2 and
+          x.shape[0] * x.shape[2] * x.shape[3] * 4 >= IGEMM_MIN_PIXELS):
+    return False
+  n, _, h, w = x.shape
+  # (the descriptor of _ConvTranspose2dIgemm: the convolution whose data gradient
+  # this layer's forward is)
+  return _desc_supported(n, stride * h, stride * w, cout, h, w, cin, k, stride, 1)
+
+
+# ---- the first convolution: 3 image channels (csrc/lsi_conv_first.hip) -------------
+FIRST_CONV = os.environ.get('LSI_FIRST_CONV', '1') != '0'
+
+
+def first_supported(x, cin, cout, k, stride):
+  """`cnv1` (reference nets.py:273): the image -- fp32 or bf16, N x C x H x W with
+  channels-last strides (= the N x H x W x C tensor the module was handed), C <=
+  4 -- through a 7 x 7 stride-2 convolution to 32 channels."""
+  if not (FIRST_CONV and x.is_cuda and x.dim() == 4 and
+          x.dtype in (torch.float32, torch.bfloat16) and x.shape[1] == cin and cin <= 4):
+    return False
+  if not x.is_contiguous(memory_format=torch.channels_last):
+    return False
+  n, _, h, w = x.shape
+  oh, ow = -(-h // stride), -(-w // stride)
+  pad = max((oh - 1) * stride + k - h, 0) // 2
+  key = ('first', n, h, w, cin, oh, ow, cout, k, stride, pad)
+  ok = _DESC_OK.get(key)
+  if ok is None:
+    d = _conv_desc(n, h, w, cin, oh, ow, cout, k, k, stride, pad, pad)
+    ok = _DESC_OK[key] = bool(_C.lib().lsi_conv2d_first_supported(ctypes.byref(d)))
+  return ok
+
+
+def _weight_layout(weight):
+  """(tensor the kernels read in place, layout bit): fp32 contiguous (0) or
+  channels-last strides (2); anything else is copied to fp32 contiguous."""
+  w = weight.detach()
+  cl = _pack_layout(w)
+  if cl is None:
+    return w.float().contiguous(), 0
+  return w, cl
+
+
+class _Conv2dFirst(torch.autograd.Function):
+  """slim.conv2d(inp_img, 32, [7, 7], stride=2) without bias: forward
+  (lsi_conv2d_first_fwd, batch-norm sums in the epilogue) and weight gradient
+  (lsi_conv2d_first_wgrad); the image gets no gradient."""
+
+  @staticmethod
+  def forward(ctx, x, weight, stride, pad_t, pad_l, oh, ow, bn_groups=0):
+    n, cin, h, w = x.shape
+    cout, _, kh, kw = weight.shape
+    desc = _conv_desc(n, h, w, cin, oh, ow, cout, kh, kw, stride, pad_t, pad_l)
+    dev = x.device
+    out = _empty_cl(n, cout, oh, ow, dev)
+    wsrc, cl = _weight_layout(weight)
+    ws_ptr = 0
+    if bn_groups:
+      from lsi.nnutils import _hip_bn  # pylint: disable=g-import-not-at-top
+      ws_ptr = _hip_bn.stats_workspace(tuple(out.shape), dev, 1, bn_groups).data_ptr()
+    rc = _C.lib().lsi_conv2d_first_fwd(ctypes.byref(desc), x.data_ptr(),
+                                       int(x.dtype == torch.bfloat16), wsrc.data_ptr(), cl,
+                                       out.data_ptr(), ws_ptr, int(bn_groups), _C.stream_ptr(dev))
+    if rc:
+      _C.check(rc, 'lsi_conv2d_first_fwd')
+    ctx.desc = desc
+    ctx.save_for_backward(x, weight)
+    return out
+
+  @staticmethod
+  def backward(ctx, g):
+    x, weight = ctx.saved_tensors
+    d = ctx.desc
+    gw = None
+    if ctx.needs_input_grad[1]:
+      if g.dtype != torch.bfloat16:
+        g = g.to(torch.bfloat16)
+      g = g.contiguous(memory_format=torch.channels_last)
+      dev = x.device
+      lib = _C.lib()
+      nbytes = int(lib.lsi_conv2d_first_wgrad_workspace_bytes(ctypes.byref(d)))
+      ws = _wgrad_workspace(dev, nbytes)
+      cl = 2 if (not weight.is_contiguous() and
+                 weight.is_contiguous(memory_format=torch.channels_last)) else 0
+      gw = torch.empty(tuple(weight.shape), dtype=torch.float32, device=dev,
+                       memory_format=torch.channels_last if cl else torch.contiguous_format)
+      rc = lib.lsi_conv2d_first_wgrad(ctypes.byref(d), x.data_ptr(),
+                                      int(x.dtype == torch.bfloat16), g.data_ptr(), gw.data_ptr(),
+                                      cl, ws.data_ptr(), ws.numel() * 4, _C.stream_ptr(dev))
+      if rc:
+        _C.check(rc, 'lsi_conv2d_first_wgrad')
+      if weight.dtype != torch.float32:
+        gw = gw.to(weight.dtype)
+    return None, gw, None, None, None, None, None, None
+
+
+def conv2d_first(x, weight, stride, pad_t, pad_l, oh, ow, bn_groups=0):
+  return _Conv2dFirst.apply(x, weight, stride, pad_t, pad_l, oh, ow, bn_groups)

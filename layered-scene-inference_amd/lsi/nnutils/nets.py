@@ -1,6 +1,10 @@
 """CNN definitions (mirror of the reference's lsi/nnutils/nets.py) as
-torch.nn.Modules on PyTorch-ROCm (convolutions run on MIOpen's MFMA kernels;
-channels-last memory format and bf16 autocast are supported by the callers).
+torch.nn.Modules on PyTorch-ROCm.  On a ROCm device with bf16 channels-last
+activations (the trainer's default: --bf16 / --channels_last) every convolution
+runs on this repo's own MFMA kernels (csrc/lsi_conv*.hip: first layer, implicit
+GEMM, the heads' 32-channel layers, all weight gradients) and every batch norm
+on csrc/lsi_bn.hip; fp32 activations (--bf16 false: the reference's own
+arithmetic) go through the library (MIOpen) -- DESIGN.md 4.8 says why.
 
 Conventions kept from the reference (tf.contrib.slim, nets.py:29-348):
   * tensors at the module boundary are B x H x W x C (channels-last logical
@@ -111,8 +115,22 @@ def _bn_relu(bn, x, prestat=False):
   if FUSED_BN and bn.is_training and x.is_cuda:
     from lsi.nnutils import _hip_bn  # pylint: disable=g-import-not-at-top
     if _hip_bn.supported(x, _BN_GROUPS[0]):
-      return _hip_bn.batch_norm_relu(x, bn.beta, bn.eps, True, _BN_GROUPS[0], prestat)
-  assert not prestat
+      if not prestat:
+        return _hip_bn.batch_norm_relu(x, bn.beta, bn.eps, True, _BN_GROUPS[0], False)
+      try:
+        return _hip_bn.batch_norm_relu(x, bn.beta, bn.eps, True, _BN_GROUPS[0], True)
+      except Exception:
+        # (the statistics the convolution left must not outlive this call: the
+        # kernels would refuse the workspace -- NaN -- until somebody cleans it)
+        _hip_bn.discard_stats(tuple(x.shape), x.device, 1, _BN_GROUPS[0])
+        raise
+    if prestat:
+      # the producer accumulated for a consumer that cannot take this tensor
+      # (layout, alignment): drop its sums, normalise the two-pass way
+      _hip_bn.discard_stats(tuple(x.shape), x.device, 1, _BN_GROUPS[0])
+  elif prestat:
+    raise RuntimeError('batch-norm statistics were requested from the convolution '
+                       'but the fused batch norm is off')
   return F.relu(bn(x))
 
 
@@ -197,6 +215,25 @@ class SlimConv2d(nn.Module):
     """x2: the layer reads tf.concat([x, x2], axis=3) (a skip connection)."""
     if x2 is not None:
       return self.forward_cat(x, x2)
+    if (MFMA_CONV and IGEMM_CONV and x.is_cuda and self.bn is not None and
+        self.conv.weight.shape[1] <= 4 and
+        (x.dtype == torch.bfloat16 or
+         (x.dtype == torch.float32 and torch.is_autocast_enabled('cuda') and
+          torch.get_autocast_dtype('cuda') == torch.bfloat16))):
+      # `cnv1`: the image itself (fp32 under autocast: rounded to bf16 inside the
+      # kernel, as autocast's cast would) through the first-layer kernel
+      from lsi.nnutils import _hip_conv  # pylint: disable=g-import-not-at-top
+      cout, cin = self.conv.weight.shape[:2]
+      if _hip_conv.first_supported(x, cin, cout, self.k, self.stride):
+        ph = _same_pad(x.shape[2], self.k, self.stride)
+        pw = _same_pad(x.shape[3], self.k, self.stride)
+        st = _stats_bn(self.bn, self.activation, x.shape[0], cout)
+        y = _hip_conv.conv2d_first(x, self.conv.weight, self.stride, ph[0], pw[0],
+                                   -(-x.shape[2] // self.stride),
+                                   -(-x.shape[3] // self.stride), st)
+        if st:
+          return _bn_relu(self.bn, y, True)
+        return self._bn_act(y)
     if MFMA_CONV and x.is_cuda and x.dtype == torch.bfloat16:
       from lsi.nnutils import _hip_conv  # pylint: disable=g-import-not-at-top
       cout, cin = self.conv.weight.shape[:2]

@@ -261,11 +261,11 @@ class Trainer(object):
     return out
 
   def _after_update(self):
-    """The convolution kernels' packed weights follow the parameters: one
-    launch for all layers (lsi_conv2d_pack_many) right after the update."""
-    if self.device.type == 'cuda':
-      from lsi.nnutils import _hip_conv  # pylint: disable=g-import-not-at-top
-      _hip_conv.repack_all(self.device)
+    """Nothing to do: the convolution kernels' packed weights follow the
+    parameters through torch.optim's global post-step hook
+    (_hip_conv._install_optimizer_hook: one lsi_conv2d_pack_many launch right
+    after `optim.step()`, eagerly or inside the captured graph) -- any training
+    loop gets that, not only this one."""
 
   def train_step(self):
     batch = self.feed()

@@ -147,21 +147,27 @@ def inverse_projection_matrix(k_s, k_t, rot, t):
                                pad_intrinsic(k_t_inv)))
 
 
-def project(mat, disp, trg_downsampling=1.0):
+def project(mat, disp, trg_downsampling=1.0, coords=None):
   """ldi.py:134-140 fused: every source pixel centre (x+.5, y+.5, 1, d) through
   M; returns (u, v, D) with u, v already scaled by trg_downsampling.
 
-  mat: B x 4 x 4, disp: B x H x W (fp32).
+  mat: B x 4 x 4, disp: B x H x W (fp32).  coords: B x H x W x 3, the
+  `pixel_coords_src` of ldi.py:134 when it is not the pixel-centre grid.
   """
   mat, disp = _f32(mat), _f32(disp)
   b, h, w = disp.shape
-  xs = (np.arange(w, dtype=np.float32) + F(0.5))[None, None, :]
-  ys = (np.arange(h, dtype=np.float32) + F(0.5))[None, :, None]
+  if coords is None:
+    xs = (np.arange(w, dtype=np.float32) + F(0.5))[None, None, :]
+    ys = (np.arange(h, dtype=np.float32) + F(0.5))[None, :, None]
+    ones = F(1)
+  else:
+    coords = _f32(coords)
+    xs, ys, ones = coords[..., 0], coords[..., 1], coords[..., 2]
   m = mat[:, :, :, None, None]  # B x 4 x 4 x 1 x 1
 
   def row(j):
     acc = xs * m[:, j, 0] + ys * m[:, j, 1]
-    acc = acc + F(1) * m[:, j, 2]
+    acc = acc + ones * m[:, j, 2]
     acc = acc + disp * m[:, j, 3]
     return acc.astype(np.float32)
 
@@ -384,8 +390,9 @@ def bilinear_wrapper(imgs, coords):
 # ---------------------------------------------------------------------------
 def forward_splat(tex, mask, disp, mat, trg_downsampling=1, bg_layer_disp=0,
                   max_disp=1, zbuf_scale=10, compose_layers=True,
-                  debug=False):
-  """ldi.py:71-182 with the projection matrix passed in as data.
+                  debug=False, coords=None):
+  """ldi.py:71-182 with the projection matrix passed in as data (coords: the
+  caller's `pixel_coords_src`, B x H x W x 3; None = the pixel-centre grid).
 
   tex L x B x H x W x 3, mask/disp L x B x H x W x 1, mat B x 4 x 4.
   Returns dict: img [nl,B,Ht,Wt,3], wts [nl,B,Ht,Wt,1], disp [nl,B,Ht,Wt,1]
@@ -402,21 +409,21 @@ def forward_splat(tex, mask, disp, mat, trg_downsampling=1, bg_layer_disp=0,
   cdsp = np.empty((nl, b, ht, wt, 1), np.float32)
   idx_all, upd_all = [], []
   for l in range(nl):
-    u, v, dd = project(mat, disp[l, ..., 0], trg_downsampling)  # :134-140
+    u, v, dd = project(mat, disp[l, ..., 0], trg_downsampling, coords)  # :134-140
     pw = zbuffer_weights(dd / F(max_disp), zbuf_scale) * mask[l, ..., 0]  # :145
-    coords = np.stack([u, v], axis=-1)
+    uv = np.stack([u, v], axis=-1)
     img0 = np.ones((b, ht, wt, c), np.float32) * bg_wt  # :123-125
     wts0 = np.ones((b, ht, wt, 1), np.float32) * bg_wt
     dsp0 = np.zeros((b, ht, wt, 1), np.float32) * bg_wt
-    cimg[l] = splat(tex[l] * pw[..., None], coords, img0)  # :148-155
-    cwts[l] = splat(pw[..., None], coords, wts0)
+    cimg[l] = splat(tex[l] * pw[..., None], uv, img0)  # :148-155
+    cwts[l] = splat(pw[..., None], uv, wts0)
     # build definition (NaN / Inf inputs, where TF's behaviour is implementation
     # defined): a pixel with zero weight adds nothing to the disparity canvas
     # either, although dd * 0 would be NaN for a non-finite dd
     with np.errstate(all='ignore'):
       keep = (pw != 0) & np.isfinite(u) & np.isfinite(v)
       dterm = np.where(keep, dd * pw, F(0)).astype(np.float32)
-    cdsp[l] = splat(dterm[..., None], coords, dsp0)
+    cdsp[l] = splat(dterm[..., None], uv, dsp0)
     if debug:
       idx4, w4 = splat_corners(u, v, ht, wt)
       idx_all.append(idx4.reshape(b, h * w, 4))

@@ -521,6 +521,49 @@ def make_focal(mods):
   print('focal_splat', out['kitti_compose_img'].shape)
 
 
+def make_coords_splat(mods):
+  """forward_splat with source coordinates that are NOT the pixel-centre grid
+  (ldi.py:134 concatenates whatever `pixel_coords_src` holds): a sub-pixel
+  shifted grid and a smoothly warped one, rectified and general cameras, both
+  compose modes, with the disparity output."""
+  ldi = mods['lsi.geometry.ldi']
+  helpers = mods['lsi.nnutils.helpers']
+  proj = mods['lsi.geometry.projection']
+  rs = np.random.RandomState(777)
+  nl, b, h, w = 2, 2, 16, 32
+  out = {}
+  for tag, cams in (('kitti', kitti_cams(b, h, w)),
+                    ('general', synth_cams(rs, b, h, w, ang=0.1, tr=0.3, tz=0.2))):
+    k_s, k_t, rot, t = cams
+    tex = rs.rand(nl, b, h, w, 3).astype(np.float32)
+    disp = (0.05 + 0.3 * rs.rand(nl, b, h, w, 1)).astype(np.float32)
+    mask = rs.rand(nl, b, h, w, 1).astype(np.float32)
+    pc = helpers.pixel_coords(b, h, w).a.copy()
+    if tag == 'kitti':
+      pc[..., 0] += 0.25
+      pc[..., 1] -= 0.4
+    else:
+      pc[..., 0] += f32(1.5 * smooth_noise(rs, (b, h, w), 3) - 0.75)
+      pc[..., 1] += f32(1.5 * smooth_noise(rs, (b, h, w), 3) - 0.75)
+    pc = f32(pc)
+    out[tag + '_M'] = proj.forward_projection_matrix(T(k_s), T(k_t), T(rot), T(t)).a
+    for k_, v in (('tex', tex), ('mask', mask), ('disp', disp), ('coords', pc),
+                  ('k_s', k_s), ('k_t', k_t), ('rot', rot), ('t', t)):
+      out[tag + '_' + k_] = v
+    for compose in (True, False):
+      img, wts, dsp = ldi.forward_splat(
+          [T(tex), T(mask), T(disp)], T(pc), T(k_s), T(k_t), T(rot), T(t),
+          compose_layers=compose, compute_trg_disp=True,
+          trg_downsampling=0.5, bg_layer_disp=1e-3, max_disp=0.4, zbuf_scale=50)
+      c = 'compose' if compose else 'indep'
+      out['%s_%s_img' % (tag, c)] = img.a
+      out['%s_%s_wts' % (tag, c)] = wts.a
+      out['%s_%s_disp' % (tag, c)] = dsp.a
+  out['params'] = np.array([0.5, 1e-3, 0.4, 50], np.float64)
+  np.savez_compressed(os.path.join(OUT, 'coords_splat.npz'), **out)
+  print('coords_splat', out['kitti_compose_img'].shape)
+
+
 def make_scene_geometry():
   """The procedural scene generator's geometry: the reference's
   pure-NumPy helpers lsi/data/syntheticPlanes/utils.py:29-201 are executed in
@@ -629,6 +672,7 @@ def main():
   make_view_synthesis()
   make_scene_geometry()
   make_focal(mods)
+  make_coords_splat(mods)
   make_nets(mods)
   total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
   print('wrote %d bytes under %s' % (total, OUT))

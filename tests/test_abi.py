@@ -39,7 +39,9 @@ def test_binding_covers_the_header(built_lib):
 def test_desc_struct_matches_header_layout(built_lib):
   from lsi import _C
   # 6 int32 + 13 int64 + 4 float + uint32 + 5 int32 = 24 + 104 + 16 + 24
-  assert ctypes.sizeof(_C.LsiSplatDesc) == 168
+  assert ctypes.sizeof(_C.LsiSplatDesc) == 176
+  assert _C.LsiSplatDesc.adapt.offset == 168
+  assert ctypes.sizeof(_C.LsiStreamAdapt) == 32
   assert _C.LsiSplatDesc.tex_sl.offset == 24
   assert _C.LsiSplatDesc.trg_downsampling.offset == 128
   assert _C.LsiSplatDesc.flags.offset == 144

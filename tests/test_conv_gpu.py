@@ -267,6 +267,96 @@ def test_igemm_transposed_convolution(case, dev, own_wgrad_everywhere):
   assert float((gw - gwr).abs().max()) <= tolw, (float((gw - gwr).abs().max()), tolw)
 
 
+# (n, h, w, groups, input dtype, parameter layout): full width of a KITTI image,
+# odd sizes (TF SAME pads 3 / 3 there, 2 / 3 for even ones; partial tiles), a map
+# smaller than one tile
+@pytest.mark.parametrize('case', [(2, 64, 256, 2, 'f32', 'contig'), (4, 37, 91, 2, 'f32', 'clast'),
+                                  (1, 9, 11, 1, 'bf16', 'contig'), (3, 130, 70, 3, 'bf16', 'clast'),
+                                  (8, 256, 768, 2, 'f32', 'clast')])
+def test_first_convolution_forward_statistics_and_weight_gradient(case, dev):
+  """`cnv1` (reference nets.py:273: slim.conv2d(inp_img, 32, [7, 7], stride=2)) on
+  lsi_conv2d_first_fwd / _wgrad: the fp32 (or bf16) image read in place, rounded
+  to bf16 as autocast rounds it, against fp32 F.conv2d of the same rounded
+  operands; the batch-norm sums left by the epilogue against fp64 moments; the
+  weight gradient (K = all output pixels, fp32 sums) against fp32 autograd."""
+  from lsi.nnutils import _hip_bn, _hip_conv
+  n, h, w, groups, xdt, layout = case
+  g = torch.Generator().manual_seed(17)
+  img = torch.rand((n, h, w, 3), generator=g).to(dev)          # N x H x W x 3, like the loader's
+  if xdt == 'bf16':
+    img = img.to(torch.bfloat16)
+  x = img.permute(0, 3, 1, 2)                                  # the module's NCHW view
+  wt = (torch.randn((32, 3, 7, 7), generator=g) * (2.0 / 147) ** 0.5).to(dev)
+  if layout == 'clast':
+    wt = wt.contiguous(memory_format=torch.channels_last)
+  wt.requires_grad_(True)
+  pt, pb, oh = _same_pads(h, 7, 2)
+  pl, pr, ow = _same_pads(w, 7, 2)
+  assert _hip_conv.first_supported(x, 3, 32, 7, 2)
+  got = _hip_conv.conv2d_first(x, wt, 2, pt, pl, oh, ow)
+  assert got.dtype == torch.bfloat16 and got.shape == (n, 32, oh, ow)
+  assert got.is_contiguous(memory_format=torch.channels_last)
+  xr = x.detach().to(torch.bfloat16).float()
+  wr = wt.detach().to(torch.bfloat16).float().contiguous().requires_grad_(True)
+  want = F.conv2d(F.pad(xr, (pl, pr, pt, pb)), wr, None, 2)
+  err = (got.float() - want).abs()
+  assert float((err - want.abs() * 2.0 ** -8).max()) <= 2e-3, float(err.max())
+  # weight gradient
+  c = torch.randn(want.shape, generator=g).to(dev).to(torch.bfloat16)
+  (got.float() * c.float()).sum().backward()
+  (want * c.float()).sum().backward()
+  gw, gwr = wt.grad, wr.grad
+  assert gw.stride() == wt.stride() and gw.dtype == torch.float32
+  tolw = float(gwr.abs().max()) * 1e-4 + 1e-6
+  assert float((gw - gwr).abs().max()) <= tolw, (float((gw - gwr).abs().max()), tolw)
+  # the same call twice: the fold is in a fixed order
+  wt.grad = None
+  (_hip_conv.conv2d_first(x, wt, 2, pt, pl, oh, ow).float() * c.float()).sum().backward()
+  assert torch.equal(wt.grad, gw)
+  # statistics from the epilogue + lsi_bn_relu_norm == the two-pass batch norm
+  beta = (torch.randn((32,), generator=g) * 0.3).to(dev)
+  y1 = _hip_conv.conv2d_first(x, wt, 2, pt, pl, oh, ow, groups)
+  assert torch.equal(y1, got)
+  z1 = _hip_bn.batch_norm_relu(y1, beta.clone().requires_grad_(True), 1e-3, True, groups, True)
+  mr = z1.grad_fn.saved_tensors[2]
+  yf = got.detach().double().view(groups, n // groups, 32, oh, ow)
+  np.testing.assert_allclose(mr[:, 0].double().cpu().numpy(), yf.mean(dim=(1, 3, 4)).cpu().numpy(),
+                             rtol=1e-5, atol=1e-5 * float(yf.abs().max()))
+  np.testing.assert_allclose(mr[:, 1].double().cpu().numpy(),
+                             torch.rsqrt(yf.var(dim=(1, 3, 4), unbiased=False) + 1e-3).cpu().numpy(),
+                             rtol=2e-5)
+  z0 = _hip_bn.batch_norm_relu(got, beta, 1e-3, True, groups)
+  assert float((z1.detach().float() - z0.float()).abs().max()) <= \
+      2.0 ** -7 * float(z0.float().abs().max())
+
+
+def test_first_layer_module_runs_the_own_kernel_under_autocast(dev, monkeypatch):
+  """nets.SlimConv2d(3, 32, 7, 2) -- `cnv1` -- under bf16 autocast with the fp32
+  image: no library convolution is called (aten.convolution is made to raise),
+  and the result follows the library path's."""
+  from lsi.nnutils import nets
+  torch.manual_seed(3)
+  layer = nets.SlimConv2d(3, 32, 7, 2).to(dev).to(memory_format=torch.channels_last)
+  g = torch.Generator().manual_seed(4)
+  img = torch.rand((4, 64, 128, 3), generator=g).to(dev)
+  x = img.permute(0, 3, 1, 2)
+  with nets.bn_groups(2), torch.autocast('cuda', dtype=torch.bfloat16):
+    monkeypatch.setattr(nets, 'IGEMM_CONV', False)
+    ref = layer(x)
+    gref, = torch.autograd.grad(ref.float().square().sum(), layer.conv.weight)
+    monkeypatch.setattr(nets, 'IGEMM_CONV', True)
+
+    def boom(*a, **k):
+      raise AssertionError('the library convolution was called for cnv1')
+    monkeypatch.setattr(F, 'conv2d', boom)
+    monkeypatch.setattr(layer.conv, 'forward', boom)
+    own = layer(x)
+    gown, = torch.autograd.grad(own.float().square().sum(), layer.conv.weight)
+  assert own.dtype == torch.bfloat16 and own.shape == ref.shape
+  assert float((own.float() - ref.float()).abs().max()) <= 2.0 ** -6 * float(ref.float().abs().max())
+  assert float((gown - gref).abs().max()) <= 2e-2 * float(gref.abs().max())
+
+
 def test_igemm_refuses_what_it_does_not_take(dev):
   import ctypes
   from lsi import _C
@@ -389,6 +479,60 @@ def test_batch_norm_statistics_from_the_convolution_epilogue(case, dev):
   assert same(z3, z0) and float((z3 != z0).float().mean()) < 0.02
 
 
+def test_statistics_hand_over_is_checked_on_the_device(dev):
+  """The hand-over convolution -> lsi_bn_relu_norm through the shared workspace
+  is tagged (C, groups) on the device.  A consumer without its producer, a
+  producer whose consumer never ran followed by a self-accumulating pass, and a
+  consumer of somebody else's statistics all write NaN -- never numbers from the
+  wrong sums -- and leave the workspace clean: the next regular calls are right.
+  lsi_bn_stats_discard drops statistics nobody will consume.  (Round 5's ADVICE:
+  a missing lsi_bn_relu_norm left the accumulators dirty for the rest of the
+  process, silently.)"""
+  from lsi.nnutils import _hip_bn, _hip_conv
+  g = torch.Generator().manual_seed(21)
+  n, cin, h, w, cout, groups = 4, 64, 12, 20, 64, 2
+  x = _clast(torch.randn((n, cin, h, w), generator=g).to(dev).to(torch.bfloat16))
+  wt = (torch.randn((cout, cin, 3, 3), generator=g) * 0.1).to(dev)
+  beta = torch.zeros((cout,), device=dev)
+  y = _hip_conv.conv2d(x, wt, 1, 1, 1, h, w)
+  want = _hip_bn.batch_norm_relu(y, beta, 1e-3, True, groups)
+  ok = lambda z: bool(torch.isfinite(z.float()).all()) and float(
+      (z.float() - want.float()).abs().max()) <= 2.0 ** -7 * float(want.float().abs().max())
+  # (1) a consumer without a producer
+  z = _hip_bn.batch_norm_relu(y, beta, 1e-3, True, groups, True)
+  assert bool(torch.isnan(z.float()).all())
+  assert ok(_hip_bn.batch_norm_relu(y, beta, 1e-3, True, groups))
+  # (2) a producer whose consumer never ran, then the two-pass kernel
+  _hip_conv.conv2d(x, wt, 1, 1, 1, h, w, groups)
+  z = _hip_bn.batch_norm_relu(y, beta, 1e-3, True, groups)
+  assert bool(torch.isnan(z.float()).all())
+  assert ok(_hip_bn.batch_norm_relu(y, beta, 1e-3, True, groups))       # clean again
+  y1 = _hip_conv.conv2d(x, wt, 1, 1, 1, h, w, groups)
+  assert ok(_hip_bn.batch_norm_relu(y1, beta, 1e-3, True, groups, True))  # and the pair works
+  # (3) statistics of another layer (32 channels, one group) in the workspace
+  w32 = (torch.randn((32, cin, 3, 3), generator=g) * 0.1).to(dev)
+  _hip_conv.conv2d(x, w32, 1, 1, 1, h, w, 1)
+  z = _hip_bn.batch_norm_relu(y, beta, 1e-3, True, groups, True)
+  assert bool(torch.isnan(z.float()).all())
+  y1 = _hip_conv.conv2d(x, wt, 1, 1, 1, h, w, groups)
+  assert ok(_hip_bn.batch_norm_relu(y1, beta, 1e-3, True, groups, True))
+  # (4) discard: what the Python layer does when the consumer cannot run
+  _hip_conv.conv2d(x, wt, 1, 1, 1, h, w, groups)
+  _hip_bn.discard_stats(tuple(y.shape), dev, 1, groups)
+  assert ok(_hip_bn.batch_norm_relu(y, beta, 1e-3, True, groups))
+  # ... and the backward's statistics pass shares the workspace
+  yb = y.clone().requires_grad_(True)
+  zb = _hip_bn.batch_norm_relu(yb, beta, 1e-3, True, groups)
+  gz = _clast(torch.randn(zb.shape, generator=g).to(dev).to(torch.bfloat16))
+  g0, = torch.autograd.grad(zb, yb, gz, retain_graph=True)
+  _hip_conv.conv2d(x, wt, 1, 1, 1, h, w, groups)            # dirty
+  g1, = torch.autograd.grad(zb, yb, gz, retain_graph=True)
+  assert bool(torch.isnan(g1.float()).all())
+  g2, = torch.autograd.grad(zb, yb, gz)
+  assert torch.isfinite(g2.float()).all() and float((g2.float() - g0.float()).abs().max()) <= \
+      2.0 ** -6 * float(g0.float().abs().max())
+
+
 def test_transposed_convolution_leaves_the_statistics_too(dev):
   from lsi.nnutils import _hip_bn, _hip_conv
   g = torch.Generator().manual_seed(12)
@@ -492,11 +636,81 @@ def test_packs_of_channels_last_parameters_and_of_silent_updates(dev):
   assert float((y2.float() + 2 * y0.float()).abs().max()) <= float(y2.float().abs().max()) * 2.0 ** -6
   gx_2, = torch.autograd.grad(y2, x, gy)
   assert float((gx_2.float() + 2 * gx_c.float()).abs().max()) <= float(gx_2.float().abs().max()) * 2.0 ** -6
-  # managed packs: repack_all brings them up to date and the calls trust them
+  # a direct repack_all() refreshes the packs but does not make them trusted:
+  # only an optimiser that keeps stepping does (the global post-step hook)
   wc.data.mul_(-0.5)
   assert _hip_conv.repack_all(dev) >= 2
+  assert not any(e.managed for k, e in _hip_conv._PACKED.items() if k[0] == id(wc))
   y3 = _hip_conv.conv2d(x, wc, 1, 1, 1, 10, 12)
   assert float((y3.float() - y0.float()).abs().max()) <= float(y0.float().abs().max()) * 2.0 ** -6
+  wc.data.mul_(3.0)                 # ... so this silent write is seen as well
+  y4 = _hip_conv.conv2d(x, wc, 1, 1, 1, 10, 12)
+  assert float((y4.float() - 3 * y0.float()).abs().max()) <= float(y4.float().abs().max()) * 2.0 ** -6
+
+
+def test_any_optimizer_loop_keeps_the_packs_fresh(dev):
+  """A plain training loop -- torch.optim.Adam(fused=True), which updates
+  parameters WITHOUT moving their version counters, no Trainer, nobody calling
+  repack_all() -- has to run every step on the weights of that step: the global
+  optimiser post-step hook re-makes the packs of the parameters the stepping
+  optimiser owns (one launch) and only then are they trusted.  A second
+  optimiser over the same parameters is covered the same way.  (Round 5's
+  ADVICE: once packs were marked managed they were trusted for ever, and any loop
+  other than the Trainer's trained on stale weights.)"""
+  import ctypes
+  from lsi import _C
+  from lsi.nnutils import _hip_conv, nets
+  torch.manual_seed(5)
+  layers = torch.nn.ModuleList([nets.SlimConv2d(64, 64, 3, 1), nets.SlimConv2d(64, 32, 3, 2),
+                                nets.SlimConvTranspose2d(32, 32)]).to(dev)
+  layers = layers.to(memory_format=torch.channels_last)
+  params = list(layers.parameters())
+  opt = torch.optim.Adam(params, lr=1e-2, fused=True)
+  opt2 = torch.optim.SGD(params, lr=1e-2)
+  g = torch.Generator().manual_seed(6)
+  x = _clast(torch.randn((2, 64, 16, 32), generator=g).to(dev).to(torch.bfloat16))
+  lib = _C.lib()
+
+  def fresh(e, w):
+    buf = torch.empty_like(e.buf)
+    src, cl = _hip_conv._pack_source(w)
+    rc = lib.lsi_conv2d_pack(ctypes.byref(e.desc), e.mode | cl, _C.ptr(src), _C.ptr(buf),
+                             buf.numel() * 2, _C.stream_ptr(w.device))
+    assert rc == 0
+    return buf
+
+  mine = lambda: [(k, e) for k, e in _hip_conv._PACKED.items()
+                  if e.wref() is not None and any(e.wref() is p for p in params)]
+  losses = []
+  for step in range(6):
+    y = x
+    for l in layers:
+      y = l(y)
+    loss = y.float().square().mean()
+    for p in params:
+      p.grad = None
+    loss.backward()
+    (opt if step != 3 else opt2).step()      # step 3: ANOTHER optimiser updates them
+    torch.cuda.synchronize()
+    packs = mine()
+    assert len(packs) >= 6, len(packs)       # three layers, both directions
+    for k, e in packs:
+      assert e.managed, (step, k)
+      assert torch.equal(fresh(e, e.wref()), e.buf), (step, k)
+    losses.append(float(loss))
+  assert losses[-1] < losses[0]
+  # the trusted packs are verified on demand (LSI_PACK_CHECK): a write through
+  # .data behind everybody's back is then an error, not a silently stale layer
+  old = _hip_conv.PACK_CHECK
+  _hip_conv.PACK_CHECK = 1
+  try:
+    layers[0](x)
+    layers[0].conv.weight.data.mul_(1.5)
+    with pytest.raises(RuntimeError, match='stale packed weights'):
+      layers[0](x)
+  finally:
+    _hip_conv.PACK_CHECK = old
+    _hip_conv.repack_all(dev)
 
 
 def test_weight_gradient_comes_in_the_parameters_layout(dev):

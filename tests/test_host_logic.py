@@ -182,23 +182,26 @@ def test_host_projection_matrices_equal_the_torch_ops_bit_for_bit(built_lib):
   assert projection._host_matrices(k.double(), k2, rot, t, False) is None
 
 
-def test_forward_splat_refuses_source_coordinates_that_are_not_the_pixel_grid():
-  """reference ldi.py:134 renders the caller's pixel_coords_src; the kernels
-  generate the grid, so anything else must raise, not be ignored."""
+def test_source_coordinates_are_compared_with_the_whole_pixel_grid():
+  """reference ldi.py:134 renders the caller's pixel_coords_src; the fused
+  kernels generate the grid, so a tensor is compared with it as a whole (an
+  interior that is not the grid must not pass on its corners) and anything else
+  goes to the generic route."""
   disps = torch.zeros(2, 3, 4, 6, 1)
   grid = helpers.pixel_coords(3, 4, 6)
-  ldi._check_pixel_grid(None, disps)
-  ldi._check_pixel_grid(grid, disps)
-  ldi._check_pixel_grid(grid, disps)          # (second call: remembered)
+  assert ldi._is_pixel_grid(None, disps)
+  assert ldi._is_pixel_grid(grid, disps)
+  assert ldi._is_pixel_grid(grid, disps)          # (second call: remembered)
   with pytest.raises(ValueError):
-    ldi._check_pixel_grid(helpers.pixel_coords(3, 4, 5), disps)
-  with pytest.raises(NotImplementedError):
-    ldi._check_pixel_grid(grid + 0.25, disps)
+    ldi._is_pixel_grid(helpers.pixel_coords(3, 4, 5), disps)
+  assert not ldi._is_pixel_grid(grid + 0.25, disps)
   moved = grid.clone()
-  ldi._check_pixel_grid(moved, disps)
-  moved[1, 3, 5, 0] += 1.0                    # in-place edit: the version moves
-  with pytest.raises(NotImplementedError):
-    ldi._check_pixel_grid(moved, disps)
+  assert ldi._is_pixel_grid(moved, disps)
+  moved[1, 2, 3, 0] += 1.0     # an INTERIOR pixel, in place: the version moves
+  assert not ldi._is_pixel_grid(moved, disps)
+  third = grid.clone()
+  third[..., 2] = 2.0          # the homogeneous coordinate counts as well
+  assert not ldi._is_pixel_grid(third, disps)
 
 
 def test_host_copy_of_cameras_follows_the_tensor_not_its_address():

@@ -98,6 +98,24 @@ def test_c_oracle_forward_splat(case, compose, ref_cpu):
   assert rel_err(r1['img'], r['img']) <= 1e-5
 
 
+@pytest.mark.parametrize('tag', ['kitti', 'general'])
+@pytest.mark.parametrize('compose', [True, False])
+def test_numpy_oracle_forward_splat_from_caller_coordinates(tag, compose):
+  """pixel_coords_src that is not the pixel grid (ldi.py:134): the oracle's
+  `coords` argument against the reference's outputs (coords_splat.npz)."""
+  g = golden('coords_splat.npz')
+  s, bg, md, zb = [float(v) for v in g['params']]
+  r = O.forward_splat(g[tag + '_tex'], g[tag + '_mask'], g[tag + '_disp'], g[tag + '_M'], s, bg,
+                      md, zb, compose, coords=g[tag + '_coords'])
+  c = 'compose' if compose else 'indep'
+  assert rel_err(r['img'], g['%s_%s_img' % (tag, c)]) <= 1e-6
+  assert rel_err(r['wts'], g['%s_%s_wts' % (tag, c)]) <= 1e-6
+  assert rel_err(r['disp'], g['%s_%s_disp' % (tag, c)]) <= 1e-6
+  plain = O.forward_splat(g[tag + '_tex'], g[tag + '_mask'], g[tag + '_disp'], g[tag + '_M'], s,
+                          bg, md, zb, compose)
+  assert np.abs(plain['img'] - r['img']).max() > 1e-3     # (the coordinates matter)
+
+
 def test_bilinear_and_wrapper():
   g = golden('bilinear.npz')
   assert rel_err(O.bilinear(g['imgs'], g['coords']), g['out']) <= 1e-6

@@ -118,6 +118,43 @@ def test_camera_api_matches_golden(dev):
 
 @pytest.mark.parametrize('tag', ['kitti', 'general'])
 @pytest.mark.parametrize('compose', [True, False])
+def test_caller_source_coordinates_match_the_reference(tag, compose, dev):
+  """forward_splat with a pixel_coords_src that is not the pixel grid (reference
+  ldi.py:134 renders whatever it holds): against outputs of the reference
+  itself (tests/golden/coords_splat.npz: a sub-pixel shifted grid with rectified
+  cameras, a smoothly warped one with general cameras); differentiable."""
+  from lsi.geometry import ldi
+  g = golden('coords_splat.npz')
+  s, bg, md, zb = [float(v) for v in g['params']]
+  ldi_src = [torch.tensor(g[tag + '_' + k], device=dev) for k in ('tex', 'mask', 'disp')]
+  ldi_src[0].requires_grad_(True)
+  ldi_src[2].requires_grad_(True)
+  coords = torch.tensor(g[tag + '_coords'], device=dev)
+  got = ldi.forward_splat(
+      ldi_src, coords, torch.tensor(g[tag + '_k_s']), torch.tensor(g[tag + '_k_t']),
+      torch.tensor(g[tag + '_rot']), torch.tensor(g[tag + '_t']), compose_layers=compose,
+      compute_trg_disp=True, trg_downsampling=s, bg_layer_disp=bg, max_disp=md, zbuf_scale=zb)
+  c = 'compose' if compose else 'indep'
+  img, wts, dsp = [t.detach().cpu().numpy() for t in got]
+  np.testing.assert_allclose(img, g['%s_%s_img' % (tag, c)], rtol=0, atol=IMG_ATOL)
+  np.testing.assert_allclose(wts, g['%s_%s_wts' % (tag, c)], rtol=WTS_RTOL, atol=0)
+  np.testing.assert_allclose(dsp, g['%s_%s_disp' % (tag, c)], rtol=DSP_RTOL, atol=1e-7)
+  got[0].mean().backward()
+  assert bool(torch.isfinite(ldi_src[0].grad).all() and torch.isfinite(ldi_src[2].grad).all())
+  assert float(ldi_src[0].grad.abs().max()) > 0 and float(ldi_src[2].grad.abs().max()) > 0
+  # the same tensors with the grid itself take the fused kernels and differ
+  from lsi.nnutils import helpers
+  b, h, w = g[tag + '_tex'].shape[1:4]
+  plain = ldi.forward_splat(
+      [t.detach() for t in ldi_src], helpers.pixel_coords(b, h, w, device=dev),
+      torch.tensor(g[tag + '_k_s']), torch.tensor(g[tag + '_k_t']),
+      torch.tensor(g[tag + '_rot']), torch.tensor(g[tag + '_t']), compose_layers=compose,
+      trg_downsampling=s, bg_layer_disp=bg, max_disp=md, zbuf_scale=zb)
+  assert float((plain[0] - got[0].detach()).abs().max()) > 1e-3
+
+
+@pytest.mark.parametrize('tag', ['kitti', 'general'])
+@pytest.mark.parametrize('compose', [True, False])
 def test_focal_disps_matches_the_reference(tag, compose, dev):
   """forward_splat(focal_disps=...) (ldi.py:130-143) against outputs of the
   reference itself (tests/golden/focal_splat.npz)."""
@@ -1431,11 +1468,13 @@ def test_streamed_backward_with_a_mask(w, both, dev, monkeypatch):
 
 
 def test_the_library_picks_the_kernel_build_from_the_field(dev, ref_cpu):
-  """lsi_stream_adapt_state (include/lsi_hip.h): on a geometry where the planner
-  alone takes 12 waves x two register sets, a folded (i.i.d.) disparity field
-  moves the library to the 16-wave build after a few calls, a smooth field
-  leaves it on 12 -- read from the kernel's own route counts, no argument
-  given; the rendering is the same either way."""
+  """LsiSplatDesc.adapt / lsi_stream_adapt_state (include/lsi_hip.h): on a
+  geometry where the planner alone takes 12 waves x two register sets, a folded
+  (i.i.d.) disparity field moves the call to the 16-wave build after a few
+  calls, a smooth field leaves it on 12 -- read from the kernel's own route
+  counts into the CALLER's record (lsi.geometry.ldi owns one per device, stream
+  and geometry; the library keeps no state); the rendering is the same either
+  way."""
   import ctypes
   from lsi import _C
   from lsi.geometry import ldi
@@ -1454,7 +1493,7 @@ def test_the_library_picks_the_kernel_build_from_the_field(dev, ref_cpu):
                      _C.bg_weight(1e-3, md, 50.0), _C.LSI_COMPOSE, 0)
     ldi.select_path(desc, mat_t, 'auto')
     assert desc.path == _C.LSI_PATH_STREAM
-    states[kind] = _C.lib().lsi_stream_adapt_state(ctypes.byref(desc))
+    states[kind] = ldi.stream_adapt(desc, dev).state()
     want = ref_cpu.forward_splat(tex, None, disp, mat, 0.5, 1e-3, md, 50, True)
     assert float(np.abs(img.cpu().numpy() - want['img']).max()) <= 2e-5
     np.testing.assert_allclose(wts.cpu().numpy(), want['wts'], rtol=1e-4)

@@ -17,6 +17,9 @@ def _trainer(tmp_path, **kw):
   args = ['--dataset', 'kitti', '--kitti_procedural', 'true', '--batch_size', '2', '--n_layers', '2',
           '--img_height', '128', '--img_width', '256', '--num_iter', '3',
           '--log_freq', '1', '--checkpoint_dir', str(tmp_path)]
+  # (the tests that do not say otherwise pin the renderer and the losses with the
+  # fp32 network; the product default is --bf16 true)
+  kw.setdefault('bf16', 'false')
   for k, v in kw.items():
     args += ['--' + k, str(v)]
   opts = script.apply_dataset_overrides(script.build_parser().parse_args(args))
