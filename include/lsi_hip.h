@@ -660,6 +660,42 @@ int lsi_conv2d_wgrad_cat(const LsiConvDesc* d, const void* x1, const void* x2, i
                          const void* gy, float* g_weight, int32_t weight_layout,
                          void* workspace, size_t workspace_bytes, lsi_stream_t stream);
 /*
+ * All of the above behind one entry, with a workspace: lsi_conv2d_run(d, mode,
+ * io) is lsi_conv2d_fwd (mode 0) / lsi_conv2d_bwd_data (mode 1) with the
+ * options of the _bnstats and _cat variants taken from `io` -- and, when
+ * `workspace` holds lsi_conv2d_workspace_bytes(d, mode) bytes (16-byte
+ * aligned), the contraction SPLIT OVER THE INPUT CHANNELS for the launches
+ * whose tiles alone do not fill the chip: the bottleneck maps of the U-Net
+ * (reference nets.py:281-305, `cnv5` ... `icnv6`: 2 x 6 ... 16 x 48 pixels with
+ * 256 - 1024 channels) are 64 - 256 tiles, each a chain of 16 - 32 dependent
+ * stages; ks splits each multiply Cin / ks channels into fp32 partial sums in
+ * the workspace, a second kernel adds them in a fixed order, rounds to bf16,
+ * stores (into the two tensors of a skip connection's gradient, too) and takes
+ * the batch-norm sums.  lsi_conv2d_workspace_bytes returns 0 where the kernel
+ * does not split; a smaller or absent workspace is not an error (no split).
+ * The caller owns the workspace (no state in the library); calls that share one
+ * must be ordered on one stream.  Results are deterministic for a given
+ * geometry and differ from the unsplit kernel's only by the fp32 summation
+ * order.
+ *   x, x2, c1 (mode 0): the input as one (x2 NULL) or two tensors;
+ *   out, out2, c1 (mode 1): the gradient into one (out2 NULL) or two tensors;
+ *   bn_workspace (NULL: none), groups: as lsi_conv2d_fwd_bnstats.
+ */
+typedef struct LsiConvIO {
+  const void* x;
+  const void* x2;
+  const void* packed;
+  void* out;
+  void* out2;
+  float* bn_workspace;
+  void* workspace;
+  size_t workspace_bytes;
+  int32_t c1, groups;
+} LsiConvIO;
+size_t lsi_conv2d_workspace_bytes(const LsiConvDesc* d, int32_t mode);
+int lsi_conv2d_run(const LsiConvDesc* d, int32_t mode, const LsiConvIO* io,
+                   lsi_stream_t stream);
+/*
  * Weight gradient of the convolution LsiConvDesc describes (TF autodiff of
  * slim.conv2d, reference nets.py:29-114, 244-348):
  *   g_weight[co][ci][ky][kx] = sum over n, oy, ox of

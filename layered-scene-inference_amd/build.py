@@ -62,6 +62,11 @@ def build(force=False, verbose=False, hooks=False):
   objs, jobs = [], []
   report = LAST_BUILD
   report.clear()
+  if not force and not _stale(so, srcs + HEADERS):
+    # (the library is newer than every source and header: nothing to do -- the
+    # objects need not exist; they do not travel to the GPU box, .gpurunignore)
+    report[os.path.basename(so)] = 'reused'
+    return so
   for src in srcs:
     obj = src[:-4] + ext
     stale = force or _stale(obj, [src] + HEADERS)

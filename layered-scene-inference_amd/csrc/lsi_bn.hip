@@ -167,7 +167,7 @@ __device__ __forceinline__ void norm_pass(const void* __restrict__ x, void* __re
 #pragma unroll
       for (int k = 0; k < NV; ++k) {
         const float z = __fmaf_rn(v[u][k], a[k], b[k]);
-        v[u][k] = relu ? fmaxf(z, 0.0f) : z;
+        v[u][k] = (relu && z < 0.0f) ? 0.0f : z;   // (not fmaxf: NaN constants must show)
       }
       Vec<BF16>::store(y, (p + u * stride) * lpp + lane, v[u]);
     }
@@ -178,7 +178,7 @@ __device__ __forceinline__ void norm_pass(const void* __restrict__ x, void* __re
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
       const float z = __fmaf_rn(v[k], a[k], b[k]);
-      v[k] = relu ? fmaxf(z, 0.0f) : z;
+      v[k] = (relu && z < 0.0f) ? 0.0f : z;
     }
     Vec<BF16>::store(y, p * lpp + lane, v);
   }

@@ -102,6 +102,15 @@ struct IgArgs {
   float* st_ws;
   int st_groups;   // sub-batch groups along N
   int st_ns;       // accumulator slots (lsi_bn_stat_slots)
+  // Split over the input channels (ks > 1): workgroup (.., ksi) multiplies the
+  // chunks [ksi nch / ks, (ksi + 1) nch / ks) of 32 input channels and leaves its
+  // fp32 sums in part[ksi][n][y][x][co]; conv_splitk_fold_kernel adds the ks
+  // slabs in a fixed order, rounds, stores (and takes the batch-norm sums).  For
+  // the bottleneck maps (2 x 6 ... 16 x 48 pixels, 256 - 1024 channels), where
+  // the tiles alone are 64 - 256 workgroups, each a chain of 16 - 32 staged
+  // units that wait a load latency per 36 - 72 MFMAs.
+  float* part;
+  int ks;
   IgClass cls[4];
 };
 
@@ -125,7 +134,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int pxl = lane & 15, kg = lane >> 4;
   const int ncb = a.Cout / BN;
-  const int zc = blockIdx.z / ncb, co0 = (blockIdx.z - zc * ncb) * BN;
+  const int zz = blockIdx.z / ncb, co0 = (blockIdx.z - zz * ncb) * BN;
+  const int ksi = zz / (a.ncls * a.N), zc = zz - ksi * (a.ncls * a.N);
   const int ci_ = zc / a.N, n = zc - ci_ * a.N;
   const IgClass& k = a.cls[ci_];
   const int i0 = blockIdx.y * TH, j0 = blockIdx.x * 16;
@@ -174,11 +184,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgArgs a) {
   // previous stage's MFMAs (one wave per SIMD and workgroup: nobody else would).
   constexpr int NWP = G * BN * 4, WB = (NWP + 255) / 256;
   const int ngrp = (ntaps + G - 1) / G;
-  const int nunit = (a.Cin / 32) * ngrp;
+  const int nch = a.Cin / 32;
+  const int ch_lo = ksi * nch / a.ks, ch_hi = (ksi + 1) * nch / a.ks;   // (this split's chunks)
+  const int nunit = (ch_hi - ch_lo) * ngrp;
   u32x4 pv[MAXP], wv[WB];
   auto fetch = [&](int u) {
-    const int ch = u / ngrp, gi = u - ch * ngrp;
-    const int c0 = ch * 32, t0 = gi * G;
+    const int chl = u / ngrp, gi = u - chl * ngrp;
+    const int c0 = (ch_lo + chl) * 32, t0 = gi * G;
     if (gi == 0) {
       // (the chunk's tensor: its channel count is the pixel pitch)
       const bool second = c0 >= a.C1;
@@ -249,6 +261,23 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgArgs a) {
   }
   // ---- channels-last stores: lane = 4 output channels of one pixel -----------
   const int j = j0 + pxl;
+  if (a.ks > 1) {
+    // ---- a split's fp32 sums: part[ksi][n][y][x][co] ----------------------------
+    if (j < k.OWt) {
+      float* const pb = a.part + (size_t)ksi * a.N * a.OHF * a.OWF * a.Cout;
+#pragma unroll
+      for (int r = 0; r < RW; ++r) {
+        const int i = i0 + wave * RW + r;
+        if (i < k.OHt) {
+          float* const o = pb + (((size_t)n * a.OHF + (size_t)(i * a.os + k.ooy)) * a.OWF +
+                                 (j * a.os + k.oox)) * a.Cout + co0 + 4 * kg;
+#pragma unroll
+          for (int c = 0; c < NCT; ++c) *reinterpret_cast<f32x4*>(o + 16 * c) = acc[r][c];
+        }
+      }
+    }
+    return;
+  }
   if (a.st_ws) {
     // ---- batch-norm statistics of this tile (see IgArgs) -----------------------
     float ss[NCT][4], qq[NCT][4];
@@ -322,6 +351,74 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgArgs a) {
           *reinterpret_cast<bf16x4*>(o + 16 * c) = v;
         }
       }
+    }
+  }
+}
+
+// The sums of a split convolution (IgArgs::part): out = bf16(slab 0 + slab 1 +
+// ...), the order fixed; the batch-norm sums of the rounded values as the
+// unsplit kernel's epilogue takes them.  Block = 64 quads of channels x 4
+// pixels; grid.x = image x pixel block (a block's pixels belong to one image =
+// one sub-batch group), grid.y = blocks of 256 channels.
+struct FoldArgs {
+  const float* part;
+  __bf16* out;
+  __bf16* out2;
+  int O1, Cout, N, ks, pb;
+  long npix;       // pixels per image
+  float* st_ws;
+  int st_groups, st_ns;
+};
+__global__ __launch_bounds__(256) void conv_splitk_fold_kernel(FoldArgs a) {
+  __shared__ float red[4][2][256];
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  const int co = 4 * ((int)blockIdx.y * 64 + tx);
+  const int n = blockIdx.x / a.pb, pbk = blockIdx.x - n * a.pb;
+  const long per = (a.npix + a.pb - 1) / a.pb;
+  const long p0 = pbk * per, p1 = p0 + per < a.npix ? p0 + per : a.npix;
+  const bool live = co < a.Cout;
+  float ss[4] = {0.f, 0.f, 0.f, 0.f}, qq[4] = {0.f, 0.f, 0.f, 0.f};
+  if (live) {
+    const size_t slab = (size_t)a.N * a.npix * a.Cout;
+    const bool second = co >= a.O1;
+    __bf16* const ob = second ? a.out2 + (co - a.O1) : a.out + co;
+    const int pitch = second ? a.Cout - a.O1 : a.O1;
+    for (long p = p0 + ty; p < p1; p += 4) {
+      const size_t pix = (size_t)n * a.npix + p;
+      const float* const src = a.part + pix * a.Cout + co;
+      f32x4 v = *reinterpret_cast<const f32x4*>(src);
+      for (int k = 1; k < a.ks; ++k) v += *reinterpret_cast<const f32x4*>(src + k * slab);
+      bf16x4 o;
+      o[0] = (__bf16)v[0]; o[1] = (__bf16)v[1]; o[2] = (__bf16)v[2]; o[3] = (__bf16)v[3];
+      *reinterpret_cast<bf16x4*>(ob + pix * pitch) = o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float r = (float)o[e];
+        ss[e] += r;
+        qq[e] = __builtin_fmaf(r, r, qq[e]);
+      }
+    }
+  }
+  if (!a.st_ws) return;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { red[ty][0][4 * tx + e] = ss[e]; red[ty][1][4 * tx + e] = qq[e]; }
+  __syncthreads();
+  const int C = a.Cout;
+  const int per_grp = a.N / a.st_groups, grp = n / per_grp;
+  const int tid = ty * 64 + tx;
+  if (tid == 0 && blockIdx.y == 0 && pbk == 0 && n == grp * per_grp)
+    __hip_atomic_store(reinterpret_cast<int*>(a.st_ws + (size_t)grp * LSI_BN_WS_STRIDE) +
+                           LSI_BN_WS_TAG,
+                       LSI_BN_TAG(C, a.st_groups), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int t = tid; t < 512; t += 256) {
+    const int q = t >> 8, ch = t & 255;
+    const int cc = (int)blockIdx.y * 256 + ch;
+    if (cc < C) {
+      const float v = (red[0][q][ch] + red[1][q][ch]) + (red[2][q][ch] + red[3][q][ch]);
+      const int f = (int)(blockIdx.y * gridDim.x + blockIdx.x);
+      __hip_atomic_fetch_add(a.st_ws + (size_t)grp * LSI_BN_WS_STRIDE + LSI_BN_WS_ACC +
+                                 (f % a.st_ns) * 2 * C + q * C + cc,
+                             v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -478,19 +575,65 @@ bool ig_shape(IgArgs& k, int* rw_out, int* nct_out, size_t* lds_out) {
   return false;
 }
 
-int ig_launch(IgArgs& k, hipStream_t stream) {
-  int rw, nct;
+// The split over the input channels (IgArgs::ks) of a launch of `nwg` tiles:
+// as many splits as bring the launch to ~2 workgroups per CU, at least two
+// chunks each (LSI_IGEMM_SPLITK: the target workgroup count, 0 = never).
+int ig_splits(const IgArgs& k, long nwg) {
+  static const char* env = getenv("LSI_IGEMM_SPLITK");   // experiments
+  const long target = env ? atol(env) : 512;
+  const int nch = k.Cin / 32;
+  if (target <= 0 || nch < 4 || nwg <= 0 || nwg * 2 > target) return 1;
+  long ks = target / nwg;
+  if (ks > nch / 2) ks = nch / 2;
+  if (ks > 16) ks = 16;
+  return ks < 2 ? 1 : (int)ks;
+}
+
+struct IgPlan {
+  int rw, nct, ks;
   size_t lds;
-  if (!ig_shape(k, &rw, &nct, &lds)) return LSI_EUNSUPPORTED;
-  const int th = 4 * rw, bn = 16 * nct;
+  dim3 grid;   // (grid.z without the splits)
+};
+
+int ig_plan(IgArgs& k, IgPlan* p) {
+  if (!ig_shape(k, &p->rw, &p->nct, &p->lds)) return LSI_EUNSUPPORTED;
+  const int th = 4 * p->rw, bn = 16 * p->nct;
   int oh = 0, ow = 0;
   for (int c = 0; c < k.ncls; ++c) {
     oh = k.cls[c].OHt > oh ? k.cls[c].OHt : oh;
     ow = k.cls[c].OWt > ow ? k.cls[c].OWt : ow;
   }
+  p->ks = 1;
+  p->grid = dim3(0, 0, 0);
   if (oh <= 0 || ow <= 0) return LSI_OK;
-  const dim3 grid((ow + 15) / 16, (oh + th - 1) / th, k.ncls * k.N * (k.Cout / bn));
-  if (grid.z > 65535 || grid.y > 65535) return LSI_EINVAL;
+  p->grid = dim3((ow + 15) / 16, (oh + th - 1) / th, k.ncls * k.N * (k.Cout / bn));
+  if (p->grid.z > 65535 || p->grid.y > 65535) return LSI_EINVAL;
+  p->ks = ig_splits(k, (long)p->grid.x * p->grid.y * p->grid.z);
+  if ((long)p->grid.z * p->ks > 65535) p->ks = 1;
+  return LSI_OK;
+}
+
+size_t ig_part_bytes(const IgArgs& k, int ks) {
+  return ks > 1 ? (size_t)ks * k.N * k.OHF * k.OWF * k.Cout * sizeof(float) : 0;
+}
+
+int ig_launch(IgArgs& k, hipStream_t stream, void* workspace = nullptr,
+              size_t workspace_bytes = 0) {
+  IgPlan pl;
+  const int prc = ig_plan(k, &pl);
+  if (prc != LSI_OK) return prc;
+  if (pl.grid.x == 0) return LSI_OK;
+  const int rw = pl.rw, nct = pl.nct;
+  const size_t lds = pl.lds;
+  dim3 grid = pl.grid;
+  k.ks = 1;
+  k.part = nullptr;
+  if (pl.ks > 1 && workspace && !((uintptr_t)workspace & 15) &&
+      workspace_bytes >= ig_part_bytes(k, pl.ks)) {
+    k.ks = pl.ks;
+    k.part = (float*)workspace;
+    grid.z *= pl.ks;
+  }
   const void* fn = nullptr;
 #define IG_CASE(R, C, GG) \
   if (rw == R && nct == C && k.G == GG) fn = (const void*)conv_igemm_kernel<R, C, GG>
@@ -505,14 +648,29 @@ int ig_launch(IgArgs& k, hipStream_t stream) {
   {
     static const char* dbg = getenv("LSI_IG_DEBUG");   // (experiments: the plan of every call)
     if (dbg)
-      fprintf(stderr, "ig N%d %dx%d cin %d cout %d s%d os%d ncls %d taps %d: RW %d NCT %d G %d grid %u x %u x %u = %u WGs, lds %zu\n",
+      fprintf(stderr, "ig N%d %dx%d cin %d cout %d s%d os%d ncls %d taps %d: RW %d NCT %d G %d grid %u x %u x %u = %u WGs (ks %d), lds %zu\n",
               k.N, k.H, k.W, k.Cin, k.Cout, k.s, k.os, k.ncls, k.cls[0].ntaps, rw, nct, k.G, grid.x, grid.y,
-              grid.z, grid.x * grid.y * grid.z, lds);
+              grid.z, grid.x * grid.y * grid.z, k.ks, lds);
   }
   if (lsi_ensure_dynamic_lds(fn, lds) != LSI_OK) return LSI_ELAUNCH;
   void* kargs[1] = {&k};
   if (hipLaunchKernel(fn, grid, dim3(256), kargs, lds, stream) != hipSuccess) return LSI_ELAUNCH;
-  return hipGetLastError() == hipSuccess ? LSI_OK : LSI_ELAUNCH;
+  if (hipGetLastError() != hipSuccess) return LSI_ELAUNCH;
+  if (k.ks > 1) {
+    FoldArgs f;
+    f.part = k.part; f.out = k.out; f.out2 = k.out2; f.O1 = k.O1; f.Cout = k.Cout;
+    f.N = k.N; f.ks = k.ks;
+    f.npix = (long)k.OHF * k.OWF;
+    // (pixel blocks per image: ~2 workgroups per CU over the launch, >= 4 pixels each)
+    const int cb = (k.Cout + 255) / 256;
+    long pb = 512 / ((long)k.N * cb);
+    if (pb > (f.npix + 3) / 4) pb = (f.npix + 3) / 4;
+    f.pb = pb < 1 ? 1 : (int)pb;
+    f.st_ws = k.st_ws; f.st_groups = k.st_groups; f.st_ns = k.st_ns;
+    hipLaunchKernelGGL(conv_splitk_fold_kernel, dim3(k.N * f.pb, cb), dim3(64, 4), 0, stream, f);
+    if (hipGetLastError() != hipSuccess) return LSI_ELAUNCH;
+  }
+  return LSI_OK;
 }
 
 bool desc_ok(const LsiConvDesc* d) {
@@ -627,7 +785,8 @@ struct IgStats {
 
 static int ig_run(const LsiConvDesc* d, int mode, const void* src, const void* packed,
                   void* dst, lsi_stream_t stream_, const IgStats* st = nullptr,
-                  const void* src2 = nullptr, int c1 = 0, void* dst2 = nullptr) {
+                  const void* src2 = nullptr, int c1 = 0, void* dst2 = nullptr,
+                  void* workspace = nullptr, size_t workspace_bytes = 0) {
   if (!d || !src || !packed || !dst) return LSI_ENULL;
   if (!desc_ok(d)) return LSI_EUNSUPPORTED;
   if (((uintptr_t)src & 15) || ((uintptr_t)dst & 7) || ((uintptr_t)packed & 15)) return LSI_EINVAL;
@@ -637,6 +796,7 @@ static int ig_run(const LsiConvDesc* d, int mode, const void* src, const void* p
   k.x = (const __bf16*)src; k.wp = (const __bf16*)packed; k.out = (__bf16*)dst;
   k.C1 = k.Cin;
   k.O1 = k.Cout;
+  k.ks = 1;
   if (dst2) {   // the data gradient as two tensors
     const int bn = (k.Cout % 64 == 0) ? 64 : 32;
     if (mode != 1 || ((uintptr_t)dst2 & 7)) return LSI_EINVAL;
@@ -656,7 +816,30 @@ static int ig_run(const LsiConvDesc* d, int mode, const void* src, const void* p
     if (st->groups < 1 || k.N % st->groups || k.Cout > 2048) return LSI_EINVAL;
     k.st_ws = st->ws; k.st_groups = st->groups; k.st_ns = lsi_bn_stat_slots(k.Cout);
   }
-  return ig_launch(k, (hipStream_t)stream_);
+  return ig_launch(k, (hipStream_t)stream_, workspace, workspace_bytes);
+}
+
+extern "C" size_t lsi_conv2d_workspace_bytes(const LsiConvDesc* d, int32_t mode) {
+  if (!desc_ok(d) || mode < 0 || mode > 1) return 0;
+  IgArgs k;
+  int8_t tap[56];
+  ig_classes(d, mode, k, tap);
+  k.C1 = k.Cin; k.O1 = k.Cout; k.ks = 1;
+  IgPlan pl;
+  if (ig_plan(k, &pl) != LSI_OK || pl.grid.x == 0) return 0;
+  return ig_part_bytes(k, pl.ks);
+}
+
+extern "C" int lsi_conv2d_run(const LsiConvDesc* d, int32_t mode, const LsiConvIO* io,
+                              lsi_stream_t stream) {
+  if (!io) return LSI_ENULL;
+  if (mode < 0 || mode > 1) return LSI_EINVAL;
+  if (io->workspace_bytes && !io->workspace) return LSI_ENULL;
+  const IgStats st = {io->bn_workspace, io->groups};
+  if (mode == 0 && io->out2) return LSI_EINVAL;
+  if (mode == 1 && io->x2) return LSI_EINVAL;
+  return ig_run(d, mode, io->x, io->packed, io->out, stream, io->bn_workspace ? &st : nullptr,
+                io->x2, io->c1, io->out2, io->workspace, io->workspace_bytes);
 }
 
 extern "C" int lsi_conv2d_fwd(const LsiConvDesc* d, const void* x, const void* packed,

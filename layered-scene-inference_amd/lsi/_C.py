@@ -72,6 +72,13 @@ class LsiPackJob(ctypes.Structure):
               [('tap', ctypes.c_int8 * 56)])
 
 
+class LsiConvIO(ctypes.Structure):
+  _fields_ = ([(n, ctypes.c_void_p) for n in ('x', 'x2', 'packed', 'out', 'out2',
+                                              'bn_workspace', 'workspace')] +
+              [('workspace_bytes', ctypes.c_size_t), ('c1', ctypes.c_int32),
+               ('groups', ctypes.c_int32)])
+
+
 # name -> (restype, argtypes); every symbol include/lsi_hip.h declares.
 _I32, _I64, _VP, _SZ = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p, ctypes.c_size_t
 _DP = ctypes.POINTER(LsiSplatDesc)
@@ -131,6 +138,8 @@ SIGNATURES = {
     'lsi_conv2d_fwd_cat': (ctypes.c_int, [_CP, _VP, _VP, _I32, _VP, _VP, _VP, _I32, _VP]),
     'lsi_conv2d_bwd_data_cat': (ctypes.c_int, [_CP, _VP, _VP, _VP, _VP, _I32, _VP]),
     'lsi_conv2d_wgrad_cat': (ctypes.c_int, [_CP, _VP, _VP, _I32, _VP, _VP, _I32, _VP, _SZ, _VP]),
+    'lsi_conv2d_workspace_bytes': (_SZ, [_CP, _I32]),
+    'lsi_conv2d_run': (ctypes.c_int, [_CP, _I32, ctypes.POINTER(LsiConvIO), _VP]),
     'lsi_conv2d_wgrad_workspace_bytes': (_SZ, [_CP]),
     'lsi_conv2d_wgrad': (ctypes.c_int, [_CP] + [_VP] * 4 + [_SZ, _VP]),
     'lsi_conv2d_first_supported': (ctypes.c_int, [_CP]),

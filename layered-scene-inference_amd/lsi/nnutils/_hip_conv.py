@@ -494,27 +494,55 @@ def repack_all(device=None, _owned=None):
   return n
 
 
+SPLITK = os.environ.get('LSI_IGEMM_SPLITK', '1') != '0'
+_RUN_BYTES = {}
+
+
+def _run_workspace(desc, mode, dev):
+  """(pointer, bytes) of the workspace lsi_conv2d_run splits the contraction
+  over the input channels in (the bottleneck maps); (0, 0) where it does not
+  split.  The buffer is the weight gradients' (per device and stream: the calls
+  that share it are ordered on that stream)."""
+  if not SPLITK:
+    return 0, 0
+  key = (mode, desc.N, desc.H, desc.W, desc.Cin, desc.OH, desc.OW, desc.Cout, desc.KH,
+         desc.KW, desc.stride, desc.pad_t, desc.pad_l)
+  n = _RUN_BYTES.get(key)
+  if n is None:
+    n = _RUN_BYTES[key] = int(_C.lib().lsi_conv2d_workspace_bytes(ctypes.byref(desc), mode))
+  if not n:
+    return 0, 0
+  ws = _wgrad_workspace(dev, n)
+  return ws.data_ptr(), ws.numel() * 4
+
+
+def _run(desc, mode, packed, dev, x=0, x2=0, out=0, out2=0, c1=0, bn_ws=0, groups=0):
+  """lsi_conv2d_run: forward (mode 0) / data gradient (mode 1) of the
+  descriptor's convolution with every option of the C ABI (two input tensors,
+  two gradient tensors, batch-norm sums, the split over the input channels)."""
+  io = _C.LsiConvIO()
+  io.x, io.x2, io.packed, io.out, io.out2 = x, x2 or None, packed, out, out2 or None
+  io.bn_workspace = bn_ws or None
+  io.c1, io.groups = int(c1), int(groups)
+  wp, wb = _run_workspace(desc, mode, dev)
+  io.workspace, io.workspace_bytes = wp or None, wb
+  rc = _C.lib().lsi_conv2d_run(ctypes.byref(desc), mode, ctypes.byref(io), _C.stream_ptr(dev))
+  if rc:
+    _C.check(rc, 'lsi_conv2d_run(mode %d)' % mode)
+
+
 def _igemm(entry, desc, src, weight, out, bn_groups=0, training=False):
   """bn_groups > 0: the kernel also adds the batch-norm sums of `out` to the
-  workspace (lsi_conv2d_*_bnstats) for the lsi_bn_relu_norm that has to follow."""
+  workspace (as lsi_conv2d_*_bnstats) for the lsi_bn_relu_norm that has to follow."""
   mode = 1 if entry == 'lsi_conv2d_bwd_data' else 0
   packed = _packed(desc, mode, weight, training)
-  lib = _C.lib()
+  dev = src.device
+  bn_ws = 0
   if bn_groups:
     from lsi.nnutils import _hip_bn  # pylint: disable=g-import-not-at-top
-    dev = src.device
-    ws = _hip_bn.stats_workspace(tuple(out.shape), dev, 1, bn_groups)
-    fn = lib.lsi_conv2d_bwd_data_bnstats if mode else lib.lsi_conv2d_fwd_bnstats
-    rc = fn(ctypes.byref(desc), src.data_ptr(), packed.data_ptr(), out.data_ptr(),
-            ws.data_ptr(), int(bn_groups), _C.stream_ptr(dev))
-    if rc:
-      _C.check(rc, entry + '_bnstats')
-    return out
-  fn = lib.lsi_conv2d_bwd_data if mode else lib.lsi_conv2d_fwd
-  rc = fn(ctypes.byref(desc), src.data_ptr(), packed.data_ptr(), out.data_ptr(),
-          _C.stream_ptr(src.device))
-  if rc:
-    _C.check(rc, entry)
+    bn_ws = _hip_bn.stats_workspace(tuple(out.shape), dev, 1, bn_groups).data_ptr()
+  _run(desc, mode, packed.data_ptr(), dev, x=src.data_ptr(), out=out.data_ptr(), bn_ws=bn_ws,
+       groups=bn_groups)
   return out
 
 
@@ -664,11 +692,8 @@ class _Conv2dCatIgemm(torch.autograd.Function):
     if bn_groups:
       from lsi.nnutils import _hip_bn  # pylint: disable=g-import-not-at-top
       ws_ptr = _hip_bn.stats_workspace(tuple(out.shape), dev, 1, bn_groups).data_ptr()
-    rc = _C.lib().lsi_conv2d_fwd_cat(ctypes.byref(desc), x1.data_ptr(), x2.data_ptr(), c1,
-                                     packed.data_ptr(), out.data_ptr(), ws_ptr,
-                                     int(bn_groups), _C.stream_ptr(dev))
-    if rc:
-      _C.check(rc, 'lsi_conv2d_fwd_cat')
+    _run(desc, 0, packed.data_ptr(), dev, x=x1.data_ptr(), x2=x2.data_ptr(), out=out.data_ptr(),
+         c1=c1, bn_ws=ws_ptr, groups=bn_groups)
     return out
 
   @staticmethod
@@ -686,10 +711,8 @@ class _Conv2dCatIgemm(torch.autograd.Function):
       gx1 = _empty_cl(d.N, c1, d.H, d.W, dev)
       gx2 = _empty_cl(d.N, d.Cin - c1, d.H, d.W, dev)
       packed = _packed(d, 1, weight)
-      rc = lib.lsi_conv2d_bwd_data_cat(ctypes.byref(d), g.data_ptr(), packed.data_ptr(),
-                                       gx1.data_ptr(), gx2.data_ptr(), c1, _C.stream_ptr(dev))
-      if rc:
-        _C.check(rc, 'lsi_conv2d_bwd_data_cat')
+      _run(d, 1, packed.data_ptr(), dev, x=g.data_ptr(), out=gx1.data_ptr(),
+           out2=gx2.data_ptr(), c1=c1)
     if ctx.needs_input_grad[2]:
       gw = _igemm_wgrad(d, x1, g, weight, x2)
     return gx1, gx2, gw, None, None, None, None, None, None

@@ -397,8 +397,11 @@ def test_repack_all_refreshes_every_layer_with_one_launch(dev):
   from lsi.nnutils import _hip_conv
   g = torch.Generator().manual_seed(14)
   x = _clast(torch.randn((1, 64, 12, 16), generator=g).to(dev).to(torch.bfloat16)).requires_grad_(True)
-  w1 = (torch.randn((32, 64, 3, 3), generator=g) * 0.1).to(dev).requires_grad_(True)
-  w2 = (torch.randn((64, 32, 4, 4), generator=g) * 0.1).to(dev).requires_grad_(True)
+  # (frozen parameters: their packs are trusted while the version counter stands;
+  # a trainable parameter that no optimiser owns is packed on every forward call --
+  # test_any_optimizer_loop_keeps_the_packs_fresh)
+  w1 = (torch.randn((32, 64, 3, 3), generator=g) * 0.1).to(dev)
+  w2 = (torch.randn((64, 32, 4, 4), generator=g) * 0.1).to(dev)
   def run():
     y = _hip_conv.conv2d(x, w1, 1, 1, 1, 12, 16)
     z = _hip_conv.conv_transpose2d(x, w2)
@@ -668,7 +671,8 @@ def test_any_optimizer_loop_keeps_the_packs_fresh(dev):
   opt = torch.optim.Adam(params, lr=1e-2, fused=True)
   opt2 = torch.optim.SGD(params, lr=1e-2)
   g = torch.Generator().manual_seed(6)
-  x = _clast(torch.randn((2, 64, 16, 32), generator=g).to(dev).to(torch.bfloat16))
+  # (the input wants a gradient: the first layer's data-gradient pack exists, too)
+  x = _clast(torch.randn((2, 64, 16, 32), generator=g).to(dev).to(torch.bfloat16)).requires_grad_(True)
   lib = _C.lib()
 
   def fresh(e, w):
@@ -732,3 +736,99 @@ def test_weight_gradient_comes_in_the_parameters_layout(dev):
     b = _hip_conv._igemm_wgrad(d, x1, gy, wc, x2)
     assert a.is_contiguous() and b.stride() == wc.stride()
     assert float((a - b).abs().max()) <= 1e-6 * float(a.abs().max())
+
+
+# (n, cin, h, w, cout, k, stride): the U-Net's bottleneck maps at 256 x 768
+# (cnv5b ... cnv7b, reference nets.py:281-289) -- tiles alone are 64 - 256
+# workgroups -- and one launch that fills the chip without a split
+_SPLITK_CASES = [(8, 512, 8, 24, 512, 3, 1), (8, 512, 8, 24, 512, 3, 2), (8, 512, 4, 12, 512, 3, 1),
+                 (8, 512, 2, 6, 512, 3, 1), (2, 256, 16, 48, 512, 3, 2), (2, 96, 5, 7, 160, 5, 1)]
+
+
+@pytest.mark.parametrize('case', _SPLITK_CASES)
+def test_split_over_the_input_channels_matches_the_unsplit_kernel(case, dev, monkeypatch):
+  """lsi_conv2d_run with a workspace (the contraction split over the input
+  channels, fp32 partial sums folded by a second kernel) against the same call
+  without one: forward, data gradient, the batch-norm sums of the epilogue; and
+  against fp32 autograd of the bf16-rounded operands.  The two differ by the
+  fp32 summation order only: at most one bf16 ulp where a sum sits on a rounding
+  boundary."""
+  import ctypes
+  from lsi import _C
+  from lsi.nnutils import _hip_bn, _hip_conv, nets
+  n, cin, h, w, cout, k, s = case
+  g = torch.Generator().manual_seed(31)
+  x = _clast(torch.randn((n, cin, h, w), generator=g).to(dev).to(torch.bfloat16)).requires_grad_(True)
+  wt = (torch.randn((cout, cin, k, k), generator=g) * (0.7 / (k * cin ** 0.5))).to(dev)
+  beta = (torch.randn((cout,), generator=g) * 0.3).to(dev)
+  ph, pw = nets._same_pad(h, k, s), nets._same_pad(w, k, s)
+  oh, ow = -(-h // s), -(-w // s)
+  d = _hip_conv._conv_desc(n, h, w, cin, oh, ow, cout, k, k, s, ph[0], pw[0])
+  nbytes = [int(_C.lib().lsi_conv2d_workspace_bytes(ctypes.byref(d), m)) for m in (0, 1)]
+  assert all(b > 0 for b in nbytes), nbytes     # (these launches do split)
+  gy = _clast(torch.randn((n, cout, oh, ow), generator=g).to(dev).to(torch.bfloat16))
+  outs = {}
+  for split in (True, False):
+    monkeypatch.setattr(_hip_conv, 'SPLITK', split)
+    y = _hip_conv.conv2d(x, wt, s, ph[0], pw[0], oh, ow, 2)
+    z = _hip_bn.batch_norm_relu(y, beta, 1e-3, True, 2, True)
+    mr = z.grad_fn.saved_tensors[2].clone()
+    gx, = torch.autograd.grad(y, x, gy)
+    outs[split] = (y.detach().float(), z.detach().float(), mr, gx.float())
+  for a, b in zip(outs[True], outs[False]):
+    assert torch.isfinite(a).all()
+    assert float((a - b).abs().max()) <= 2.0 ** -7 * float(b.abs().max())
+  # the statistics: those of the split call's own rounded outputs
+  ys = outs[True][0].double().view(2, n // 2, cout, oh, ow)
+  mean = ys.mean(dim=(1, 3, 4))
+  assert float((outs[True][2][:, 0].double() - mean).abs().max()) <= 1e-4 * float(
+      ys.abs().max())
+  # fp32 autograd of the same operands
+  xf = x.detach().float().requires_grad_(True)
+  xp = F.pad(xf, (pw[0], pw[1], ph[0], ph[1]))
+  want = F.conv2d(xp, wt.to(torch.bfloat16).float(), None, s)
+  wgx, = torch.autograd.grad(want, xf, gy.float())
+  assert float((outs[True][0] - want).abs().max()) <= 2.0 ** -8 * float(want.abs().max()) + 1e-3
+  assert float((outs[True][3] - wgx).abs().max()) <= 2.0 ** -7 * float(wgx.abs().max())
+
+
+def test_split_convolution_over_a_skip_connection_and_without_workspace(dev, monkeypatch):
+  """The two-tensor variants split, too (input as two tensors forward, gradient
+  into two tensors backward), identically to the split call on the concatenated
+  tensor; a workspace that is too small is not an error (no split)."""
+  import ctypes
+  from lsi import _C
+  from lsi.nnutils import _hip_conv
+  g = torch.Generator().manual_seed(32)
+  n, c1, c2, h, w, cout = 8, 512, 512, 4, 12, 512
+  a = _clast(torch.randn((n, c1, h, w), generator=g).to(dev).to(torch.bfloat16)).requires_grad_(True)
+  b = _clast(torch.randn((n, c2, h, w), generator=g).to(dev).to(torch.bfloat16)).requires_grad_(True)
+  wt = (torch.randn((cout, c1 + c2, 3, 3), generator=g) * 0.01).to(dev)
+  gy = _clast(torch.randn((n, cout, h, w), generator=g).to(dev).to(torch.bfloat16))
+  y1 = _hip_conv.conv2d_cat(a, b, wt, 1, 1, 1, h, w)
+  ga1, gb1 = torch.autograd.grad(y1, (a, b), gy)
+  ab = _clast(torch.cat([a.detach(), b.detach()], 1)).requires_grad_(True)
+  y2 = _hip_conv.conv2d(ab, wt, 1, 1, 1, h, w)
+  gab, = torch.autograd.grad(y2, ab, gy)
+  assert torch.equal(y1, y2)
+  assert torch.equal(torch.cat([ga1, gb1], 1), gab)
+  # a workspace one byte short: the unsplit kernel, no error
+  lib = _C.lib()
+  d = _hip_conv._conv_desc(n, h, w, c1 + c2, h, w, cout, 3, 3, 1, 1, 1)
+  need = int(lib.lsi_conv2d_workspace_bytes(ctypes.byref(d), 0))
+  assert need > 0
+  ws = torch.empty((need,), dtype=torch.uint8, device=dev)
+  packed = _hip_conv._packed(d, 0, wt)
+  out = torch.empty_like(y2)
+  io = _C.LsiConvIO()
+  io.x, io.packed, io.out = ab.data_ptr(), packed.data_ptr(), out.data_ptr()
+  io.workspace, io.workspace_bytes = ws.data_ptr(), need - 1
+  assert lib.lsi_conv2d_run(ctypes.byref(d), 0, ctypes.byref(io), _C.stream_ptr(dev)) == 0
+  monkeypatch.setattr(_hip_conv, 'SPLITK', False)
+  y3 = _hip_conv.conv2d(ab, wt, 1, 1, 1, h, w)
+  assert torch.equal(out, y3)
+  io.workspace_bytes = need
+  assert lib.lsi_conv2d_run(ctypes.byref(d), 0, ctypes.byref(io), _C.stream_ptr(dev)) == 0
+  assert torch.equal(out, y2)
+  io.workspace = None
+  assert lib.lsi_conv2d_run(ctypes.byref(d), 0, ctypes.byref(io), _C.stream_ptr(dev)) == -2  # LSI_ENULL
