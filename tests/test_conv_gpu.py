@@ -742,7 +742,7 @@ def test_weight_gradient_comes_in_the_parameters_layout(dev):
 # (cnv5b ... cnv7b, reference nets.py:281-289) -- tiles alone are 64 - 256
 # workgroups -- and one launch that fills the chip without a split
 _SPLITK_CASES = [(8, 512, 8, 24, 512, 3, 1), (8, 512, 8, 24, 512, 3, 2), (8, 512, 4, 12, 512, 3, 1),
-                 (8, 512, 2, 6, 512, 3, 1), (2, 256, 16, 48, 512, 3, 2), (2, 96, 5, 7, 160, 5, 1)]
+                 (8, 512, 2, 6, 512, 3, 1), (2, 256, 16, 48, 512, 3, 2), (2, 160, 5, 7, 128, 5, 1)]
 
 
 @pytest.mark.parametrize('case', _SPLITK_CASES)
