@@ -17,6 +17,7 @@ end: lsi_conv3x3_pred_bwd forms sigmoid'(z) * g in registers and computes the
 data gradient (K = 9 taps x 4 channels) and the 4 x 288 + 4 weight / bias
 gradients (K = pixels) on the matrix cores.
 """
+import os
 import torch
 
 from lsi import _C
@@ -61,6 +62,72 @@ def _launch(x, weight, cout, mode, bias=None):
   return out
 
 
+# ---- weight gradients on a second stream ---------------------------------------
+# In the backward pass a layer's weight gradient is needed by nobody until the
+# optimiser steps, while its data gradient is on the critical path -- and most of
+# that path (the bottleneck maps' convolutions, every batch-norm pass on a small
+# map) is chains of dependent round trips that leave the chip idle.  With
+# enable_wgrad_stream(True) a layer's backward() launches the weight gradient on
+# a per-device side stream (ordered behind the incoming gradient by an event,
+# BEFORE the data gradient goes onto the main stream), and a callback at the end
+# of the backward pass joins the side stream back into the main one.  Inside a
+# captured HIP graph the fork / join become graph edges.
+#   * only when the parameter's .grad is None (autograd then takes the tensor as
+#     it is: no kernel touches it before the join); accumulation into an existing
+#     gradient (a flat DDP buffer, gradient accumulation) stays on the main stream;
+#   * the tensors the side stream reads (saved activations, the incoming gradient)
+#     are kept alive until the join -- the caching allocator would otherwise hand
+#     their memory to main-stream kernels while the side stream still reads them.
+# Off by default: a wrapper that consumes gradients from hooks on the main stream
+# (torch DDP's reducer) would read them before the join.  The Trainer switches it
+# on for single-process runs.
+_WGRAD_STREAM = {'on': os.environ.get('LSI_WGRAD_STREAM', '') == '1'}
+_SIDE_STREAMS = {}
+_SIDE_PENDING = []   # [(main stream, side stream, kept tensors)] of the running backward pass
+
+
+def enable_wgrad_stream(on=True):
+  """Weight gradients on a side stream (see above); returns the previous setting."""
+  old = _WGRAD_STREAM['on']
+  _WGRAD_STREAM['on'] = bool(on)
+  return old
+
+
+def _join_side_streams():
+  pend, _SIDE_PENDING[:] = list(_SIDE_PENDING), []
+  seen = set()
+  for main, side, _ in pend:
+    key = (main.cuda_stream, side.cuda_stream)
+    if key in seen:
+      continue
+    seen.add(key)
+    ev = torch.cuda.Event()
+    ev.record(side)
+    main.wait_event(ev)
+  # (`pend` -- the kept tensors -- is dropped here: behind the join in stream order)
+
+
+def _wgrad_async(weight, fn, *keep):
+  """gw = fn(): the launch(es) of a weight gradient -- on the side stream when
+  enabled and safe (module comment), else where the caller is."""
+  if not (_WGRAD_STREAM['on'] and weight.is_cuda and weight.grad is None):
+    return fn()
+  dev = weight.device
+  main = torch.cuda.current_stream(dev)
+  side = _SIDE_STREAMS.get(dev.index)
+  if side is None:
+    side = _SIDE_STREAMS[dev.index] = torch.cuda.Stream(device=dev)
+  ev = torch.cuda.Event()
+  ev.record(main)
+  side.wait_event(ev)
+  with torch.cuda.stream(side):
+    gw = fn()
+  if not _SIDE_PENDING:
+    torch.autograd.Variable._execution_engine.queue_callback(_join_side_streams)
+  _SIDE_PENDING.append((main, side, keep))
+  return gw
+
+
 class _Conv3x3C32(torch.autograd.Function):
   """32 -> cout (16 | 32) channels, no bias, bf16 out."""
 
@@ -75,6 +142,8 @@ class _Conv3x3C32(torch.autograd.Function):
     g = g.contiguous(memory_format=torch.channels_last)
     gx = gw = None
     cout = weight.shape[0]
+    if ctx.needs_input_grad[1]:   # (first: it may go to the side stream)
+      gw = _wgrad_async(weight, lambda: _weight_grad(x, g, weight), x, g)
     if ctx.needs_input_grad[0]:
       if cout == 32 and g.dtype == torch.bfloat16 and g.data_ptr() % 16 == 0:
         # dL/dx = conv(g, W flipped in space, transposed in channels): mode 2
@@ -83,8 +152,6 @@ class _Conv3x3C32(torch.autograd.Function):
         gx = torch.ops.aten.convolution_backward(
             g, x, weight.to(g.dtype), None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
             [True, False, False])[0]
-    if ctx.needs_input_grad[1]:
-      gw = _weight_grad(x, g, weight)
     return gx, gw
 
 
@@ -618,16 +685,13 @@ class _Conv2dIgemm(torch.autograd.Function):
       g = g.to(torch.bfloat16)
     g = g.contiguous(memory_format=torch.channels_last)
     gx = gw = None
-    if ctx.needs_input_grad[0]:
-      gx = _igemm('lsi_conv2d_bwd_data', d, g, weight,
-                  _empty_cl(d.N, d.Cin, d.H, d.W, x.device))
-    if ctx.needs_input_grad[1]:
-      if (d.KH == 3 and d.KW == 3 and d.stride == 1 and d.pad_t == 1 and d.pad_l == 1 and
-          wgrad_supported(x, d.Cin, d.Cout, 3, 1)):
-        gw = _weight_grad(x, g, weight)    # (the row-ring kernel: full / half resolution)
-      elif OWN_WGRAD and _igemm_wgrad_bytes(d) > 0:
-        gw = _igemm_wgrad(d, x, g, weight)
-      else:
+    if ctx.needs_input_grad[1]:   # (first: it may go to the side stream)
+      def wgrad():
+        if (d.KH == 3 and d.KW == 3 and d.stride == 1 and d.pad_t == 1 and d.pad_l == 1 and
+            wgrad_supported(x, d.Cin, d.Cout, 3, 1)):
+          return _weight_grad(x, g, weight)    # (the row-ring kernel: full / half resolution)
+        if OWN_WGRAD and _igemm_wgrad_bytes(d) > 0:
+          return _igemm_wgrad(d, x, g, weight)
         # explicit padding: TF SAME is asymmetric for stride 2 (one more after)
         pb = max((d.OH - 1) * d.stride + d.KH - d.H - d.pad_t, 0)
         pr = max((d.OW - 1) * d.stride + d.KW - d.W - d.pad_l, 0)
@@ -635,9 +699,13 @@ class _Conv2dIgemm(torch.autograd.Function):
           xp, pad = x, [d.pad_t, d.pad_l]
         else:
           xp, pad = torch.nn.functional.pad(x, (d.pad_l, pr, d.pad_t, pb)), [0, 0]
-        gw = torch.ops.aten.convolution_backward(
+        return torch.ops.aten.convolution_backward(
             g, xp, weight.to(g.dtype), None, [d.stride, d.stride], pad, [1, 1], False,
             [0, 0], 1, [False, True, False])[1].to(weight.dtype)
+      gw = _wgrad_async(weight, wgrad, x, g)
+    if ctx.needs_input_grad[0]:
+      gx = _igemm('lsi_conv2d_bwd_data', d, g, weight,
+                  _empty_cl(d.N, d.Cin, d.H, d.W, x.device))
     return gx, gw, None, None, None, None, None, None
 
 
@@ -707,14 +775,14 @@ class _Conv2dCatIgemm(torch.autograd.Function):
     g = g.contiguous(memory_format=torch.channels_last)
     lib = _C.lib()
     gx1 = gx2 = gw = None
+    if ctx.needs_input_grad[2]:   # (first: it may go to the side stream)
+      gw = _wgrad_async(weight, lambda: _igemm_wgrad(d, x1, g, weight, x2), x1, x2, g)
     if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
       gx1 = _empty_cl(d.N, c1, d.H, d.W, dev)
       gx2 = _empty_cl(d.N, d.Cin - c1, d.H, d.W, dev)
       packed = _packed(d, 1, weight)
       _run(d, 1, packed.data_ptr(), dev, x=g.data_ptr(), out=gx1.data_ptr(),
            out2=gx2.data_ptr(), c1=c1)
-    if ctx.needs_input_grad[2]:
-      gw = _igemm_wgrad(d, x1, g, weight, x2)
     return gx1, gx2, gw, None, None, None, None, None, None
 
 
@@ -750,18 +818,19 @@ class _ConvTranspose2dIgemm(torch.autograd.Function):
       g = g.to(torch.bfloat16)
     g = g.contiguous(memory_format=torch.channels_last)
     gx = gw = None
+    if ctx.needs_input_grad[1]:   # (first: it may go to the side stream)
+      def wgrad():
+        if OWN_WGRAD and _igemm_wgrad_bytes(d) > 0:
+          # the descriptor's convolution: "input" = this layer's output gradient,
+          # "output gradient" = this layer's input
+          return _igemm_wgrad(d, g, x, weight)
+        return torch.ops.aten.convolution_backward(
+            g, x, weight.to(g.dtype), None, [stride, stride], [pad, pad], [1, 1], True,
+            [0, 0], 1, [False, True, False])[1].to(weight.dtype)
+      gw = _wgrad_async(weight, wgrad, x, g)
     if ctx.needs_input_grad[0]:
       gx = _igemm('lsi_conv2d_fwd', d, g, weight,
                   _empty_cl(d.N, d.Cout, d.OH, d.OW, x.device))
-    if ctx.needs_input_grad[1]:
-      if OWN_WGRAD and _igemm_wgrad_bytes(d) > 0:
-        # the descriptor's convolution: "input" = this layer's output gradient,
-        # "output gradient" = this layer's input
-        gw = _igemm_wgrad(d, g, x, weight)
-      else:
-        gw = torch.ops.aten.convolution_backward(
-            g, x, weight.to(g.dtype), None, [stride, stride], [pad, pad], [1, 1], True,
-            [0, 0], 1, [False, True, False])[1].to(weight.dtype)
     return gx, gw, None, None, None
 
 

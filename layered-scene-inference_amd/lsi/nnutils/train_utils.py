@@ -140,6 +140,20 @@ class Trainer(object):
                                   fused=bool(use_gpu) and bool(getattr(opts, 'fused_adam', True)))
     if self.use_graph:
       self._stream = torch.cuda.Stream(self.device)
+    if use_gpu:
+      # weight gradients on a second stream, joined at the end of the backward
+      # pass (_hip_conv.enable_wgrad_stream): single process, gradients stolen
+      # by autograd -- not with DDP's reducer hooks or the flat gradient buffer,
+      # which read a gradient on the main stream as soon as it is returned --
+      # and eager launches: inside a captured HIP graph the fork / join edges
+      # cost more than the overlap wins (4 layers, batch 4, 256 x 768: eager
+      # 324 -> 336 samples/s, graphed 326 -> 319; profiles/r06/train_ab_*.txt).
+      # LSI_WGRAD_STREAM=0 / 1 forces it off / on.
+      from lsi.nnutils import _hip_conv  # pylint: disable=g-import-not-at-top
+      env = os.environ.get('LSI_WGRAD_STREAM', '')
+      _hip_conv.enable_wgrad_stream(
+          self.world == 1 and not self.flat_grads and
+          (env == '1' or (env != '0' and not self.use_graph)))
     self.resume()
     if self.flat_grads:
       self._setup_flat_grads()

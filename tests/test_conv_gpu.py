@@ -832,3 +832,63 @@ def test_split_convolution_over_a_skip_connection_and_without_workspace(dev, mon
   assert torch.equal(out, y2)
   io.workspace = None
   assert lib.lsi_conv2d_run(ctypes.byref(d), 0, ctypes.byref(io), _C.stream_ptr(dev)) == -2  # LSI_ENULL
+
+
+def test_weight_gradients_on_the_side_stream_equal_the_in_stream_ones(dev):
+  """_hip_conv.enable_wgrad_stream: a backward pass whose weight gradients run on
+  a second stream (forked behind the incoming gradient, joined by the callback at
+  the end of the pass) gives bit-identical gradients (a chain without batch
+  norms: every kernel of it is deterministic); a parameter that already holds a
+  gradient (accumulation) stays on the main stream and accumulates."""
+  from lsi.nnutils import _hip_conv, nets
+  g = torch.Generator().manual_seed(10)
+  n, h, w = 4, 24, 40
+  mk = lambda *shape: (torch.randn(shape, generator=g) * (2.0 / (shape[1] * shape[2] * shape[3])) ** 0.5
+                       ).to(dev).requires_grad_(True)
+  w1, w2, w3, w5 = mk(64, 64, 3, 3), mk(128, 64, 3, 3), mk(128, 128, 3, 3), mk(32, 64, 5, 5)
+  wt = mk(128, 64, 4, 4)     # (ConvTranspose2d: in x out x k x k)
+  params = [w1, w2, w3, wt, w5]
+  x = _clast(torch.randn((n, 64, h, w), generator=g).to(dev).to(torch.bfloat16)).requires_grad_(True)
+
+  def net():
+    y = torch.relu(_hip_conv.conv2d(x, w1, 1, 1, 1, h, w))
+    p2 = nets._same_pad(h, 3, 2)[0], nets._same_pad(w, 3, 2)[0]
+    y = torch.relu(_hip_conv.conv2d(y, w2, 2, p2[0], p2[1], h // 2, w // 2))
+    y = torch.relu(_hip_conv.conv2d(y, w3, 1, 1, 1, h // 2, w // 2))
+    y = torch.relu(_hip_conv.conv_transpose2d(y, wt))
+    y = _hip_conv.conv2d(y, w5, 1, 2, 2, h, w)
+    return y.float().square().mean()
+
+  def grads():
+    for p in params:
+      p.grad = None
+    x.grad = None
+    net().backward()
+    torch.cuda.synchronize()
+    return [p.grad.clone() for p in params] + [x.grad.clone()]
+
+  old = _hip_conv.enable_wgrad_stream(False)
+  try:
+    want = grads()
+    for a, b in zip(grads(), want):
+      assert torch.equal(a, b)                    # (deterministic in-stream)
+    _hip_conv.enable_wgrad_stream(True)
+    for _ in range(3):
+      got = grads()
+      assert not _hip_conv._SIDE_PENDING          # (joined and released)
+      for a, b in zip(got, want):
+        assert torch.equal(a, b)
+    # accumulation into existing gradients: main stream, twice the values
+    net().backward()
+    torch.cuda.synchronize()
+    for p, b in zip(params, want):
+      assert float((p.grad - 2 * b).abs().max()) <= 1e-6 * float(b.abs().max()) + 1e-12
+    # torch.autograd.grad (no .grad involved) joins, too
+    for p in params:
+      p.grad = None
+    gs = torch.autograd.grad(net(), params)
+    torch.cuda.synchronize()
+    for a, b in zip(gs, want):
+      assert torch.equal(a, b)
+  finally:
+    _hip_conv.enable_wgrad_stream(old)
