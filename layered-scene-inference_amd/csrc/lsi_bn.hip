@@ -483,9 +483,25 @@ bool bn_shape_ok(long npix, int C, int bf16) {
 // last workgroup publishes the constants, the others wait for a flag -- was
 // built and measured: 16.4 / 21.7 us against 13.8 / 19.5 us for two launches
 // at 1.6 MB, 277-281 against 285 samples/s for the bf16 training step; dropped.)
-int bn_grid(long npix, int C, int bf16) {
+// Workgroups per group of a pass.  >= 16 steps of `rows` pixels per workgroup (the
+// reduction and its atomics amortised), at most 8 workgroups per CU.  Tensors of
+// at most 2 M elements (the U-Net's 2 x 6 ... 16 x 48 maps) used to get 12 - 48
+// workgroups that way, each a chain of 4 dependent rounds of loads on an idle
+// chip: there the steps per workgroup go down to 2 while the launch has fewer
+// than 512 workgroups (tools/bn_small_time.py, pair of kernels inside a graph:
+// 18.9 -> 10.8 us backward, 14.7 -> 9.8 forward at 8 x 4 x 12 x 512; the 6 - 25 MB
+// tensors get slower with more workgroups -- more atomics on the same lines --
+// and keep 16).  LSI_BN_MIN_STEPS overrides the 2.
+int bn_grid(long npix, int C, int bf16, int groups = 1) {
+  static const char* env = getenv("LSI_BN_MIN_STEPS");   // experiments
+  const int min_steps = env ? atoi(env) : 2;
   const int rows = BN_THREADS / (C / (bf16 ? 8 : 4));
-  long g = (npix + rows * 16 - 1) / (rows * 16);   // >= 16 steps per workgroup
+  const long nstep = (npix + rows - 1) / rows;        // steps of the whole group
+  long steps = 16;
+  if (npix * C * groups <= (2l << 20))
+    while (steps > min_steps && (nstep + steps - 1) / steps * groups < 512) steps >>= 1;
+  if (steps < 1) steps = 1;
+  long g = (nstep + steps - 1) / steps;
   if (g < 1) g = 1;
   if (g > 2048) g = 2048;                           // 8 workgroups per CU
   return (int)g;
@@ -511,7 +527,7 @@ extern "C" int lsi_bn_relu_fwd(const void* x, void* y, const float* beta,
       groups > 65535)
     return LSI_EINVAL;
   hipStream_t st = (hipStream_t)stream_;
-  const dim3 grid(bn_grid(npix, C, bf16), groups), blk(BN_THREADS);
+  const dim3 grid(bn_grid(npix, C, bf16, groups), groups), blk(BN_THREADS);
   if (bf16) {
     hipLaunchKernelGGL(bn_stats_kernel<true>, grid, blk, 0, st, x, beta, workspace,
                        mean_rstd, (long)npix, C, eps);
@@ -533,7 +549,7 @@ extern "C" int lsi_bn_relu_norm(const void* x, void* y, const float* beta, float
   if (!bn_shape_ok(npix, C, bf16) || !al16(x) || !al16(y) || groups < 1 || groups > 65535)
     return LSI_EINVAL;
   hipStream_t st = (hipStream_t)stream_;
-  const dim3 grid(bn_grid(npix, C, bf16), groups), blk(BN_THREADS);
+  const dim3 grid(bn_grid(npix, C, bf16, groups), groups), blk(BN_THREADS);
   const int ns = lsi_bn_stat_slots(C);
   if (bf16)
     hipLaunchKernelGGL(bn_norm_sums_kernel<true>, grid, blk, 0, st, x, y, beta, workspace,
@@ -564,7 +580,7 @@ extern "C" int lsi_bn_relu_bwd(const void* x, const void* dy, const float* mean_
       groups < 1 || groups > 65535)
     return LSI_EINVAL;
   hipStream_t st = (hipStream_t)stream_;
-  const dim3 grid(bn_grid(npix, C, bf16), groups), blk(BN_THREADS);
+  const dim3 grid(bn_grid(npix, C, bf16, groups), groups), blk(BN_THREADS);
   if (bf16) {
     hipLaunchKernelGGL(bn_bwd_stats_kernel<true>, grid, blk, 0, st, x, dy, mean_rstd,
                        beta, workspace, (long)npix, C, relu);
