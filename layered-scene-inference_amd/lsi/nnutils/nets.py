@@ -474,6 +474,19 @@ class DecoderSimple(nn.Module):
     return feat
 
 
+# The per-layer decoders of the LDI heads on one stream each (PixelwisePredictor):
+# off by default; the Trainer switches it on for eager single-process runs (inside
+# a captured HIP graph the fork / join edges cost more than the overlap wins).
+HEAD_STREAMS = {'on': os.environ.get('LSI_HEAD_STREAMS', '') == '1'}
+_HEAD_STREAM_POOL = {}
+
+
+def enable_head_streams(on=True):
+  old = HEAD_STREAMS['on']
+  HEAD_STREAMS['on'] = bool(on)
+  return old
+
+
 class PixelwisePredictor(nn.Module):
   """pixelwise_predictor (reference nets.py:117-161): per layer an own
   DecoderSimple (n_layerwise_steps stages) and a 3x3 sigmoid head with bias.
@@ -494,8 +507,31 @@ class PixelwisePredictor(nn.Module):
 
   def forward(self, feat, skip_feat=None):
     preds = []
-    for dec, head in zip(self.decoders, self.preds):
-      preds.append(head(dec(feat, skip_feat)))
+    if HEAD_STREAMS['on'] and feat.is_cuda and len(self.decoders) > 1:
+      # The L per-layer decoders are independent chains (reference nets.py:131-158:
+      # one decoder_simple per layer): decoder l > 0 runs on its own stream, forked
+      # behind the features and joined before the stack.  autograd runs a node's
+      # backward on its forward's stream and synchronises across streams itself,
+      # so the backward chains overlap the same way.  Every per-stream resource of
+      # the kernels (batch-norm and weight-gradient workspaces) is keyed by stream.
+      dev = feat.device
+      main = torch.cuda.current_stream(dev)
+      pool = _HEAD_STREAM_POOL.setdefault(dev.index, [])
+      while len(pool) < len(self.decoders) - 1:
+        pool.append(torch.cuda.Stream(device=dev))
+      for i, (dec, head) in enumerate(zip(self.decoders, self.preds)):
+        if i == 0:
+          preds.append(head(dec(feat, skip_feat)))
+          continue
+        side = pool[i - 1]
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+          preds.append(head(dec(feat, skip_feat)))
+      for side in pool[:len(self.decoders) - 1]:
+        main.wait_stream(side)
+    else:
+      for dec, head in zip(self.decoders, self.preds):
+        preds.append(head(dec(feat, skip_feat)))
     stacked = torch.stack(preds, dim=0)        # L x B x nc x H x W
     return stacked.permute(0, 1, 3, 4, 2)      # L x B x H x W x nc (view)
 

@@ -154,6 +154,12 @@ class Trainer(object):
       _hip_conv.enable_wgrad_stream(
           self.world == 1 and not self.flat_grads and
           (env == '1' or (env != '0' and not self.use_graph)))
+      # ... and the heads' per-layer decoders on a stream each (nets.HEAD_STREAMS)
+      from lsi.nnutils import nets  # pylint: disable=g-import-not-at-top
+      env = os.environ.get('LSI_HEAD_STREAMS', '')
+      nets.enable_head_streams(
+          self.world == 1 and not self.flat_grads and
+          (env == '1' or (env != '0' and not self.use_graph)))
     self.resume()
     if self.flat_grads:
       self._setup_flat_grads()
