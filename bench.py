@@ -524,7 +524,7 @@ TRAIN_CONFIGS = [
 ]
 
 
-def train_step_extra(dev, budget_s, steps=8):
+def train_step_extra(dev, budget_s, steps=16):
   """the full training step -- network (bf16 convolutions on
   the own MFMA kernels, fp32 accumulation), both directions' per-layer + composed
   renderings and their backward, the six losses, fused Adam and the re-pack of
@@ -537,7 +537,9 @@ def train_step_extra(dev, budget_s, steps=8):
   out = {'note': 'full train step (U-Net + heads bf16 on own MFMA kernels, 2 x '
                  'forward_splat_both + backward, losses, fused Adam, weight re-pack); '
                  'tflops = samples/s x 6 x forward GFLOP per image (SURVEY 8d); '
-                 'peak = %.0f TFLOP/s dense bf16; not part of `value`' % MFMA_PEAK_TFLOPS,
+                 'peak = %.0f TFLOP/s dense bf16; eager = weight gradients and the per-layer '
+                 'decoders on side streams, graph = one stream captured; not part of `value`'
+                 % MFMA_PEAK_TFLOPS,
          'configs': {}}
   t_start = time.perf_counter()
   for name, nl, h, w, b, gflop in TRAIN_CONFIGS:
@@ -578,6 +580,10 @@ def train_step_extra(dev, budget_s, steps=8):
       except Exception as e:  # pylint: disable=broad-except
         res[mode] = {'error': '%s: %s' % (type(e).__name__, e)}
       torch.cuda.empty_cache()
+    done = [(res[m]['samples_per_s'], m) for m in ('graph', 'eager') if 'samples_per_s' in res[m]]
+    if done:
+      res['best'] = {'mode': max(done)[1], 'samples_per_s': max(done)[0],
+                     'frac_of_mfma_peak': res[max(done)[1]]['frac_of_mfma_peak']}
     out['configs'][name] = res
   out['wall_s'] = time.perf_counter() - t_start
   return out

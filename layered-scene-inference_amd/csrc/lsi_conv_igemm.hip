@@ -111,6 +111,7 @@ struct IgArgs {
   // units that wait a load latency per 36 - 72 MFMAs.
   float* part;
   int ks;
+  int swz;   // XCD-aware workgroup order (see the kernel's index decode)
   IgClass cls[4];
 };
 
@@ -134,11 +135,36 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int pxl = lane & 15, kg = lane >> 4;
   const int ncb = a.Cout / BN;
-  const int zz = blockIdx.z / ncb, co0 = (blockIdx.z - zz * ncb) * BN;
-  const int ksi = zz / (a.ncls * a.N), zc = zz - ksi * (a.ncls * a.N);
-  const int ci_ = zc / a.N, n = zc - ci_ * a.N;
+  // Workgroup -> (tile, image, class, channel block, split).  The workgroups that
+  // read the same input patch -- the parity classes of a stride-2 data gradient /
+  // transposed convolution, the blocks of output channels, the splits -- used to
+  // sit gridDim.x * gridDim.y * N apart in dispatch order: never in flight
+  // together, on whatever XCD, and the patch came from HBM once per class
+  // (`upcnv1`: 4 x 50 MB read for 100 MB written).  a.swz: with block b on XCD
+  // b % 8 (observed placement; a speed matter only), the (class, channel block,
+  // split) siblings of a tile are consecutive blocks OF ONE XCD -- eight apart in
+  // dispatch order: in flight together, sharing that XCD's L2.
+  int bx = blockIdx.x, by = blockIdx.y, co0, ksi, ci_, n;
+  if (a.swz) {
+    const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const unsigned xcd = lin & 7u, r = lin >> 3;
+    const unsigned nsib = (unsigned)(a.ks * a.ncls * ncb);
+    const unsigned g = r % nsib, tile = (r / nsib) * 8u + xcd;   // tile over gx * gy * N
+    bx = (int)(tile % gridDim.x);
+    by = (int)((tile / gridDim.x) % gridDim.y);
+    n = (int)(tile / (gridDim.x * gridDim.y));
+    co0 = (int)(g % ncb) * BN;
+    ci_ = (int)((g / ncb) % a.ncls);
+    ksi = (int)(g / (ncb * a.ncls));
+  } else {
+    const int zz = blockIdx.z / ncb;
+    co0 = (blockIdx.z - zz * ncb) * BN;
+    ksi = zz / (a.ncls * a.N);
+    const int zc = zz - ksi * (a.ncls * a.N);
+    ci_ = zc / a.N; n = zc - ci_ * a.N;
+  }
   const IgClass& k = a.cls[ci_];
-  const int i0 = blockIdx.y * TH, j0 = blockIdx.x * 16;
+  const int i0 = by * TH, j0 = bx * 16;
   if (i0 >= k.OHt || j0 >= k.OWt) return;  // (the grid covers the largest class)
   const int PW = a.PW, npix = a.PH * PW;
   unsigned char* const patch = ig_smem;
@@ -319,7 +345,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgArgs a) {
     const int per_grp = a.N / a.st_groups, grp = n / per_grp;
     // (the hand-over tag of the group, by the workgroup of its first tile: see
     // lsi_splat_internal.h)
-    if (tid == 0 && blockIdx.x == 0 && blockIdx.y == 0 && co0 == 0 && ci_ == 0 &&
+    if (tid == 0 && bx == 0 && by == 0 && co0 == 0 && ci_ == 0 &&
         n == grp * per_grp)
       __hip_atomic_store(reinterpret_cast<int*>(a.st_ws + (size_t)grp * LSI_BN_WS_STRIDE) +
                              LSI_BN_WS_TAG,
@@ -589,6 +615,8 @@ int ig_splits(const IgArgs& k, long nwg) {
   return ks < 2 ? 1 : (int)ks;
 }
 
+static inline int bn_of(int nct) { return 16 * nct; }
+
 struct IgPlan {
   int rw, nct, ks;
   size_t lds;
@@ -633,6 +661,17 @@ int ig_launch(IgArgs& k, hipStream_t stream, void* workspace = nullptr,
     k.ks = pl.ks;
     k.part = (float*)workspace;
     grid.z *= pl.ks;
+  }
+  {
+    // (bijective only when the tiles split evenly over the eight XCDs.  Taken for
+    // the parity classes of large maps only -- `upcnv1` 88 -> 71 us forward,
+    // profiles/r06/conv_bench_swz{0,1}.txt; where the WEIGHTS are the traffic -- the
+    // bottleneck maps, their splits and channel blocks -- the workgroups that share
+    // weights are neighbours in the plain order and the swizzle costs 3 - 8 us.)
+    static const char* env = getenv("LSI_IGEMM_SWZ");   // experiments
+    const long tiles = (long)grid.x * grid.y * k.N;
+    k.swz = (env ? atoi(env) != 0 : true) && k.ks == 1 && k.ncls > 1 && tiles >= 1024 &&
+            tiles % 8 == 0;
   }
   const void* fn = nullptr;
 #define IG_CASE(R, C, GG) \
