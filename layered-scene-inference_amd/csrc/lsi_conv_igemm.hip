@@ -670,7 +670,7 @@ int ig_launch(IgArgs& k, hipStream_t stream, void* workspace = nullptr,
     // weights are neighbours in the plain order and the swizzle costs 3 - 8 us.)
     static const char* env = getenv("LSI_IGEMM_SWZ");   // experiments
     const long tiles = (long)grid.x * grid.y * k.N;
-    k.swz = (env ? atoi(env) != 0 : true) && k.ks == 1 && k.ncls > 1 && tiles >= 1024 &&
+    k.swz = (env ? atoi(env) != 0 : true) && k.ks == 1 && k.ncls > 1 && tiles >= 512 &&
             tiles % 8 == 0;
   }
   const void* fn = nullptr;
