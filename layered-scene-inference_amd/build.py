@@ -64,7 +64,7 @@ def build(force=False, verbose=False, hooks=False):
   report.clear()
   if not force and not _stale(so, srcs + HEADERS):
     # (the library is newer than every source and header: nothing to do -- the
-    # objects need not exist; they do not travel to the GPU box, .gpurunignore)
+    # objects need not exist)
     report[os.path.basename(so)] = 'reused'
     return so
   for src in srcs:
