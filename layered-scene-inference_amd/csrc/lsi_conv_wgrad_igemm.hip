@@ -29,6 +29,7 @@
 //   convolution's output gradient and whose "output gradient" is its input).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/lsi_hip.h"
@@ -67,6 +68,12 @@ struct GwArgs {
   // rounds of the chip for 1.1 - 1.5 rounds of work.  Every workgroup writes one
   // partial sum (nstrip * PS of them to fold).
   int nrs, PS;
+  // XCD-aware workgroup order: the workgroups of one pixel block -- the (input
+  // chunk, tap group, output block) siblings, which read the same input rows and
+  // the same gy tile -- are consecutive blocks of ONE XCD (block b runs on XCD
+  // b % 8: observed, a speed matter only) instead of gridDim.x apart: in flight
+  // together, sharing that XCD's L2.  Needs gridDim.x % 8 == 0.
+  int swz;
   signed char tdy[GW_MAXTAPS + 3], tdx[GW_MAXTAPS + 3];
 };
 
@@ -96,10 +103,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_igemm_kernel(GwArgs a) {
   __bf16* const xs = reinterpret_cast<__bf16*>(gw_smem);
   __bf16* const gs = xs + (size_t)npix * XS;
 
-  const int st = blockIdx.x % a.nstrip, slot = blockIdx.x / a.nstrip;
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (a.swz) {
+    const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const unsigned xcd = lin & 7u, r = lin >> 3;
+    const unsigned nsib = gridDim.y * gridDim.z, g = r % nsib;
+    bx = (int)((r / nsib) * 8u + xcd);
+    by = (int)(g % gridDim.y);
+    bz = (int)(g / gridDim.y);
+  }
+  const int st = bx % a.nstrip, slot = bx / a.nstrip;
   const int n = 0;   // (goff below is relative to image 0; `shift` adds the image)
-  const int tg = blockIdx.y % a.ntg, c0 = (blockIdx.y / a.ntg) * 32;
-  const int o0 = blockIdx.z * BN;
+  const int tg = by % a.ntg, c0 = (by / a.ntg) * 32;
+  const int o0 = bz * BN;
   const int t0 = tg * GW_GT, nt = min(GW_GT, a.ntaps - t0);
   const int i_end = a.OH, j0 = st * 32;
   const int nstage = a.N * a.nrs;
@@ -210,7 +226,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_igemm_kernel(GwArgs a) {
   }
   // accumulator of lane (t, g), register r: co = 16 m + 4 g + r, ci = 16 c + t
   const size_t nout = (size_t)a.Cout * a.Cin * a.khw;
-  float* const out = a.part + (size_t)blockIdx.x * nout;
+  float* const out = a.part + (size_t)bx * nout;
 #pragma unroll
   for (int j = 0; j < PB; ++j) {
     const int p = wave + j * NW;
@@ -361,6 +377,19 @@ bool gw_plan(const LsiConvDesc* d, GwArgs& k, int* nct_out, size_t* lds_out, int
   if (ps < 1) ps = 1;
   if (ps > nstage) ps = nstage;
   while (ps > 1 && (size_t)(ps * k.nstrip) * wbytes > GW_PART_CAP) --ps;
+  // (the sibling swizzle needs ps * nstrip % 8 == 0: the largest such ps, if it
+  // keeps at least three quarters of the workgroups)
+  k.swz = 0;
+  {
+    static const char* env = getenv("LSI_WGRAD_SWZ");   // experiments
+    const int mode = env ? atoi(env) : 1;   // 0 off, 1 on, 2 stride-1 layers only
+    const bool want = mode != 0 && chan_wgs > 1 && (mode != 2 || s == 1);
+    if (want) {
+      long q = ps;
+      while (q >= 1 && (q * k.nstrip) % 8) --q;
+      if (q >= 1 && 4 * q >= 3 * ps) { ps = q; k.swz = 1; }
+    }
+  }
   k.PS = (int)ps;
   const long nblk = ps * k.nstrip;
   if ((size_t)nblk * wbytes > GW_PART_CAP || nblk > 65535 * 32L) return false;

@@ -93,7 +93,16 @@ def enable_wgrad_stream(on=True):
   return old
 
 
+# queued: the join callback of the running backward pass is on the engine's list;
+# seq: _FWD_SEQ when it was queued.  A forward call of this module since then means
+# that pass is over -- if its callback never ran (the pass raised), the next
+# backward joins what it left and queues its own.
+_SIDE_CB = {'queued': False, 'seq': -1}
+_FWD_SEQ = [0]
+
+
 def _join_side_streams():
+  _SIDE_CB['queued'] = False
   pend, _SIDE_PENDING[:] = list(_SIDE_PENDING), []
   seen = set()
   for main, side, _ in pend:
@@ -122,8 +131,15 @@ def _wgrad_async(weight, fn, *keep):
   side.wait_event(ev)
   with torch.cuda.stream(side):
     gw = fn()
-  if not _SIDE_PENDING:
+  if _SIDE_CB['queued'] and _SIDE_CB['seq'] != _FWD_SEQ[0]:
+    _SIDE_CB['queued'] = False
+  if not _SIDE_CB['queued']:
+    if _SIDE_PENDING:
+      # (left by a backward pass that raised before its callback ran: join it now)
+      _join_side_streams()
     torch.autograd.Variable._execution_engine.queue_callback(_join_side_streams)
+    _SIDE_CB['queued'] = True
+    _SIDE_CB['seq'] = _FWD_SEQ[0]
   _SIDE_PENDING.append((main, side, keep))
   return gw
 
@@ -602,6 +618,8 @@ def _igemm(entry, desc, src, weight, out, bn_groups=0, training=False):
   """bn_groups > 0: the kernel also adds the batch-norm sums of `out` to the
   workspace (as lsi_conv2d_*_bnstats) for the lsi_bn_relu_norm that has to follow."""
   mode = 1 if entry == 'lsi_conv2d_bwd_data' else 0
+  if training:          # (a forward call of a layer: see _SIDE_CB)
+    _FWD_SEQ[0] += 1
   packed = _packed(desc, mode, weight, training)
   dev = src.device
   bn_ws = 0

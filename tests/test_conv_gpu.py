@@ -890,5 +890,18 @@ def test_weight_gradients_on_the_side_stream_equal_the_in_stream_ones(dev):
     torch.cuda.synchronize()
     for a, b in zip(gs, want):
       assert torch.equal(a, b)
+    # a backward pass that raises after its weight gradients were forked (the
+    # engine may never run its join callback) leaves nothing behind for the next
+    def boom(_g):
+      raise RuntimeError('boom')
+    for p in params:
+      p.grad = None
+    h = x.register_hook(boom)
+    with pytest.raises(RuntimeError, match='boom'):
+      net().backward()
+    h.remove()
+    for a, b in zip(grads(), want):
+      assert torch.equal(a, b)
+    assert not _hip_conv._SIDE_PENDING
   finally:
     _hip_conv.enable_wgrad_stream(old)
