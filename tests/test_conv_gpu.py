@@ -896,10 +896,10 @@ def test_weight_gradients_on_the_side_stream_equal_the_in_stream_ones(dev):
       raise RuntimeError('boom')
     for p in params:
       p.grad = None
-    h = x.register_hook(boom)
+    hk = x.register_hook(boom)
     with pytest.raises(RuntimeError, match='boom'):
       net().backward()
-    h.remove()
+    hk.remove()
     for a, b in zip(grads(), want):
       assert torch.equal(a, b)
     assert not _hip_conv._SIDE_PENDING
