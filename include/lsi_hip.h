@@ -319,12 +319,21 @@ int lsi_bilinear_fwd(int32_t B, int32_t Hs, int32_t Ws, int32_t C, int32_t Ht,
  * sampling.bilinear (compose=False), sampling.py:124-130: the four taps, each
  * multiplied by its border-validity mask, and the four un-masked bilinear
  * weights, in the reference's order (x0,y0), (x0,y1), (x1,y0), (x1,y1).
- *   taps [4,B,Ht,Wt,C], wts [4,B,Ht,Wt,1].  Forward only (no caller of the
- * reference differentiates this form).
+ *   taps [4,B,Ht,Wt,C], wts [4,B,Ht,Wt,1].
+ * lsi_bilinear_taps_bwd: TF autodiff of that form -- the taps' gradients are
+ * scatter-added (through the masks) into g_imgs [B,Hs,Ws,C] (zero on entry; may
+ * be NULL), the weights' gradients g_wts [4,B,Ht,Wt,1] (may be NULL: zero) give
+ * g_coords [B,Ht,Wt,2] (may be NULL): d wts / d x = (-wy0, -wy1, +wy0, +wy1),
+ * d wts / d y = (-wx0, +wx0, -wx1, +wx1); floor / clip / equal carry no gradient,
+ * so the taps contribute nothing to g_coords.
  */
 int lsi_bilinear_taps(int32_t B, int32_t Hs, int32_t Ws, int32_t C, int32_t Ht,
                       int32_t Wt, const float* imgs, const float* coords,
                       float* taps, float* wts, lsi_stream_t stream);
+int lsi_bilinear_taps_bwd(int32_t B, int32_t Hs, int32_t Ws, int32_t C, int32_t Ht,
+                          int32_t Wt, const float* coords, const float* g_taps,
+                          const float* g_wts, float* g_imgs, float* g_coords,
+                          lsi_stream_t stream);
 
 /*
  * Gradients of lsi_bilinear_fwd.  g_imgs [B,Hs,Ws,C] must be zero on entry

@@ -234,6 +234,47 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(
   if (g_coords) { g_coords[2 * ti] = gx; g_coords[2 * ti + 1] = gy; }
 }
 
+// TF autodiff of sampling.py:124-130 (compose=False).  The taps are gathers times
+// a 0 / 1 mask: their gradient is a scatter-add into the image (floor / clip /
+// equal carry no gradient to the coordinates); the weights are products of
+// (x1 - x), (x - x0), (y1 - y), (y - y0) with d/dx = -1, +1 and d/dy = -1, +1.
+__global__ __launch_bounds__(256) void bilinear_taps_bwd_kernel(
+    int Hs, int Ws, int C, int Nt, int B, const float* __restrict__ coords,
+    const float* __restrict__ g_taps, const float* __restrict__ g_wts,
+    float* __restrict__ g_imgs, float* __restrict__ g_coords) {
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= Nt) return;
+  const size_t ti = (size_t)b * Nt + i;
+  const size_t N = (size_t)B * Nt;
+  Taps t;
+  taps_of(coords[2 * ti], coords[2 * ti + 1], Hs, Ws, t);
+  if (g_coords) {
+    float gx = 0.f, gy = 0.f;
+    if (g_wts) {
+      const float g0 = g_wts[0 * N + ti], g1 = g_wts[1 * N + ti], g2 = g_wts[2 * N + ti],
+                  g3 = g_wts[3 * N + ti];
+      // wts: wx0 wy0, wx0 wy1, wx1 wy0, wx1 wy1
+      gx = (g2 * t.wy0 + g3 * t.wy1) - (g0 * t.wy0 + g1 * t.wy1);
+      gy = (g1 * t.wx0 + g3 * t.wx1) - (g0 * t.wx0 + g2 * t.wx1);
+    }
+    g_coords[2 * ti] = gx;
+    g_coords[2 * ti + 1] = gy;
+  }
+  if (!g_imgs || !g_taps || !t.ok) return;
+  float* gb = g_imgs + (size_t)b * Hs * Ws * C;
+  const float m[4] = {t.vx0 * t.vy0, t.vx0 * t.vy1, t.vx1 * t.vy0, t.vx1 * t.vy1};
+  const int idx[4] = {t.i00, t.i01, t.i10, t.i11};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (m[k] == 0.f) continue;
+    for (int ch = 0; ch < C; ++ch) {
+      const float u = g_taps[(k * N + ti) * C + ch];
+      if (u != 0.f) atomic_add_f32(gb + (size_t)idx[k] * C + ch, u);
+    }
+  }
+}
+
 inline int launch_rc() {
   return hipGetLastError() == hipSuccess ? LSI_OK : LSI_ELAUNCH;
 }
@@ -327,6 +368,22 @@ int lsi_bilinear_taps(int32_t B, int32_t Hs, int32_t Ws, int32_t C, int32_t Ht,
   hipLaunchKernelGGL(bilinear_taps_kernel, dim3((Nt + 255) / 256, B), dim3(256),
                      0, (hipStream_t)stream, Hs, Ws, C, Nt, B, imgs, coords, taps,
                      wts);
+  return launch_rc();
+}
+
+int lsi_bilinear_taps_bwd(int32_t B, int32_t Hs, int32_t Ws, int32_t C, int32_t Ht,
+                          int32_t Wt, const float* coords, const float* g_taps,
+                          const float* g_wts, float* g_imgs, float* g_coords,
+                          lsi_stream_t stream) {
+  if (B <= 0 || Hs <= 0 || Ws <= 0 || C <= 0 || Ht <= 0 || Wt <= 0 ||
+      B > 65535 || (int64_t)Hs * Ws >= (1 << 24))
+    return LSI_EINVAL;
+  if (!coords) return LSI_ENULL;
+  if (g_imgs && !g_taps) return LSI_ENULL;
+  const int Nt = Ht * Wt;
+  hipLaunchKernelGGL(bilinear_taps_bwd_kernel, dim3((Nt + 255) / 256, B), dim3(256),
+                     0, (hipStream_t)stream, Hs, Ws, C, Nt, B, coords, g_taps, g_wts,
+                     g_imgs, g_coords);
   return launch_rc();
 }
 

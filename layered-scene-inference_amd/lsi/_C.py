@@ -111,6 +111,7 @@ SIGNATURES = {
     'lsi_projection_matrices': (ctypes.c_int, [_I32] + [_VP] * 4 + [_I32, _VP]),
     'lsi_bilinear_taps': (ctypes.c_int, [_I32] * 6 + [_VP] * 5),
     'lsi_bilinear_bwd': (ctypes.c_int, [_I32] * 6 + [_VP] * 6),
+    'lsi_bilinear_taps_bwd': (ctypes.c_int, [_I32] * 6 + [_VP] * 5 + [_VP]),
     'lsi_loss_workspace_bytes': (_SZ, []),
     'lsi_zbuf_comp_loss_fwd': (ctypes.c_int, [_LP] + [_VP] * 6 + [_SZ, _VP]),
     'lsi_zbuf_comp_loss_bwd': (ctypes.c_int, [_LP] + [_VP] * 9),

@@ -62,25 +62,55 @@ def bilinear(imgs, coords, compose=True):
   return _Bilinear.apply(imgs, coords)
 
 
+class _BilinearTaps(torch.autograd.Function):
+  """lsi_bilinear_taps / lsi_bilinear_taps_bwd: taps [4,B,Ht,Wt,C] and weights
+  [4,B,Ht,Wt,1] of sampling.bilinear(compose=False)."""
+
+  @staticmethod
+  def forward(ctx, imgs, coords):
+    dev = _C.require_device(imgs, coords)
+    imgs, coords = imgs.contiguous(), coords.contiguous()
+    b, hs, ws, c = imgs.shape
+    _, ht, wt, _ = coords.shape
+    taps = torch.empty((4, b, ht, wt, c), dtype=torch.float32, device=dev)
+    wts = torch.empty((4, b, ht, wt, 1), dtype=torch.float32, device=dev)
+    rc = _C.lib().lsi_bilinear_taps(*_dims(b, hs, ws, c, ht, wt), _C.ptr(imgs),
+                                    _C.ptr(coords), _C.ptr(taps), _C.ptr(wts),
+                                    _C.stream_ptr(dev))
+    _C.check(rc, 'lsi_bilinear_taps')
+    ctx.save_for_backward(coords)
+    ctx.img_shape = tuple(imgs.shape)
+    return taps, wts
+
+  @staticmethod
+  def backward(ctx, g_taps, g_wts):
+    coords, = ctx.saved_tensors
+    dev = coords.device
+    b, hs, ws, c = ctx.img_shape
+    _, ht, wt, _ = coords.shape
+    g_imgs = g_coords = None
+    if ctx.needs_input_grad[0]:
+      g_imgs = torch.zeros(ctx.img_shape, dtype=torch.float32, device=dev)
+    if ctx.needs_input_grad[1]:
+      g_coords = torch.empty_like(coords)
+    if g_imgs is not None or g_coords is not None:
+      g_taps = None if g_taps is None else g_taps.contiguous()
+      g_wts = None if g_wts is None else g_wts.contiguous()
+      rc = _C.lib().lsi_bilinear_taps_bwd(
+          *_dims(b, hs, ws, c, ht, wt), _C.ptr(coords),
+          _C.ptr(g_taps) if g_imgs is not None else None, _C.ptr(g_wts),
+          _C.ptr(g_imgs), _C.ptr(g_coords), _C.stream_ptr(dev))
+      _C.check(rc, 'lsi_bilinear_taps_bwd')
+    return g_imgs, g_coords
+
+
 def _bilinear_taps(imgs, coords):
   """compose=False (reference sampling.py:124-130): the four border-masked taps
   and the four un-masked weights, tap order (x0,y0), (x0,y1), (x1,y0), (x1,y1)
-  -- lsi_bilinear_taps.  Forward only: no caller of the reference uses this
-  form, let alone differentiates it; inputs that require a gradient are an
-  error rather than a silently cut graph."""
-  if torch.is_grad_enabled() and (imgs.requires_grad or coords.requires_grad):
-    raise RuntimeError('bilinear(compose=False) is not differentiable here '
-                       '(lsi_bilinear_taps has no backward); detach the inputs')
-  dev = _C.require_device(imgs, coords)
-  imgs, coords = imgs.contiguous(), coords.contiguous()
-  b, hs, ws, c = imgs.shape
-  _, ht, wt, _ = coords.shape
-  taps = torch.empty((4, b, ht, wt, c), dtype=torch.float32, device=dev)
-  wts = torch.empty((4, b, ht, wt, 1), dtype=torch.float32, device=dev)
-  rc = _C.lib().lsi_bilinear_taps(*_dims(b, hs, ws, c, ht, wt), _C.ptr(imgs),
-                                  _C.ptr(coords), _C.ptr(taps), _C.ptr(wts),
-                                  _C.stream_ptr(dev))
-  _C.check(rc, 'lsi_bilinear_taps')
+  -- lsi_bilinear_taps; differentiable as TF differentiates it
+  (lsi_bilinear_taps_bwd: the taps scatter their gradient into the image, the
+  weights give the coordinates' gradient)."""
+  taps, wts = _BilinearTaps.apply(imgs, coords)
   return list(taps.unbind(0)), list(wts.unbind(0))
 
 

@@ -119,6 +119,33 @@ def bilinear(imgs, coords):
   return out
 
 
+def bilinear_taps(imgs, coords):
+  """sampling.py:124-130 (compose=False): ([4 border-masked taps], [4 weights]) in
+  the reference's order (x0,y0), (x0,y1), (x1,y0), (x1,y1) -- the gradient
+  oracle of lsi_bilinear_taps_bwd (same op graph: floor / clip / equal carry no
+  gradient, gathers scatter theirs)."""
+  b, hs, ws, c = imgs.shape
+  dt = imgs.dtype
+  x, y = coords[..., 0:1] - 0.5, coords[..., 1:2] - 0.5
+  x0, y0 = torch.floor(x).detach(), torch.floor(y).detach()
+  x1, y1 = x0 + 1, y0 + 1
+  x0s, x1s = x0.clamp(0, ws - 1), x1.clamp(0, ws - 1)
+  y0s, y1s = y0.clamp(0, hs - 1), y1.clamp(0, hs - 1)
+  wx0, wx1, wy0, wy1 = x1 - x, x - x0, y1 - y, y - y0
+  vx0, vx1 = (x0 == x0s).to(dt), (x1 == x1s).to(dt)
+  vy0, vy1 = (y0 == y0s).to(dt), (y1 == y1s).to(dt)
+  flat = imgs.reshape(b, hs * ws, c)
+
+  def tap(xs_, ys_):
+    idx = (xs_ + ys_ * ws).long()[..., 0]
+    return torch.stack([flat[bi][idx[bi]] for bi in range(b)])
+
+  ims = [vx0 * vy0 * tap(x0s, y0s), vx0 * vy1 * tap(x0s, y1s),
+         vx1 * vy0 * tap(x1s, y0s), vx1 * vy1 * tap(x1s, y1s)]
+  wts = [wx0 * wy0, wx0 * wy1, wx1 * wy0, wx1 * wy1]
+  return ims, wts
+
+
 # ---------------------------------------------------------------------------
 # Losses and layer composition (gradient oracles of csrc/lsi_loss.hip).  Same
 # op graphs as the reference, torch ops, any float dtype; their forward values

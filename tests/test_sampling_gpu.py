@@ -94,9 +94,6 @@ def test_bilinear_goldens(dev):
   assert ims5[0].shape == tuple(g['out5'].shape) and wts5[0].shape[-1] == 1
   comp = sum(w * t for w, t in zip(wts5, ims5))   # taps are border-masked already
   np.testing.assert_allclose(comp.cpu().numpy(), g['out5'], rtol=1e-5, atol=1e-6)
-  with pytest.raises(RuntimeError, match='not differentiable'):
-    sampling.bilinear(T(g['imgs'], dev).requires_grad_(True), T(g['coords'], dev),
-                      compose=False)
 
 
 def test_bilinear_and_splat_gradients(dev):
@@ -121,6 +118,34 @@ def test_bilinear_and_splat_gradients(dev):
                              rtol=1e-4, atol=1e-5)
   np.testing.assert_allclose(c32.grad.cpu().numpy(), c64.grad.numpy(),
                              rtol=1e-4, atol=1e-4)
+
+  # compose=False (sampling.py:124-130): the taps scatter their gradient into the
+  # image, the weights give the coordinates' gradient (lsi_bilinear_taps_bwd)
+  tw = [rs.rand(2, 6, 7, 3) for _ in range(4)]
+  ww = [rs.rand(2, 6, 7, 1) for _ in range(4)]
+  i64 = torch.tensor(imgs, requires_grad=True)
+  c64 = torch.tensor(coords, requires_grad=True)
+  ims64, wts64 = TR.bilinear_taps(i64, c64)
+  sum((t * torch.tensor(a)).sum() + (w * torch.tensor(b)).sum()
+      for t, w, a, b in zip(ims64, wts64, tw, ww)).backward()
+  i32 = torch.tensor(imgs, dtype=torch.float32, device=dev, requires_grad=True)
+  c32 = torch.tensor(coords, dtype=torch.float32, device=dev, requires_grad=True)
+  ims32, wts32 = sampling.bilinear(i32, c32, compose=False)
+  for t, t64, w, w64 in zip(ims32, ims64, wts32, wts64):
+    np.testing.assert_allclose(t.detach().cpu().numpy(), t64.detach().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(w.detach().cpu().numpy(), w64.detach().numpy(), rtol=1e-4, atol=1e-5)
+  sum((t * T(a, dev).float()).sum() + (w * T(b, dev).float()).sum()
+      for t, w, a, b in zip(ims32, wts32, tw, ww)).backward()
+  np.testing.assert_allclose(i32.grad.cpu().numpy(), i64.grad.numpy(), rtol=1e-4, atol=1e-5)
+  np.testing.assert_allclose(c32.grad.cpu().numpy(), c64.grad.numpy(), rtol=1e-4, atol=1e-4)
+  # ... through the wrapper's leading dimensions, only the weights used
+  i5 = torch.tensor(imgs[None], dtype=torch.float32, device=dev)
+  c5 = torch.tensor(coords[None], dtype=torch.float32, device=dev, requires_grad=True)
+  _, w5 = sampling.bilinear_wrapper(i5, c5, compose=False)
+  (w5[3] * T(ww[3][None], dev).float()).sum().backward()
+  c64b = torch.tensor(coords, requires_grad=True)
+  (TR.bilinear_taps(torch.tensor(imgs), c64b)[1][3] * torch.tensor(ww[3])).sum().backward()
+  np.testing.assert_allclose(c5.grad[0].cpu().numpy(), c64b.grad.numpy(), rtol=1e-4, atol=1e-4)
 
   src = rs.rand(2, 6, 7, 3)
   init = rs.rand(2, 9, 11, 3)
