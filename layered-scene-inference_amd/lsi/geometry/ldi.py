@@ -146,7 +146,7 @@ def _stream_workspace(desc, dev):
   address baked in and relies on the counters the library left zero -- a call
   of the same geometry that needs more gets its own, larger buffer."""
   need = int(_C.lib().lsi_splat_workspace_bytes(ctypes.byref(desc)))
-  key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, desc.path,
+  key = (dev.index, _C.stream_ptr(dev), desc.path,
          desc.L, desc.B, desc.H, desc.W, desc.Ht, desc.Wt, desc.tune_rows,
          desc.flags & ~_C.LSI_WS_KEEP)
   with _WS_LOCK:
@@ -192,7 +192,7 @@ def stream_adapt(desc, dev):
   if (desc.path != _C.LSI_PATH_STREAM or not (desc.flags & _C.LSI_COMPOSE) or
       desc.tune_threads or desc.tune_rows or dev.type != 'cuda'):
     return None
-  key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, desc.L, desc.B, desc.H,
+  key = (dev.index, _C.stream_ptr(dev), desc.L, desc.B, desc.H,
          desc.W, desc.Ht, desc.Wt, desc.tune_window, desc.flags & _C.LSI_PACKED_RGBD,
          float(desc.trg_downsampling), float(desc.max_disp))
   with _WS_LOCK:

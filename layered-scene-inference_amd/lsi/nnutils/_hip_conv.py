@@ -191,7 +191,7 @@ def wgrad_supported(x, cin, cout, k, stride):
 def _wgrad_workspace(dev, nbytes):
   """Partial sums of the pixel blocks: per (device, stream) the largest buffer
   asked for so far; smaller ones stay alive (kernels in flight may use them)."""
-  key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+  key = (dev.index, _C.stream_ptr(dev))
   bufs = _WGRAD_WS.setdefault(key, [])
   if not bufs or bufs[-1].numel() * 4 < nbytes:
     bufs.append(torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=dev))
